@@ -1,0 +1,162 @@
+/*
+ * scanner_hip.h -- C-ABI of the MI355X spectrum-scan DSP path.
+ *
+ * The reference (wpats/scanner) has no FFI: its boundary is the C++ class
+ * surface ProcessSamples / SampleQueue.  This header is the cut just below
+ * those classes and just above the arithmetic: one `scn_plan` replaces what
+ * one consumer thread of the reference owns (process.cpp:101-107: per-thread
+ * input/output buffers, the FFT plan of fft.cpp:4-11, the window of
+ * process.cpp:14-21) plus the producer-side convert of
+ * messageQueue.h:190-237, batched over many buffers per submit.
+ *
+ * Conventions: every entry point returns an int status (SCN_OK == 0); nothing
+ * exits or throws across the boundary (the reference's device layers exit(1),
+ * e.g. hackRFSource.cpp:19-30 -- a library must not).  All pointers are plain
+ * host or device addresses; no C++ or torch types.  A plan is NOT thread-safe
+ * and owns one HIP stream: use one plan per consumer thread, as the reference
+ * uses one buffer set per thread.  Different plans may run concurrently.
+ */
+#ifndef SCANNER_HIP_H
+#define SCANNER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCN_ABI_VERSION 1
+
+/* status codes */
+enum {
+  SCN_OK = 0,
+  SCN_E_INVALID = 1,      /* bad argument / unsupported configuration */
+  SCN_E_HIP = 2,          /* a HIP runtime call failed (see scn_last_error) */
+  SCN_E_NOMEM = 3,
+  SCN_E_STATE = 4,        /* call out of order (collect before submit, ...) */
+  SCN_E_TRUNCATED = 5,    /* more hits than the caller's / the plan's capacity:
+                             n_hits holds the true total, the list the first ones */
+  SCN_E_NO_DEVICE = 6
+};
+
+/* Wire format of one IQ sample; values are messageQueue.h:31-37 SampleKind. */
+enum {
+  SCN_KIND_BYTE_COMPLEX = 1,  /* int8  I,Q interleaved (hackRFSource.cpp:261) */
+  SCN_KIND_SHORT = 2,         /* int16 planar: I[n] then Q[n] (sdrplaySource.cpp:197) */
+  SCN_KIND_SHORT_COMPLEX = 3, /* int16 I,Q interleaved (bladerfSource.cpp:297) */
+  SCN_KIND_FLOAT_COMPLEX = 4  /* float I,Q interleaved (airspySource.cpp:197) */
+};
+
+/* process.h:27-31 ProcessSamples::Mode */
+enum { SCN_MODE_TIME_DOMAIN = 1, SCN_MODE_FREQUENCY_DOMAIN = 2 };
+
+/* gr::fft::window::win_type subset; scan.cpp:215 only ever passes this one. */
+enum { SCN_WIN_BLACKMAN_HARRIS = 5, SCN_WIN_RECTANGULAR = 3 };
+
+/* output selection (flags) */
+enum {
+  SCN_OUT_SPECTRUM = 1u, /* keep the N-bin dB spectrum of every buffer */
+  SCN_OUT_HITS = 2u      /* threshold every in-band bin into the hit list */
+};
+
+/* One detection: a `freq %lu power_db %f` line of process.cpp:57. */
+typedef struct scn_hit {
+  uint64_t seq_id;  /* MessageHeader::m_sequenceId of the buffer */
+  uint32_t i;       /* fftshift-ordered bin index, the loop variable of process.cpp:46 */
+  float power_db;   /* magnitudes[j], j = (i + N/2) % N */
+  uint64_t freq_hz; /* uint64_t(start_frequency + i*bin_step), process.cpp:55-57 */
+} scn_hit;
+
+/* Everything the reference bakes into the ProcessSamples (process.h:74-85) and
+ * SampleQueue (messageQueue.h:141-146) constructors.  Zero-initialise, set
+ * struct_size = sizeof(scn_plan_desc), then fill; 0 picks the reference's
+ * constant where one exists. */
+typedef struct scn_plan_desc {
+  uint32_t struct_size;
+  uint32_t n;              /* sampleCount = FFT size (scan.cpp:85); 1024/2048/4096/8192 */
+  uint32_t sample_rate;    /* Hz (scan.cpp:92) */
+  uint32_t sample_kind;    /* SCN_KIND_* */
+  uint32_t enob;           /* effective bits (scan.cpp:138,183) */
+  uint32_t correct_dc;     /* SampleQueue correctDCOffset */
+  uint32_t window_type;    /* 0 -> SCN_WIN_BLACKMAN_HARRIS */
+  uint32_t mode;           /* 0 -> SCN_MODE_FREQUENCY_DOMAIN */
+  float threshold;         /* dB (scan.cpp:94) */
+  uint32_t dc_ignore_bins; /* 0 -> 4 (process.cpp:87); use SCN_DC_IGNORE_NONE for none */
+  double use_bandwidth;    /* 0 -> 0.75 (scan.cpp:65) */
+  uint32_t trigger_count;  /* 0 -> 1047 (process.cpp:62) */
+  uint32_t max_batch;      /* buffers per submit (>= 1) */
+  uint32_t max_hits;       /* device hit-list capacity per slot; 0 -> 64 per buffer */
+  uint32_t flags;          /* SCN_OUT_*; 0 -> SPECTRUM|HITS */
+  int32_t device_id;       /* HIP device ordinal */
+  uint32_t reserved[5];
+} scn_plan_desc;
+
+#define SCN_DC_IGNORE_NONE 0xffffffffu
+#define SCN_NUM_SLOTS 2
+
+typedef struct scn_plan scn_plan;
+
+const char *scn_error_name(int status);
+/* Text of the most recent failure on this thread ("" if none). */
+const char *scn_last_error(void);
+uint32_t scn_abi_version(void);
+
+int scn_plan_create(const scn_plan_desc *desc, scn_plan **out);
+int scn_plan_destroy(scn_plan *plan);
+
+/* Bytes of one raw buffer (N samples) in the plan's wire format. */
+int scn_buffer_bytes(const scn_plan *plan, size_t *bytes);
+
+/* The plan's pinned host staging slot (max_batch raw buffers back to back),
+ * slot in [0, SCN_NUM_SLOTS).  Replaces MemoryPool/SampleQueue storage
+ * (memoryPool.h:32-77): producers write device-format IQ straight into it.
+ * Plan-owned, valid until scn_plan_destroy; allocated on first use. */
+int scn_host_buffer(scn_plan *plan, int slot, void **ptr, size_t *bytes);
+
+/* Asynchronously copy n_buffers raw buffers from the pinned slot to the GPU
+ * and run convert -> window -> FFT -> dB -> threshold on the plan's stream.
+ * center_freqs / seq_ids (n_buffers each, host) are the MessageHeader fields
+ * m_frequency / m_sequenceId (messageQueue.h:25-26); seq_ids may be NULL
+ * (0,1,2,...).  Returns without waiting for the GPU. */
+int scn_submit(scn_plan *plan, int slot, uint32_t n_buffers,
+               const double *center_freqs, const uint64_t *seq_ids);
+
+/* Same, for raw IQ already resident in device memory (d_raw: n_buffers raw
+ * buffers back to back).  d_power_db: optional device destination for the
+ * dB spectra (n_buffers*N floats); NULL uses the plan's own buffer. */
+int scn_submit_device(scn_plan *plan, int slot, const void *d_raw,
+                      uint32_t n_buffers, const double *center_freqs,
+                      const uint64_t *seq_ids, float *d_power_db);
+
+/* Wait for the slot's submit and fetch results.  power_db: host, n_buffers*N
+ * floats in natural FFT bin order (bin 0 = DC), or NULL.  hits: host array of
+ * hit_cap entries or NULL; on return *n_hits is the total number of hits,
+ * the list is ordered by (buffer order, i) as a single-threaded reference run
+ * prints them.  trigger: n_buffers bytes, process_fft's return value
+ * (hits > trigger_count) per buffer, or NULL. */
+int scn_collect(scn_plan *plan, int slot, float *power_db, scn_hit *hits,
+                uint32_t hit_cap, uint32_t *n_hits, uint8_t *trigger);
+
+/* Wait for the slot's submit without copying anything back. */
+int scn_wait(scn_plan *plan, int slot);
+
+/* Plumbing for callers that keep results on the GPU or time the stream. */
+int scn_plan_stream(scn_plan *plan, void **hip_stream);
+int scn_device_spectrum(scn_plan *plan, int slot, float **d_power_db);
+/* Window coefficients the plan uses (host copy, n floats). */
+int scn_plan_window(const scn_plan *plan, float *w, uint32_t n);
+
+/* frequencyTable.cpp:9-37: centre frequencies f1 + i*step*fs covering
+ * [start, stop).  Writes min(count, cap) entries, returns count in *count.
+ * shard / n_shards select the contiguous index range a rank owns
+ * (n_shards = 1, shard = 0 for the whole table): *first is its first index. */
+int scn_frequency_table(uint32_t sample_rate, double start, double stop,
+                        double use_bandwidth, double dc_ignore_width,
+                        uint32_t shard, uint32_t n_shards, double *out,
+                        uint32_t cap, uint32_t *count, uint32_t *first);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

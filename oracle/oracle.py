@@ -1,0 +1,219 @@
+"""ctypes binding for the CPU oracle (oracle/libscn_oracle.so) + float64 goldens.
+
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED: the reference has no golden
+vectors and cannot be built here (see oracle/scn_oracle.h).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
+the product package scanner_amd never does.
+
+Two layers:
+  * ``Oracle`` -- the float32 C restatement of utility.cpp / process.cpp /
+    fft.cpp (the thing parity is checked against).
+  * ``ref64_*`` -- float64 numpy restatements of the third-party arithmetic
+    (FFTW DFT definition, GNU Radio Blackman-Harris, VOLK multiply) used to
+    pin BOTH the oracle and the HIP path to the mathematics.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libscn_oracle.so")
+
+KIND_BYTE_COMPLEX = 1
+KIND_SHORT = 2
+KIND_SHORT_COMPLEX = 3
+KIND_FLOAT_COMPLEX = 4
+
+HIT_DTYPE = np.dtype(
+    [("seq_id", "<u8"), ("i", "<u4"), ("power_db", "<f4"), ("freq_hz", "<u8")], align=True
+)
+assert HIT_DTYPE.itemsize == 24
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("sample_rate", C.c_uint32),
+        ("threshold", C.c_float),
+        ("use_bandwidth", C.c_double),
+        ("dc_ignore_bins", C.c_uint32),
+        ("trigger_count", C.c_uint32),
+    ]
+
+
+def build(force=False):
+    """Compile oracle/libscn_oracle.so with gcc (seconds)."""
+    src = os.path.join(_HERE, "scn_oracle.c")
+    if (
+        force
+        or not os.path.exists(_LIB)
+        or os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(src[:-2] + ".h"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        vp, u32, f32p = C.c_void_p, C.c_uint32, C.POINTER(C.c_float)
+        L.scn_oracle_short_complex_to_float_complex.argtypes = [vp, vp, u32, u32, C.c_int]
+        L.scn_oracle_short_planar_to_float_complex.argtypes = [vp, vp, vp, u32, u32, C.c_int]
+        L.scn_oracle_byte_complex_to_float_complex.argtypes = [vp, vp, u32, u32, C.c_int]
+        L.scn_oracle_window_blackman_harris.argtypes = [vp, u32]
+        L.scn_oracle_window_apply.argtypes = [vp, vp, u32]
+        L.scn_oracle_fft_create.restype = vp
+        L.scn_oracle_fft_create.argtypes = [u32]
+        L.scn_oracle_fft_destroy.argtypes = [vp]
+        L.scn_oracle_fft_process.argtypes = [vp, vp, vp]
+        L.scn_oracle_complex_to_magnitude.argtypes = [vp, vp, u32, C.c_int]
+        L.scn_oracle_process_fft.restype = u32
+        L.scn_oracle_process_fft.argtypes = [
+            C.POINTER(Params), vp, C.c_double, C.c_uint64, vp, vp, u32, C.POINTER(C.c_int)]
+        L.scn_oracle_time_domain.restype = C.c_int
+        L.scn_oracle_time_domain.argtypes = [vp, u32, C.c_float, f32p, f32p]
+        L.scn_oracle_frequency_table.restype = u32
+        L.scn_oracle_frequency_table.argtypes = [
+            u32, C.c_double, C.c_double, C.c_double, C.c_double, vp, u32]
+        L.scn_oracle_run_batch.restype = C.c_uint64
+        L.scn_oracle_run_batch.argtypes = [
+            C.POINTER(Params), C.c_int, u32, C.c_int, vp, u32, vp, vp, vp, vp, C.c_uint64, vp, u32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def raw_bytes_per_sample(kind):
+    return {KIND_BYTE_COMPLEX: 2, KIND_SHORT: 4, KIND_SHORT_COMPLEX: 4, KIND_FLOAT_COMPLEX: 8}[kind]
+
+
+class Oracle:
+    """The reference's ProcessSamples+SampleQueue arithmetic for one configuration.
+
+    Ctor arguments mirror ProcessSamples (process.h:74-85) and SampleQueue
+    (messageQueue.h:141-146)."""
+
+    def __init__(self, n, sample_rate=8000000, threshold=10.0, kind=KIND_FLOAT_COMPLEX, enob=12,
+                 correct_dc=False, use_bandwidth=0.75, dc_ignore_bins=4, trigger_count=1047):
+        self.n = int(n)
+        self.kind = kind
+        self.enob = enob
+        self.correct_dc = bool(correct_dc)
+        self.params = Params(self.n, int(sample_rate), float(threshold), float(use_bandwidth),
+                             int(dc_ignore_bins), int(trigger_count))
+
+    # -- single stages ------------------------------------------------------
+    def convert(self, raw):
+        """raw: int16 [n,2] / int16 [2,n] planar / int8 [n,2] / complex64 [n] -> complex64 [n]."""
+        n = self.n
+        out = np.empty(n, np.complex64)
+        L = lib()
+        if self.kind == KIND_FLOAT_COMPLEX:
+            return np.ascontiguousarray(raw, np.complex64).copy()
+        raw = np.ascontiguousarray(raw)
+        if self.kind == KIND_SHORT_COMPLEX:
+            assert raw.dtype == np.int16 and raw.size == 2 * n
+            L.scn_oracle_short_complex_to_float_complex(_p(raw), _p(out), n, self.enob, self.correct_dc)
+        elif self.kind == KIND_SHORT:
+            assert raw.dtype == np.int16 and raw.size == 2 * n
+            flat = raw.reshape(-1)
+            L.scn_oracle_short_planar_to_float_complex(
+                _p(flat), C.c_void_p(flat.ctypes.data + 2 * n), _p(out), n, self.enob, self.correct_dc)
+        elif self.kind == KIND_BYTE_COMPLEX:
+            assert raw.dtype == np.int8 and raw.size == 2 * n
+            L.scn_oracle_byte_complex_to_float_complex(_p(raw), _p(out), n, self.enob, self.correct_dc)
+        else:
+            raise ValueError(self.kind)
+        return out
+
+    def window(self):
+        w = np.empty(self.n, np.float32)
+        lib().scn_oracle_window_blackman_harris(_p(w), self.n)
+        return w
+
+    def fft(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        out = np.empty(self.n, np.complex64)
+        L = lib()
+        f = L.scn_oracle_fft_create(self.n)
+        assert f, "oracle FFT needs a power-of-two n"
+        L.scn_oracle_fft_process(f, _p(out), _p(x))
+        L.scn_oracle_fft_destroy(f)
+        return out
+
+    def magnitude(self, X, use_log2f=False):
+        X = np.ascontiguousarray(X, np.complex64)
+        out = np.empty(self.n, np.float32)
+        lib().scn_oracle_complex_to_magnitude(_p(X), _p(out), self.n, int(use_log2f))
+        return out
+
+    def time_domain(self, x, threshold=None):
+        x = np.ascontiguousarray(x, np.complex64)
+        mx, mn = C.c_float(), C.c_float()
+        thr = self.params.threshold if threshold is None else threshold
+        r = lib().scn_oracle_time_domain(_p(x), self.n, thr, C.byref(mx), C.byref(mn))
+        return bool(r), mx.value, mn.value
+
+    # -- whole path ---------------------------------------------------------
+    def run(self, raw, center_freqs=None, seq_ids=None, want_power=True, want_hits=True, threads=1):
+        """raw: array holding n_buffers buffers back to back in the kind's wire format.
+        Returns (power_db [B,n] or None, hits (HIT_DTYPE) or None, trigger uint8[B])."""
+        raw = np.ascontiguousarray(raw)
+        per = raw_bytes_per_sample(self.kind) * self.n
+        assert raw.nbytes % per == 0, (raw.nbytes, per)
+        nb = raw.nbytes // per
+        fc = np.zeros(nb, np.float64) if center_freqs is None else np.ascontiguousarray(center_freqs, np.float64)
+        seq = np.arange(nb, dtype=np.uint64) if seq_ids is None else np.ascontiguousarray(seq_ids, np.uint64)
+        assert fc.size == nb and seq.size == nb
+        power = np.empty((nb, self.n), np.float32) if want_power else None
+        trig = np.zeros(nb, np.uint8)
+        cap = nb * self.n if want_hits else 0
+        hits = np.zeros(cap, HIT_DTYPE) if want_hits else None
+        total = lib().scn_oracle_run_batch(
+            C.byref(self.params), self.kind, self.enob, int(self.correct_dc), _p(raw), nb, _p(fc), _p(seq),
+            _p(power), _p(hits), cap, _p(trig), threads)
+        if want_hits:
+            hits = hits[:total].copy()
+        return power, hits, trig
+
+
+def frequency_table(sample_rate, start, stop, use_bandwidth=0.75, dc_ignore_width=0.0):
+    """frequencyTable.cpp:9-37"""
+    L = lib()
+    cnt = L.scn_oracle_frequency_table(sample_rate, start, stop, use_bandwidth, dc_ignore_width, None, 0)
+    out = np.empty(cnt, np.float64)
+    L.scn_oracle_frequency_table(sample_rate, start, stop, use_bandwidth, dc_ignore_width, _p(out), cnt)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# float64 mathematics (pins the third-party arithmetic)
+# ---------------------------------------------------------------------------
+
+def ref64_window(n):
+    """4-term Blackman-Harris, symmetric, float64 ([3P] gr::fft::window::build)."""
+    k = np.arange(n, dtype=np.float64) / (n - 1)
+    return (0.35875 - 0.48829 * np.cos(2 * np.pi * k) + 0.14128 * np.cos(4 * np.pi * k)
+            - 0.01168 * np.cos(6 * np.pi * k))
+
+
+def ref64_spectrum(x_c64, window_f32):
+    """float64 evaluation of window -> DFT -> power for float32 inputs.
+    x_c64: [B,n] complex64 (already converted), window_f32: [n] float32.
+    Returns (X complex128 [B,n], linear power [B,n], dB = 5*log10(power))."""
+    x = np.asarray(x_c64).astype(np.complex128) * np.asarray(window_f32).astype(np.float64)
+    X = np.fft.fft(x, axis=-1)
+    P = X.real ** 2 + X.imag ** 2
+    with np.errstate(divide="ignore"):
+        dB = 5.0 * np.log10(P)
+    return X, P, dB

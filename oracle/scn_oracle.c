@@ -1,0 +1,439 @@
+/*
+ * scn_oracle.c -- CPU restatement of wpats/scanner's per-buffer DSP hot path
+ * (convert -> window -> FFT -> log magnitude -> fftshift-indexed threshold).
+ *
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see scn_oracle.h for why and
+ * for what pins it instead.  Each function names the reference lines it
+ * follows (paths relative to /root/reference).  Nothing here is copied: the
+ * reference delegates the FFT, the window and the multiply to FFTW / GNU
+ * Radio / VOLK, whose published definitions are restated with plain loops.
+ */
+#include "scn_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- K1: integer IQ -> complex float ---------------------------------- */
+
+/* utility.cpp:64-65 / :16-17: `int16_t max = 1 << (enob - 1); float onebymax
+ * = float(1.0/max);` -- the narrowing to int16_t wraps for enob == 16 (max =
+ * -32768, every sample sign-flipped) exactly as the reference does. */
+static float scale_for_i16(uint32_t enob) {
+  int16_t max = (int16_t)(uint16_t)(1u << ((enob - 1u) & 31u));
+  return (float)(1.0 / (double)max);
+}
+
+/* utility.cpp:40-41: same with `int8_t max` -- enob == 8 (the only value the
+ * reference uses for byte sources, scan.cpp:183,196) gives max = -128. */
+static float scale_for_i8(uint32_t enob) {
+  int8_t max = (int8_t)(uint8_t)(1u << ((enob - 1u) & 31u));
+  return (float)(1.0 / (double)max);
+}
+
+/* utility.cpp:77-78 / :25-26 / :49-50: `dc_real /= sampleCount` with int32_t
+ * /= uint32_t -- the dividend is converted to unsigned first, so a negative
+ * sum becomes a huge positive quotient.  Reproduced bit for bit. */
+static int32_t quirky_mean(int32_t sum, uint32_t n) {
+  return (int32_t)((uint32_t)sum / n);
+}
+
+static float conv1(int32_t s, int32_t dc, float scale) {
+  /* `float(source - dc) * onebymax`, utility.cpp:81-82; int arithmetic with
+   * two's-complement wrap (what the compiled reference does on overflow). */
+  int32_t d = (int32_t)((uint32_t)s - (uint32_t)dc);
+  return (float)d * scale;
+}
+
+void scn_oracle_short_complex_to_float_complex(const int16_t *src, float *dst,
+                                               uint32_t n, uint32_t enob,
+                                               int correct_dc) {
+  float scale = scale_for_i16(enob);
+  int32_t dc_re = 0, dc_im = 0;
+  if (correct_dc) {
+    uint32_t sr = 0, si = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      sr += (uint32_t)(int32_t)src[2 * i];
+      si += (uint32_t)(int32_t)src[2 * i + 1];
+    }
+    dc_re = quirky_mean((int32_t)sr, n);
+    dc_im = quirky_mean((int32_t)si, n);
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    dst[2 * i] = conv1(src[2 * i], dc_re, scale);
+    dst[2 * i + 1] = conv1(src[2 * i + 1], dc_im, scale);
+  }
+}
+
+void scn_oracle_short_planar_to_float_complex(const int16_t *re,
+                                              const int16_t *im, float *dst,
+                                              uint32_t n, uint32_t enob,
+                                              int correct_dc) {
+  float scale = scale_for_i16(enob);
+  int32_t dc_re = 0, dc_im = 0;
+  if (correct_dc) {
+    uint32_t sr = 0, si = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      sr += (uint32_t)(int32_t)re[i];
+      si += (uint32_t)(int32_t)im[i];
+    }
+    dc_re = quirky_mean((int32_t)sr, n);
+    dc_im = quirky_mean((int32_t)si, n);
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    dst[2 * i] = conv1(re[i], dc_re, scale);
+    dst[2 * i + 1] = conv1(im[i], dc_im, scale);
+  }
+}
+
+void scn_oracle_byte_complex_to_float_complex(const int8_t *src, float *dst,
+                                              uint32_t n, uint32_t enob,
+                                              int correct_dc) {
+  float scale = scale_for_i8(enob);
+  int32_t dc_re = 0, dc_im = 0;
+  if (correct_dc) {
+    uint32_t sr = 0, si = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      sr += (uint32_t)(int32_t)src[2 * i];
+      si += (uint32_t)(int32_t)src[2 * i + 1];
+    }
+    dc_re = quirky_mean((int32_t)sr, n);
+    dc_im = quirky_mean((int32_t)si, n);
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    dst[2 * i] = conv1(src[2 * i], dc_re, scale);
+    dst[2 * i + 1] = conv1(src[2 * i + 1], dc_im, scale);
+  }
+}
+
+/* ---- K2: window -------------------------------------------------------- */
+
+/* process.cpp:18 asks GNU Radio for WIN_BLACKMAN_HARRIS (the only type
+ * scan.cpp:215 ever passes).  [3P] restated from the published 4-term
+ * Blackman-Harris definition: symmetric, evaluated in double, stored float. */
+void scn_oracle_window_blackman_harris(float *w, uint32_t n) {
+  const double c0 = 0.35875, c1 = 0.48829, c2 = 0.14128, c3 = 0.01168;
+  const double pi = 3.14159265358979323846;
+  double m = (double)n - 1.0;
+  for (uint32_t i = 0; i < n; i++) {
+    double x = (double)i / m;
+    w[i] = (float)(c0 - c1 * cos(2.0 * pi * x) + c2 * cos(4.0 * pi * x) -
+                   c3 * cos(6.0 * pi * x));
+  }
+}
+
+/* process.cpp:28-34: in-place complex * real multiply. */
+void scn_oracle_window_apply(float *s, const float *w, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    s[2 * i] *= w[i];
+    s[2 * i + 1] *= w[i];
+  }
+}
+
+/* ---- K3: forward FFT ---------------------------------------------------- */
+
+/* fft.cpp:4-11: one cached out-of-place forward plan with its own in/out
+ * buffers.  [3P] FFTW's codelets are replaced by a plain float radix-2
+ * decimation-in-time FFT with a double-precision-generated twiddle table;
+ * same definition (sign -1, unnormalised, natural order). */
+struct scn_oracle_fft {
+  uint32_t n, log2n;
+  float *in, *out; /* fftwIn / fftwOut of fft.h:14-15 */
+  float *tw;       /* n/2 complex twiddles */
+  uint32_t *rev;
+};
+
+scn_oracle_fft *scn_oracle_fft_create(uint32_t n) {
+  if (n < 2 || (n & (n - 1)) != 0) return NULL;
+  scn_oracle_fft *f = (scn_oracle_fft *)calloc(1, sizeof(*f));
+  if (!f) return NULL;
+  f->n = n;
+  while ((1u << f->log2n) < n) f->log2n++;
+  f->in = (float *)aligned_alloc(64, sizeof(float) * 2 * n);
+  f->out = (float *)aligned_alloc(64, sizeof(float) * 2 * n);
+  f->tw = (float *)aligned_alloc(64, sizeof(float) * n);
+  f->rev = (uint32_t *)malloc(sizeof(uint32_t) * n);
+  const double pi = 3.14159265358979323846;
+  for (uint32_t k = 0; k < n / 2; k++) {
+    double a = -2.0 * pi * (double)k / (double)n;
+    f->tw[2 * k] = (float)cos(a);
+    f->tw[2 * k + 1] = (float)sin(a);
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < f->log2n; b++)
+      if (i & (1u << b)) r |= 1u << (f->log2n - 1 - b);
+    f->rev[i] = r;
+  }
+  return f;
+}
+
+void scn_oracle_fft_destroy(scn_oracle_fft *f) {
+  if (!f) return;
+  free(f->in);
+  free(f->out);
+  free(f->tw);
+  free(f->rev);
+  free(f);
+}
+
+static void fft_execute(scn_oracle_fft *f) {
+  const uint32_t n = f->n;
+  float *o = f->out;
+  const float *x = f->in;
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t r = f->rev[i];
+    o[2 * r] = x[2 * i];
+    o[2 * r + 1] = x[2 * i + 1];
+  }
+  for (uint32_t half = 1; half < n; half <<= 1) {
+    uint32_t step = n / (2 * half);
+    for (uint32_t base = 0; base < n; base += 2 * half) {
+      for (uint32_t k = 0; k < half; k++) {
+        float wr = f->tw[2 * k * step], wi = f->tw[2 * k * step + 1];
+        float *a = o + 2 * (base + k), *b = o + 2 * (base + k + half);
+        float tr = b[0] * wr - b[1] * wi;
+        float ti = b[0] * wi + b[1] * wr;
+        b[0] = a[0] - tr;
+        b[1] = a[1] - ti;
+        a[0] = a[0] + tr;
+        a[1] = a[1] + ti;
+      }
+    }
+  }
+}
+
+/* fft.cpp:20-25 */
+void scn_oracle_fft_process(scn_oracle_fft *f, float *dest, const float *src) {
+  memcpy(f->in, src, sizeof(float) * 2 * f->n);
+  fft_execute(f);
+  memcpy(dest, f->out, sizeof(float) * 2 * f->n);
+}
+
+/* ---- K4: log magnitude -------------------------------------------------- */
+
+/* utility.cpp:86-98: mag = sqrt(re*re + im*im) in float, then
+ * 10 * log2(mag) / log2(10) evaluated in double and stored as float. */
+void scn_oracle_complex_to_magnitude(const float *d, float *mag, uint32_t n,
+                                     int use_log2f) {
+  double log10v = log2(10.0);
+  for (uint32_t i = 0; i < n; i++) {
+    float re = d[2 * i], im = d[2 * i + 1];
+    float m = sqrtf(re * re + im * im);
+    if (use_log2f)
+      mag[i] = (float)(10 * (double)log2f(m) / log10v);
+    else
+      mag[i] = (float)(10 * log2((double)m) / log10v);
+  }
+}
+
+/* ---- K5: fftshift-indexed mask + threshold ------------------------------ */
+
+/* process.cpp:36-64 */
+uint32_t scn_oracle_process_fft(const scn_oracle_params *p, const float *fft,
+                                double fc, uint64_t seq_id, float *mag_out,
+                                scn_oracle_hit *hits, uint32_t cap,
+                                int *trigger) {
+  const uint32_t n = p->n;
+  double start_frequency = fc - (double)(p->sample_rate / 2u); /* :38 */
+  uint32_t bin_step = p->sample_rate / n;                      /* :39 */
+  uint32_t use_window = (uint32_t)(p->use_bandwidth * n / 2.0); /* :85 */
+  uint32_t dcw = p->dc_ignore_bins;                             /* :87 */
+  float *mag = mag_out ? mag_out : (float *)malloc(sizeof(float) * n);
+  scn_oracle_complex_to_magnitude(fft, mag, n, 0); /* :42 */
+  uint32_t count = 0;
+  uint32_t half = n / 2;
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t j = (i + half) % n;                       /* :47 */
+    if (j < dcw || (n - j) < dcw) continue;            /* :48 */
+    if (i < (half - use_window) || i > (half + use_window)) continue; /* :51 */
+    if (mag[j] > p->threshold) {                       /* :54 */
+      double frequency = start_frequency + (double)(uint32_t)(i * bin_step);
+      if (hits && count < cap) {
+        hits[count].seq_id = seq_id;
+        hits[count].i = i;
+        hits[count].power_db = mag[j];
+        hits[count].freq_hz = (uint64_t)frequency;     /* :57 */
+      }
+      count++;
+    }
+  }
+  if (trigger) *trigger = count > p->trigger_count;    /* :62 */
+  if (!mag_out) free(mag);
+  return count;
+}
+
+/* ---- K6: time-domain thresholding --------------------------------------- */
+
+/* process.cpp:203-237.  process.cpp includes <math.h>, so sqrt/log2 resolve
+ * to the float overloads there; the odd initial values of :207-208
+ * (numeric_limits<float>::min() is the smallest POSITIVE float) are kept. */
+int scn_oracle_time_domain(const float *s, uint32_t n, float thr,
+                           float *max_db, float *min_db) {
+  double log10v = log2(10.0);
+  float maxm = 1.17549435e-38f, minm = 3.40282347e+38f;
+  for (uint32_t i = 0; i < n; i++) {
+    float re = s[2 * i], im = s[2 * i + 1];
+    float m = sqrtf(re * re + im * im);
+    float db = (float)(10 * log2f(m) / log10v);
+    if (db > maxm) maxm = db;
+    if (db < minm) minm = db;
+  }
+  if (max_db) *max_db = maxm;
+  if (min_db) *min_db = minm;
+  return maxm >= thr;
+}
+
+/* ---- frequency table ----------------------------------------------------- */
+
+/* frequencyTable.cpp:9-37 */
+uint32_t scn_oracle_frequency_table(uint32_t fs, double start, double stop,
+                                    double use_bw, double dc_ignore,
+                                    double *out, uint32_t cap) {
+  double f1 = start + use_bw / 2 * fs;
+  double step = use_bw;
+  if (dc_ignore > 0) step = (use_bw - dc_ignore) / 2;
+  uint32_t count = 0;
+  if (stop == 0.0) {
+    count = 1;
+  } else {
+    while (f1 + count * step * (double)fs < stop) count++;
+  }
+  for (uint32_t i = 0; i < count && i < cap; i++)
+    out[i] = f1 + i * step * (double)fs;
+  return count;
+}
+
+/* ---- whole consumer sequence over a batch ------------------------------- */
+
+typedef struct {
+  const scn_oracle_params *p;
+  int kind;
+  uint32_t enob;
+  int correct_dc;
+  const uint8_t *raw;
+  size_t buf_bytes;
+  uint32_t lo, hi;
+  const double *fc;
+  const uint64_t *seq;
+  float *power_db;
+  uint8_t *trigger;
+  int want_hits;
+  scn_oracle_hit *hits; /* thread-private, grown on demand */
+  uint64_t n_hits, cap_hits;
+} worker_t;
+
+static void *worker_main(void *arg) {
+  worker_t *w = (worker_t *)arg;
+  const uint32_t n = w->p->n;
+  scn_oracle_fft *fft = scn_oracle_fft_create(n);
+  float *win = (float *)aligned_alloc(64, sizeof(float) * n);
+  float *conv = (float *)aligned_alloc(64, sizeof(float) * 2 * n);  /* m_floatComplex, messageQueue.h:58 */
+  float *msg = (float *)aligned_alloc(64, sizeof(float) * 2 * n);   /* pooled message, :73-75 */
+  float *in = (float *)aligned_alloc(64, sizeof(float) * 2 * n);    /* m_inputSamples[tid] */
+  float *out = (float *)aligned_alloc(64, sizeof(float) * 2 * n);   /* m_fftOutputBuffer[tid] */
+  float *mag = (float *)aligned_alloc(64, sizeof(float) * n);
+  scn_oracle_hit *tmp = (scn_oracle_hit *)malloc(sizeof(scn_oracle_hit) * n);
+  scn_oracle_window_blackman_harris(win, n);
+  for (uint32_t b = w->lo; b < w->hi; b++) {
+    const uint8_t *src = w->raw + (size_t)b * w->buf_bytes;
+    const float *fsrc = conv;
+    /* producer side: messageQueue.h:190-237 */
+    switch (w->kind) {
+      case SCN_ORACLE_KIND_BYTE_COMPLEX:
+        scn_oracle_byte_complex_to_float_complex((const int8_t *)src, conv, n, w->enob, w->correct_dc);
+        break;
+      case SCN_ORACLE_KIND_SHORT:
+        scn_oracle_short_planar_to_float_complex((const int16_t *)src, (const int16_t *)src + n, conv, n,
+                                                 w->enob, w->correct_dc);
+        break;
+      case SCN_ORACLE_KIND_SHORT_COMPLEX:
+        scn_oracle_short_complex_to_float_complex((const int16_t *)src, conv, n, w->enob, w->correct_dc);
+        break;
+      default:
+        fsrc = (const float *)src;
+        break;
+    }
+    memset(msg, 0, sizeof(float) * 2 * n); /* messageQueue.h:74 */
+    memcpy(msg, fsrc, sizeof(float) * 2 * n); /* :75 */
+    /* consumer side: process.cpp:293-299 */
+    memcpy(in, msg, sizeof(float) * 2 * n);
+    scn_oracle_window_apply(in, win, n);
+    scn_oracle_fft_process(fft, out, in);
+    int trig = 0;
+    float *mdst = w->power_db ? w->power_db + (size_t)b * n : mag;
+    uint32_t c = scn_oracle_process_fft(w->p, out, w->fc ? w->fc[b] : 0.0, w->seq ? w->seq[b] : b, mdst,
+                                        w->want_hits ? tmp : NULL, n, &trig);
+    if (w->trigger) w->trigger[b] = (uint8_t)trig;
+    if (w->want_hits && c) {
+      if (w->n_hits + c > w->cap_hits) {
+        w->cap_hits = (w->n_hits + c) * 2;
+        w->hits = (scn_oracle_hit *)realloc(w->hits, sizeof(scn_oracle_hit) * w->cap_hits);
+      }
+      memcpy(w->hits + w->n_hits, tmp, sizeof(scn_oracle_hit) * c);
+    }
+    w->n_hits += c;
+  }
+  free(tmp);
+  free(mag);
+  free(out);
+  free(in);
+  free(msg);
+  free(conv);
+  free(win);
+  scn_oracle_fft_destroy(fft);
+  return NULL;
+}
+
+uint64_t scn_oracle_run_batch(const scn_oracle_params *p, int kind, uint32_t enob, int correct_dc,
+                              const void *raw, uint32_t n_buffers, const double *fc, const uint64_t *seq,
+                              float *power_db, scn_oracle_hit *hits, uint64_t cap, uint8_t *trigger,
+                              uint32_t n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > n_buffers && n_buffers > 0) n_threads = n_buffers;
+  size_t per = 0;
+  switch (kind) {
+    case SCN_ORACLE_KIND_BYTE_COMPLEX: per = 2; break;
+    case SCN_ORACLE_KIND_SHORT:
+    case SCN_ORACLE_KIND_SHORT_COMPLEX: per = 4; break;
+    default: per = 8; break;
+  }
+  worker_t *ws = (worker_t *)calloc(n_threads, sizeof(worker_t));
+  pthread_t *th = (pthread_t *)calloc(n_threads, sizeof(pthread_t));
+  for (uint32_t t = 0; t < n_threads; t++) {
+    worker_t *w = &ws[t];
+    w->p = p;
+    w->kind = kind;
+    w->enob = enob;
+    w->correct_dc = correct_dc;
+    w->raw = (const uint8_t *)raw;
+    w->buf_bytes = per * p->n;
+    w->lo = (uint32_t)((uint64_t)n_buffers * t / n_threads);
+    w->hi = (uint32_t)((uint64_t)n_buffers * (t + 1) / n_threads);
+    w->fc = fc;
+    w->seq = seq;
+    w->power_db = power_db;
+    w->trigger = trigger;
+    w->want_hits = hits != NULL;
+  }
+  if (n_threads == 1) {
+    worker_main(&ws[0]);
+  } else {
+    for (uint32_t t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, worker_main, &ws[t]);
+    for (uint32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  }
+  uint64_t total = 0;
+  for (uint32_t t = 0; t < n_threads; t++) {
+    if (hits && ws[t].n_hits) {
+      uint64_t room = total < cap ? cap - total : 0;
+      uint64_t c = ws[t].n_hits < room ? ws[t].n_hits : room;
+      memcpy(hits + total, ws[t].hits, sizeof(scn_oracle_hit) * c);
+    }
+    total += ws[t].n_hits;
+    free(ws[t].hits);
+  }
+  free(th);
+  free(ws);
+  return total;
+}

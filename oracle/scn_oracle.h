@@ -1,0 +1,133 @@
+/*
+ * scn_oracle.h -- CPU restatement of wpats/scanner's per-buffer DSP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under scanner_amd/ (the product) may
+ * include, link or call this; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and there only as the checker / the
+ * timed CPU baseline.
+ *
+ * PARITY UNPINNED (see DESIGN.md "Oracle"): the reference holds no test,
+ * golden vector or fixture for this path, and it cannot be
+ * built in this image -- every hot-path source includes <fftw3.h>
+ * (fft.h:3), <volk/volk.h> (process.cpp:8), <gnuradio/fft/window.h>
+ * (process.h:5) or <boost/circular_buffer.hpp> (messageQueue.h:6), none of
+ * which exist here, and stand-in headers are not allowed.  The oracle is
+ * therefore pinned by mathematics instead: float64 DFT / window goldens
+ * (numpy/scipy) and hand-derivable known answers under tests/golden/.
+ *
+ * Third-party arithmetic restated here (absent from /root/reference, no
+ * version pinned by the reference -- its Makefile:10-11 links -lfftw3f -lvolk
+ * -lgnuradio-fft unversioned):
+ *   FFTW3 single precision  fftwf_plan_dft_1d(FFTW_FORWARD)/fftwf_execute
+ *       published definition: Y[k] = sum_n X[n] exp(-2 pi i n k / N),
+ *       unnormalised, natural order in and out.
+ *   VOLK  volk_32fc_32f_multiply_32fc_a: c[n] = a[n] * b[n], a complex, b real.
+ *   GNU Radio gr::fft::window::build(WIN_BLACKMAN_HARRIS, N, 0.0): 4-term
+ *       Blackman-Harris, coefficients 0.35875 / 0.48829 / 0.14128 / 0.01168,
+ *       symmetric (denominator N-1).
+ */
+#ifndef SCN_ORACLE_H
+#define SCN_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SampleKind values follow messageQueue.h:31-37. */
+enum {
+  SCN_ORACLE_KIND_BYTE_COMPLEX = 1,
+  SCN_ORACLE_KIND_SHORT = 2,          /* planar int16 I[], Q[] */
+  SCN_ORACLE_KIND_SHORT_COMPLEX = 3,  /* interleaved int16 */
+  SCN_ORACLE_KIND_FLOAT_COMPLEX = 4
+};
+
+typedef struct {
+  uint64_t seq_id;
+  uint32_t i;        /* fftshift-ordered loop index of process.cpp:46 */
+  float power_db;    /* magnitudes[j] */
+  uint64_t freq_hz;  /* uint64_t(frequency) of process.cpp:57 */
+} scn_oracle_hit;
+
+/* utility.cpp:58-84 */
+void scn_oracle_short_complex_to_float_complex(const int16_t *src /*[n][2]*/,
+                                               float *dst /*[n][2]*/,
+                                               uint32_t n, uint32_t enob,
+                                               int correct_dc);
+/* utility.cpp:9-32 */
+void scn_oracle_short_planar_to_float_complex(const int16_t *re,
+                                              const int16_t *im, float *dst,
+                                              uint32_t n, uint32_t enob,
+                                              int correct_dc);
+/* utility.cpp:34-56 */
+void scn_oracle_byte_complex_to_float_complex(const int8_t *src /*[n][2]*/,
+                                              float *dst, uint32_t n,
+                                              uint32_t enob, int correct_dc);
+
+/* process.cpp:14-21 (gr::fft::window::build, [3P]) */
+void scn_oracle_window_blackman_harris(float *w, uint32_t n);
+/* process.cpp:28-34 (volk_32fc_32f_multiply_32fc_a, [3P]) */
+void scn_oracle_window_apply(float *samples /*[n][2]*/, const float *w,
+                             uint32_t n);
+
+/* fft.cpp:4-25: plan + process.  n must be a power of two (the oracle's own
+ * radix-2 FFT; FFTW itself accepts any n). */
+typedef struct scn_oracle_fft scn_oracle_fft;
+scn_oracle_fft *scn_oracle_fft_create(uint32_t n);
+void scn_oracle_fft_destroy(scn_oracle_fft *f);
+/* memcpy in -> execute -> memcpy out, as fft.cpp:22-24 */
+void scn_oracle_fft_process(scn_oracle_fft *f, float *dest, const float *src);
+
+/* utility.cpp:86-98.  use_log2f = 0: double log2 (what utility.cpp gets via
+ * <cmath>); 1: log2f flavour. */
+void scn_oracle_complex_to_magnitude(const float *fft_data, float *mag,
+                                     uint32_t n, int use_log2f);
+
+/* process.cpp:36-64 with the ctor constants of process.cpp:85-87.
+ * Returns the number of hits found (all counted, at most cap stored);
+ * *trigger = (hits > trigger_count), process.cpp:62. */
+typedef struct {
+  uint32_t n;
+  uint32_t sample_rate;
+  float threshold;
+  double use_bandwidth;    /* 0.75, scan.cpp:65 */
+  uint32_t dc_ignore_bins; /* 4, process.cpp:87 */
+  uint32_t trigger_count;  /* 1047, process.cpp:62 */
+} scn_oracle_params;
+
+uint32_t scn_oracle_process_fft(const scn_oracle_params *p,
+                                const float *fft_data, double center_freq,
+                                uint64_t seq_id, float *mag_out /*[n], may be NULL*/,
+                                scn_oracle_hit *hits, uint32_t cap,
+                                int *trigger);
+
+/* process.cpp:203-237 (time-domain mode).  Returns 1 when max >= threshold. */
+int scn_oracle_time_domain(const float *samples, uint32_t n, float threshold,
+                           float *max_db, float *min_db);
+
+/* frequencyTable.cpp:9-37.  Returns the count; fills at most cap entries. */
+uint32_t scn_oracle_frequency_table(uint32_t sample_rate, double start,
+                                    double stop, double use_bandwidth,
+                                    double dc_ignore_width, double *out,
+                                    uint32_t cap);
+
+/* The consumer sequence of process.cpp:293-299 preceded by the producer-side
+ * convert of messageQueue.h:190-237, for a batch of buffers laid out back to
+ * back in `raw` (kind decides the element size; planar = I block then Q block
+ * per buffer).  power_db (n_buffers*n floats) and hits may be NULL.
+ * n_threads worker threads each own their plan and scratch (the reference's
+ * shared-plan race, process.h:65 + fft.cpp:22-24, is not reproduced); hits
+ * are returned sorted by (buffer, i).  Returns total hit count. */
+uint64_t scn_oracle_run_batch(const scn_oracle_params *p, int kind,
+                              uint32_t enob, int correct_dc, const void *raw,
+                              uint32_t n_buffers, const double *center_freqs,
+                              const uint64_t *seq_ids, float *power_db,
+                              scn_oracle_hit *hits, uint64_t cap,
+                              uint8_t *trigger, uint32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,459 @@
+// scn_api.hip -- the C-ABI of include/scanner_hip.h on top of the kernels.
+//
+// A plan owns: one HIP stream, the window and twiddle tables, and SCN_NUM_SLOTS
+// independent result slots (double buffering: the host fills / drains one slot while the
+// GPU works on the other -- the replacement for the reference's MemoryPool + bounded
+// queue, memoryPool.h:32-77 / messageQueue.h:65-91).  No call blocks on the GPU except
+// scn_collect / scn_wait / scn_plan_destroy.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/scanner_hip.h"
+#include "scn_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return status;
+}
+
+#define SCN_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(e_ == hipErrorOutOfMemory ? SCN_E_NOMEM : SCN_E_HIP, "%s failed: %s", #call, \
+                  hipGetErrorString(e_));                                                      \
+  } while (0)
+
+struct Slot {
+  void *h_raw = nullptr;            // pinned staging, max_batch raw buffers
+  void *d_raw = nullptr;            // device copy of the staging slot
+  float *d_power = nullptr;         // [max_batch][N] dB spectra (plan-owned destination)
+  float *cur_power = nullptr;       // destination of the pending submit
+  uint32_t *d_buf_hits = nullptr;   // [max_batch] hits per buffer
+  uint32_t *h_buf_hits = nullptr;   // pinned copy
+  ScnDevHit *d_hits = nullptr;      // [max_hits]
+  uint32_t *d_hit_counter = nullptr;
+  uint32_t *h_hit_counter = nullptr;  // pinned
+  uint32_t hit_base = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  uint32_t n_buffers = 0;
+  std::vector<double> fc;
+  std::vector<uint64_t> seq;
+  std::vector<ScnDevHit> host_hits;
+};
+
+}  // namespace
+
+struct scn_plan {
+  scn_plan_desc d;
+  int num_cus = 0;
+  hipStream_t stream = nullptr;
+  size_t buf_bytes = 0;
+  float scale = 1.0f;
+  uint32_t i_lo = 0, i_hi = 0;
+  std::vector<float> h_window;
+  float *d_window = nullptr;
+  scn_v2f *d_twiddle = nullptr;
+  Slot slot[SCN_NUM_SLOTS];
+};
+
+namespace {
+
+size_t bytes_per_sample(uint32_t kind) {
+  switch (kind) {
+    case SCN_KIND_BYTE_COMPLEX: return 2;
+    case SCN_KIND_SHORT:
+    case SCN_KIND_SHORT_COMPLEX: return 4;
+    case SCN_KIND_FLOAT_COMPLEX: return 8;
+    default: return 0;
+  }
+}
+
+// `int16_t max = 1 << (enob - 1); float onebymax = float(1.0/max);` (utility.cpp:64-65,
+// :16-17) and the int8_t flavour (utility.cpp:40-41), including the narrowing wrap that
+// makes enob == width give a negative scale.
+float convert_scale(uint32_t kind, uint32_t enob) {
+  uint32_t one = 1u << ((enob - 1u) & 31u);
+  if (kind == SCN_KIND_BYTE_COMPLEX) return (float)(1.0 / (double)(int8_t)(uint8_t)one);
+  if (kind == SCN_KIND_SHORT || kind == SCN_KIND_SHORT_COMPLEX) return (float)(1.0 / (double)(int16_t)(uint16_t)one);
+  return 1.0f;
+}
+
+// gr::fft::window::build(type, N, 0.0) as process.cpp:18 calls it ([3P]); 4-term
+// Blackman-Harris 0.35875/0.48829/0.14128/0.01168, symmetric, double -> float.
+void build_window(uint32_t type, uint32_t n, std::vector<float> &w) {
+  w.resize(n);
+  if (type == SCN_WIN_RECTANGULAR) {
+    std::fill(w.begin(), w.end(), 1.0f);
+    return;
+  }
+  const double pi = 3.14159265358979323846;
+  const double m = (double)n - 1.0;
+  for (uint32_t i = 0; i < n; i++) {
+    double x = (double)i / m;
+    w[i] = (float)(0.35875 - 0.48829 * std::cos(2.0 * pi * x) + 0.14128 * std::cos(4.0 * pi * x) -
+                   0.01168 * std::cos(6.0 * pi * x));
+  }
+}
+
+int check_slot(scn_plan *p, int slot) {
+  if (!p) return fail(SCN_E_INVALID, "null plan");
+  if (slot < 0 || slot >= SCN_NUM_SLOTS) return fail(SCN_E_INVALID, "slot %d out of range", slot);
+  return SCN_OK;
+}
+
+int ensure_slot_outputs(scn_plan *p, Slot &s) {
+  if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if ((p->d.flags & SCN_OUT_HITS) && !s.d_hits) {
+    SCN_HIP(hipMalloc(&s.d_hits, sizeof(ScnDevHit) * (size_t)p->d.max_hits));
+    SCN_HIP(hipMalloc(&s.d_buf_hits, sizeof(uint32_t) * p->d.max_batch));
+    SCN_HIP(hipMalloc(&s.d_hit_counter, sizeof(uint32_t)));
+    SCN_HIP(hipMemsetAsync(s.d_hit_counter, 0, sizeof(uint32_t), p->stream));
+    SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * p->d.max_batch, hipHostMallocDefault));
+    SCN_HIP(hipHostMalloc(&s.h_hit_counter, sizeof(uint32_t), hipHostMallocDefault));
+    s.hit_base = 0;
+  }
+  return SCN_OK;
+}
+
+int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const double *fc, const uint64_t *seq,
+                  float *d_power) {
+  int st = ensure_slot_outputs(p, s);
+  if (st) return st;
+  const uint32_t n = p->d.n;
+  if (!d_power && (p->d.flags & SCN_OUT_SPECTRUM)) {
+    if (!s.d_power) SCN_HIP(hipMalloc(&s.d_power, sizeof(float) * (size_t)n * p->d.max_batch));
+    d_power = s.d_power;
+  }
+  s.cur_power = d_power;
+  s.n_buffers = nb;
+  s.fc.assign(fc, fc + nb);
+  s.seq.resize(nb);
+  for (uint32_t b = 0; b < nb; b++) s.seq[b] = seq ? seq[b] : (uint64_t)b;
+
+  ScnFftArgs a;
+  memset(&a, 0, sizeof(a));
+  a.raw = d_raw;
+  a.window = p->d_window;
+  a.twiddle = p->d_twiddle;
+  a.power_db = d_power;
+  a.n_buffers = nb;
+  a.scale = p->scale;
+  a.threshold = p->d.threshold;
+  a.dc_ignore = p->d.dc_ignore_bins;
+  a.i_lo = p->i_lo;
+  a.i_hi = p->i_hi;
+  a.hit_counter = s.d_hit_counter;
+  a.hit_base = s.hit_base;
+  a.hit_cap = p->d.max_hits;
+  a.hits = s.d_hits;
+  a.per_buffer_hits = s.d_buf_hits;
+  const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
+  SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, p->stream));
+  if (hits && nb) {
+    SCN_HIP(hipMemcpyAsync(s.h_hit_counter, s.d_hit_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
+    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, p->stream));
+  }
+  SCN_HIP(hipEventRecord(s.done, p->stream));
+  s.pending = true;
+  return SCN_OK;
+}
+
+void free_slot(Slot &s) {
+  if (s.h_raw) (void)hipHostFree(s.h_raw);
+  if (s.d_raw) (void)hipFree(s.d_raw);
+  if (s.d_power) (void)hipFree(s.d_power);
+  if (s.d_buf_hits) (void)hipFree(s.d_buf_hits);
+  if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
+  if (s.d_hits) (void)hipFree(s.d_hits);
+  if (s.d_hit_counter) (void)hipFree(s.d_hit_counter);
+  if (s.h_hit_counter) (void)hipHostFree(s.h_hit_counter);
+  if (s.done) (void)hipEventDestroy(s.done);
+  s = Slot();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *scn_error_name(int status) {
+  switch (status) {
+    case SCN_OK: return "SCN_OK";
+    case SCN_E_INVALID: return "SCN_E_INVALID";
+    case SCN_E_HIP: return "SCN_E_HIP";
+    case SCN_E_NOMEM: return "SCN_E_NOMEM";
+    case SCN_E_STATE: return "SCN_E_STATE";
+    case SCN_E_TRUNCATED: return "SCN_E_TRUNCATED";
+    case SCN_E_NO_DEVICE: return "SCN_E_NO_DEVICE";
+    default: return "SCN_E_UNKNOWN";
+  }
+}
+
+const char *scn_last_error(void) { return g_last_error.c_str(); }
+
+uint32_t scn_abi_version(void) { return SCN_ABI_VERSION; }
+
+int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
+  if (!desc || !out) return fail(SCN_E_INVALID, "null argument");
+  *out = nullptr;
+  if (desc->struct_size != sizeof(scn_plan_desc))
+    return fail(SCN_E_INVALID, "scn_plan_desc.struct_size %u != %zu (ABI mismatch)", desc->struct_size,
+                sizeof(scn_plan_desc));
+  scn_plan_desc d = *desc;
+  if (!d.window_type) d.window_type = SCN_WIN_BLACKMAN_HARRIS;
+  if (!d.mode) d.mode = SCN_MODE_FREQUENCY_DOMAIN;
+  if (!d.dc_ignore_bins) d.dc_ignore_bins = 4;  // process.cpp:87
+  if (d.dc_ignore_bins == SCN_DC_IGNORE_NONE) d.dc_ignore_bins = 0;
+  if (d.use_bandwidth == 0.0) d.use_bandwidth = 0.75;  // scan.cpp:65
+  if (!d.trigger_count) d.trigger_count = 1047;        // process.cpp:62
+  if (!d.flags) d.flags = SCN_OUT_SPECTRUM | SCN_OUT_HITS;
+  if (!d.max_batch) return fail(SCN_E_INVALID, "max_batch must be >= 1");
+  if (!d.max_hits) d.max_hits = (uint32_t)std::min<uint64_t>((uint64_t)d.max_batch * 64u, 1u << 28);
+  if (bytes_per_sample(d.sample_kind) == 0) return fail(SCN_E_INVALID, "unknown sample_kind %u", d.sample_kind);
+  if (d.sample_kind != SCN_KIND_FLOAT_COMPLEX && (d.enob < 1 || d.enob > 32))
+    return fail(SCN_E_INVALID, "enob %u out of range", d.enob);
+  if (d.window_type != SCN_WIN_BLACKMAN_HARRIS && d.window_type != SCN_WIN_RECTANGULAR)
+    return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
+  if (d.mode != SCN_MODE_FREQUENCY_DOMAIN) return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
+  if (!scn_fft_size_supported(d.n)) return fail(SCN_E_INVALID, "unsupported FFT size %u", d.n);
+  if (d.sample_rate == 0) return fail(SCN_E_INVALID, "sample_rate must be > 0");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SCN_E_NO_DEVICE, "no HIP device visible");
+  if (d.device_id < 0 || d.device_id >= ndev) return fail(SCN_E_INVALID, "device_id %d out of range", d.device_id);
+  SCN_HIP(hipSetDevice(d.device_id));
+
+  scn_plan *p = new (std::nothrow) scn_plan();
+  if (!p) return fail(SCN_E_NOMEM, "out of host memory");
+  p->d = d;
+  p->buf_bytes = bytes_per_sample(d.sample_kind) * d.n;
+  p->scale = convert_scale(d.sample_kind, d.enob);
+  // process.cpp:85 m_useWindow = uint32_t(useBandWidth * numSamples / 2.0); :51 bounds in uint32
+  uint32_t use_window = (uint32_t)(d.use_bandwidth * d.n / 2.0);
+  p->i_lo = d.n / 2 - use_window;
+  p->i_hi = d.n / 2 + use_window;
+  build_window(d.window_type, d.n, p->h_window);
+
+  hipDeviceProp_t prop;
+  int st = SCN_OK;
+  do {
+#define SCN_TRY(call)                                                            \
+  if ((call) != hipSuccess) {                                                    \
+    st = fail(SCN_E_HIP, "%s failed: %s", #call, hipGetErrorString(hipGetLastError())); \
+    break;                                                                       \
+  }
+    SCN_TRY(hipGetDeviceProperties(&prop, d.device_id));
+    p->num_cus = prop.multiProcessorCount;
+    SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    SCN_TRY(hipMalloc(&p->d_window, sizeof(float) * d.n));
+    SCN_TRY(hipMalloc(&p->d_twiddle, sizeof(scn_v2f) * d.n));
+    std::vector<float> tw(2 * (size_t)d.n);
+    const double pi = 3.14159265358979323846;
+    for (uint32_t m = 0; m < d.n; m++) {
+      double a = -2.0 * pi * (double)m / (double)d.n;
+      tw[2 * m] = (float)std::cos(a);
+      tw[2 * m + 1] = (float)std::sin(a);
+    }
+    SCN_TRY(hipMemcpyAsync(p->d_window, p->h_window.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, p->stream));
+    SCN_TRY(hipMemcpyAsync(p->d_twiddle, tw.data(), sizeof(float) * 2 * d.n, hipMemcpyHostToDevice, p->stream));
+    SCN_TRY(hipStreamSynchronize(p->stream));
+#undef SCN_TRY
+  } while (0);
+  if (st != SCN_OK) {
+    scn_plan_destroy(p);
+    return st;
+  }
+  *out = p;
+  return SCN_OK;
+}
+
+int scn_plan_destroy(scn_plan *p) {
+  if (!p) return SCN_OK;
+  (void)hipSetDevice(p->d.device_id);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  for (int i = 0; i < SCN_NUM_SLOTS; i++) free_slot(p->slot[i]);
+  if (p->d_window) (void)hipFree(p->d_window);
+  if (p->d_twiddle) (void)hipFree(p->d_twiddle);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return SCN_OK;
+}
+
+int scn_buffer_bytes(const scn_plan *p, size_t *bytes) {
+  if (!p || !bytes) return fail(SCN_E_INVALID, "null argument");
+  *bytes = p->buf_bytes;
+  return SCN_OK;
+}
+
+int scn_host_buffer(scn_plan *p, int slot, void **ptr, size_t *bytes) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if (!ptr) return fail(SCN_E_INVALID, "null argument");
+  Slot &s = p->slot[slot];
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  size_t total = p->buf_bytes * p->d.max_batch;
+  if (!s.h_raw) SCN_HIP(hipHostMalloc(&s.h_raw, total, hipHostMallocDefault));
+  *ptr = s.h_raw;
+  if (bytes) *bytes = total;
+  return SCN_OK;
+}
+
+int scn_submit(scn_plan *p, int slot, uint32_t nb, const double *fc, const uint64_t *seq) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  Slot &s = p->slot[slot];
+  if (nb > p->d.max_batch) return fail(SCN_E_INVALID, "n_buffers %u > max_batch %u", nb, p->d.max_batch);
+  if (nb && !fc) return fail(SCN_E_INVALID, "center_freqs is null");
+  if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
+  if (!s.h_raw) return fail(SCN_E_STATE, "slot %d: scn_host_buffer was never called", slot);
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  if (!s.d_raw) SCN_HIP(hipMalloc(&s.d_raw, p->buf_bytes * p->d.max_batch));
+  if (nb) SCN_HIP(hipMemcpyAsync(s.d_raw, s.h_raw, p->buf_bytes * nb, hipMemcpyHostToDevice, p->stream));
+  return submit_common(p, s, s.d_raw, nb, fc, seq, nullptr);
+}
+
+int scn_submit_device(scn_plan *p, int slot, const void *d_raw, uint32_t nb, const double *fc, const uint64_t *seq,
+                      float *d_power_db) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  Slot &s = p->slot[slot];
+  if (nb > p->d.max_batch) return fail(SCN_E_INVALID, "n_buffers %u > max_batch %u", nb, p->d.max_batch);
+  if (nb && (!fc || !d_raw)) return fail(SCN_E_INVALID, "null argument");
+  if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  return submit_common(p, s, d_raw, nb, fc, seq, d_power_db);
+}
+
+int scn_wait(scn_plan *p, int slot) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  Slot &s = p->slot[slot];
+  if (!s.pending) return fail(SCN_E_STATE, "slot %d has nothing submitted", slot);
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  SCN_HIP(hipEventSynchronize(s.done));
+  return SCN_OK;
+}
+
+int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t hit_cap, uint32_t *n_hits,
+                uint8_t *trigger) {
+  int st = scn_wait(p, slot);
+  if (st) return st;
+  Slot &s = p->slot[slot];
+  s.pending = false;
+  const uint32_t n = p->d.n, nb = s.n_buffers;
+  const bool have_hits = (p->d.flags & SCN_OUT_HITS) != 0;
+  if ((hits || trigger) && !have_hits) return fail(SCN_E_INVALID, "plan was created without SCN_OUT_HITS");
+  if (power_db && !s.cur_power) return fail(SCN_E_INVALID, "plan was created without SCN_OUT_SPECTRUM");
+
+  int result = SCN_OK;
+  uint32_t total = 0;
+  if (have_hits && nb) {
+    total = *s.h_hit_counter - s.hit_base;  // wrapping
+    s.hit_base = *s.h_hit_counter;
+    if (trigger)
+      for (uint32_t b = 0; b < nb; b++) trigger[b] = s.h_buf_hits[b] > p->d.trigger_count;  // process.cpp:62
+    uint32_t on_device = std::min(total, p->d.max_hits);
+    if (hits && on_device) {
+      s.host_hits.resize(on_device);
+      SCN_HIP(hipMemcpyAsync(s.host_hits.data(), s.d_hits, sizeof(ScnDevHit) * on_device, hipMemcpyDeviceToHost,
+                             p->stream));
+      SCN_HIP(hipStreamSynchronize(p->stream));
+      // the order a single-threaded reference run prints: by buffer, then by i
+      std::sort(s.host_hits.begin(), s.host_hits.end(), [](const ScnDevHit &a, const ScnDevHit &b) {
+        return a.buffer != b.buffer ? a.buffer < b.buffer : a.i < b.i;
+      });
+      const uint32_t bin_step = p->d.sample_rate / n;  // process.cpp:39 (truncating)
+      const uint32_t out_n = std::min(on_device, hit_cap);
+      for (uint32_t k = 0; k < out_n; k++) {
+        const ScnDevHit &h = s.host_hits[k];
+        double start_frequency = s.fc[h.buffer] - (double)(p->d.sample_rate / 2u);  // process.cpp:38
+        double frequency = start_frequency + (double)(uint32_t)(h.i * bin_step);    // process.cpp:55
+        hits[k].seq_id = s.seq[h.buffer];
+        hits[k].i = h.i;
+        hits[k].power_db = h.power_db;
+        hits[k].freq_hz = (uint64_t)frequency;  // process.cpp:57
+      }
+    }
+    if (total > p->d.max_hits || (hits && total > hit_cap)) result = SCN_E_TRUNCATED;
+  } else if (trigger) {
+    memset(trigger, 0, nb);
+  }
+  if (n_hits) *n_hits = total;
+  if (power_db && nb) {
+    SCN_HIP(hipMemcpyAsync(power_db, s.cur_power, sizeof(float) * (size_t)n * nb, hipMemcpyDeviceToHost, p->stream));
+    SCN_HIP(hipStreamSynchronize(p->stream));
+  }
+  if (result == SCN_E_TRUNCATED) return fail(result, "%u hits, capacity %u (device) / %u (caller)", total, p->d.max_hits, hit_cap);
+  return SCN_OK;
+}
+
+int scn_plan_stream(scn_plan *p, void **hip_stream) {
+  if (!p || !hip_stream) return fail(SCN_E_INVALID, "null argument");
+  *hip_stream = (void *)p->stream;
+  return SCN_OK;
+}
+
+int scn_device_spectrum(scn_plan *p, int slot, float **d_power_db) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if (!d_power_db) return fail(SCN_E_INVALID, "null argument");
+  Slot &s = p->slot[slot];
+  if (!s.d_power) {
+    SCN_HIP(hipSetDevice(p->d.device_id));
+    SCN_HIP(hipMalloc(&s.d_power, sizeof(float) * (size_t)p->d.n * p->d.max_batch));
+  }
+  *d_power_db = s.d_power;
+  return SCN_OK;
+}
+
+int scn_plan_window(const scn_plan *p, float *w, uint32_t n) {
+  if (!p || !w) return fail(SCN_E_INVALID, "null argument");
+  if (n != p->d.n) return fail(SCN_E_INVALID, "n %u != plan n %u", n, p->d.n);
+  memcpy(w, p->h_window.data(), sizeof(float) * n);
+  return SCN_OK;
+}
+
+int scn_frequency_table(uint32_t sample_rate, double start, double stop, double use_bandwidth,
+                        double dc_ignore_width, uint32_t shard, uint32_t n_shards, double *out, uint32_t cap,
+                        uint32_t *count, uint32_t *first) {
+  if (!count || n_shards == 0 || shard >= n_shards) return fail(SCN_E_INVALID, "bad shard arguments");
+  // frequencyTable.cpp:17-29
+  double f1 = start + use_bandwidth / 2 * sample_rate;
+  double step = use_bandwidth;
+  if (dc_ignore_width > 0) step = (use_bandwidth - dc_ignore_width) / 2;
+  uint32_t total = 0;
+  if (stop == 0.0) {
+    total = 1;
+  } else {
+    if (!(step * (double)sample_rate > 0)) return fail(SCN_E_INVALID, "frequency step must be positive");
+    while (f1 + total * step * (double)sample_rate < stop) total++;
+  }
+  // contiguous index range [lo, hi) of this shard
+  uint32_t lo = (uint32_t)((uint64_t)total * shard / n_shards);
+  uint32_t hi = (uint32_t)((uint64_t)total * (shard + 1) / n_shards);
+  if (first) *first = lo;
+  *count = hi - lo;
+  if (out)
+    for (uint32_t i = lo; i < hi && i - lo < cap; i++) out[i - lo] = f1 + i * step * (double)sample_rate;  // :33
+  return SCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// scn_kernels.h -- internal interface between the C-ABI layer (scn_api.hip) and the
+// kernels (scn_kernels.hip).  Not installed; the public surface is include/scanner_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// same numbering as messageQueue.h:31-37 / SCN_KIND_*
+#define SCN_K_BYTE_COMPLEX 1
+#define SCN_K_SHORT 2
+#define SCN_K_SHORT_COMPLEX 3
+#define SCN_K_FLOAT_COMPLEX 4
+
+typedef float scn_v2f __attribute__((ext_vector_type(2)));
+
+// A hit as the kernel records it (unordered); the host adds seq_id / freq and sorts.
+struct ScnDevHit {
+  uint32_t buffer;  // index within the submit
+  uint32_t i;       // fftshift-ordered bin index (process.cpp:46)
+  float power_db;
+  uint32_t pad;
+};
+
+struct ScnFftArgs {
+  const void *raw;          // n_buffers raw buffers back to back
+  const float *window;      // [N]
+  const scn_v2f *twiddle;   // W_N^m = exp(-2 pi i m / N), m in [0, N)
+  float *power_db;          // [n_buffers][N] or nullptr
+  uint32_t n_buffers;
+  float scale;              // onebymax of utility.cpp:65 (1.0 for float input)
+  // K5 (process.cpp:46-62), all in the reference's uint32 arithmetic
+  float threshold;
+  uint32_t dc_ignore;       // m_dcIgnoreWindow
+  uint32_t i_lo, i_hi;      // halfSampleCount -/+ m_useWindow (wrapping)
+  uint32_t *hit_counter;    // monotonically increasing across submits
+  uint32_t hit_base;        // value of *hit_counter before this submit
+  uint32_t hit_cap;
+  ScnDevHit *hits;
+  uint32_t *per_buffer_hits;  // [n_buffers]
+};
+
+hipError_t scn_launch_fft(uint32_t n, int kind, bool correct_dc, bool hits, const ScnFftArgs &args,
+                          int num_cus, hipStream_t stream);
+bool scn_fft_size_supported(uint32_t n);

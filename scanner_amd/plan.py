@@ -1,0 +1,144 @@
+"""`Plan`: thin object wrapper over one scn_plan handle.
+
+Mirrors what one consumer thread of the reference owns (ProcessSamples + SampleQueue ctor
+arguments: process.h:74-85, messageQueue.h:141-146).  Device memory handed to
+``submit_device`` is a torch tensor (plumbing only); results come back as numpy arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class Plan:
+    def __init__(self, n, sample_rate=8000000, threshold=10.0, kind=capi.KIND_FLOAT_COMPLEX, enob=12,
+                 correct_dc=False, max_batch=1, use_bandwidth=0.75, dc_ignore_bins=4, trigger_count=1047,
+                 max_hits=0, flags=capi.OUT_SPECTRUM | capi.OUT_HITS, device_id=0,
+                 window_type=capi.WIN_BLACKMAN_HARRIS):
+        self._L = capi.lib()
+        d = capi.PlanDesc()
+        d.struct_size = C.sizeof(capi.PlanDesc)
+        d.n = n
+        d.sample_rate = int(sample_rate)
+        d.sample_kind = kind
+        d.enob = enob
+        d.correct_dc = int(bool(correct_dc))
+        d.window_type = window_type
+        d.mode = capi.MODE_FREQUENCY_DOMAIN
+        d.threshold = threshold
+        d.dc_ignore_bins = capi.DC_IGNORE_NONE if dc_ignore_bins == 0 else dc_ignore_bins
+        d.use_bandwidth = use_bandwidth
+        d.trigger_count = trigger_count
+        d.max_batch = max_batch
+        d.max_hits = max_hits
+        d.flags = flags
+        d.device_id = device_id
+        self.n, self.kind, self.max_batch, self.flags, self.device_id = n, kind, max_batch, flags, device_id
+        self.sample_rate = int(sample_rate)
+        self.use_bandwidth = use_bandwidth
+        self.buffer_bytes = capi.BYTES_PER_SAMPLE[kind] * n
+        self._h = C.c_void_p()
+        capi.check(self._L.scn_plan_create(C.byref(d), C.byref(self._h)), "scn_plan_create")
+        self._nb = [0] * capi.NUM_SLOTS
+        self._keep = [None] * capi.NUM_SLOTS
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.scn_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- staging ------------------------------------------------------------
+    def host_buffer(self, slot):
+        """The pinned staging slot as a writable uint8 numpy view (max_batch raw buffers)."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        capi.check(self._L.scn_host_buffer(self._h, slot, C.byref(ptr), C.byref(nbytes)), "scn_host_buffer")
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes.value,))
+
+    @staticmethod
+    def _meta(nb, center_freqs, seq_ids):
+        fc = np.zeros(nb, np.float64) if center_freqs is None else np.ascontiguousarray(center_freqs, np.float64)
+        seq = None if seq_ids is None else np.ascontiguousarray(seq_ids, np.uint64)
+        assert fc.size == nb and (seq is None or seq.size == nb)
+        return fc, seq
+
+    def submit(self, slot, n_buffers, center_freqs=None, seq_ids=None):
+        """Process the first n_buffers raw buffers of the pinned slot (async)."""
+        fc, seq = self._meta(n_buffers, center_freqs, seq_ids)
+        capi.check(self._L.scn_submit(self._h, slot, n_buffers, fc.ctypes.data_as(C.c_void_p),
+                                      None if seq is None else seq.ctypes.data_as(C.c_void_p)), "scn_submit")
+        self._nb[slot] = n_buffers
+
+    def submit_device(self, slot, d_raw, n_buffers=None, center_freqs=None, seq_ids=None, d_power_db=None):
+        """Process raw IQ already in device memory (a torch tensor or an int address)."""
+        if hasattr(d_raw, "data_ptr"):
+            nbytes = d_raw.numel() * d_raw.element_size()
+            if n_buffers is None:
+                n_buffers = nbytes // self.buffer_bytes
+            assert d_raw.is_contiguous() and nbytes >= n_buffers * self.buffer_bytes
+            ptr = d_raw.data_ptr()
+        else:
+            ptr = int(d_raw)
+        out_ptr = None
+        if d_power_db is not None:
+            assert d_power_db.is_contiguous() and d_power_db.numel() >= n_buffers * self.n
+            out_ptr = C.c_void_p(d_power_db.data_ptr())
+        fc, seq = self._meta(n_buffers, center_freqs, seq_ids)
+        capi.check(self._L.scn_submit_device(self._h, slot, C.c_void_p(ptr), n_buffers,
+                                             fc.ctypes.data_as(C.c_void_p),
+                                             None if seq is None else seq.ctypes.data_as(C.c_void_p), out_ptr),
+                   "scn_submit_device")
+        self._nb[slot] = n_buffers
+        self._keep[slot] = (d_raw, d_power_db)  # keep the tensors alive until collected
+
+    def wait(self, slot):
+        capi.check(self._L.scn_wait(self._h, slot), "scn_wait")
+
+    def collect(self, slot, want_power=True, want_hits=True, hit_cap=None):
+        """Block on the slot and return (power_db [B,n] | None, hits (HIT_DTYPE) | None, trigger uint8[B] | None).
+        Raises ScannerError(E_TRUNCATED) when more hits exist than hit_cap / the plan's max_hits."""
+        nb = self._nb[slot]
+        have_hits = bool(self.flags & capi.OUT_HITS)
+        power = np.empty((nb, self.n), np.float32) if (want_power and self.flags & capi.OUT_SPECTRUM) else None
+        want_hits = want_hits and have_hits
+        cap = (nb * 64 + 1024) if hit_cap is None else hit_cap
+        hits = np.zeros(cap, capi.HIT_DTYPE) if want_hits else None
+        trig = np.zeros(nb, np.uint8) if have_hits else None
+        n_hits = C.c_uint32()
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        st = self._L.scn_collect(self._h, slot, vp(power), vp(hits), cap if want_hits else 0, C.byref(n_hits),
+                                 vp(trig))
+        self._keep[slot] = None
+        if st == capi.E_TRUNCATED and want_hits and hit_cap is None:
+            # grow once to the true total and report everything the device kept
+            raise capi.ScannerError(st, "scn_collect", f"{n_hits.value} hits exceed capacity {cap}")
+        capi.check(st, "scn_collect")
+        self.last_n_hits = n_hits.value
+        if want_hits:
+            hits = hits[: min(n_hits.value, cap)]
+        return power, hits, trig
+
+    # -- plumbing -----------------------------------------------------------
+    @property
+    def stream_handle(self):
+        s = C.c_void_p()
+        capi.check(self._L.scn_plan_stream(self._h, C.byref(s)), "scn_plan_stream")
+        return s.value or 0
+
+    def window(self):
+        w = np.empty(self.n, np.float32)
+        capi.check(self._L.scn_plan_window(self._h, w.ctypes.data_as(C.c_void_p), self.n), "scn_plan_window")
+        return w

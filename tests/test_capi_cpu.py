@@ -1,0 +1,100 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, exports every symbol the header
+declares, and its GPU-free entry points behave.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from scanner_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "scanner_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scn_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    names = declared_symbols()
+    assert len(names) >= 14
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built_lib], text=True)
+    exported = set(re.findall(r" T (scn_\w+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, f"declared in scanner_hip.h but not exported: {missing}"
+    # ... and the ctypes twin binds exactly that set
+    assert sorted(capi.SYMBOLS) == names
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    for comp, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "cpp")):
+        f = tmp_path / f"t.{ext}"
+        f.write_text('#include "scanner_hip.h"\nint main(void){ scn_plan_desc d; d.struct_size = sizeof d; '
+                     'return (int)(sizeof(scn_hit) != 24) + (int)(d.struct_size != %d); }\n'
+                     % C.sizeof(capi.PlanDesc))
+        exe = tmp_path / f"t_{ext}"
+        subprocess.check_call([comp, std, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(f), "-o",
+                               str(exe)])
+        assert subprocess.call([str(exe)]) == 0, "struct layout differs between header and ctypes binding"
+
+
+def test_loads_and_reports_errors(built_lib):
+    L = capi.lib()
+    assert L.scn_abi_version() == capi.ABI_VERSION
+    assert L.scn_error_name(0) == b"SCN_OK" and L.scn_error_name(capi.E_TRUNCATED) == b"SCN_E_TRUNCATED"
+    assert L.scn_error_name(1234) == b"SCN_E_UNKNOWN"
+    h = C.c_void_p()
+    d = capi.PlanDesc()
+    assert L.scn_plan_create(C.byref(d), C.byref(h)) == capi.E_INVALID     # struct_size not set
+    assert b"struct_size" in L.scn_last_error()
+    assert L.scn_plan_create(None, C.byref(h)) == capi.E_INVALID
+    assert L.scn_plan_destroy(None) == capi.OK
+    d.struct_size = C.sizeof(capi.PlanDesc)
+    d.n, d.sample_rate, d.sample_kind, d.max_batch = 1000, 8000000, capi.KIND_FLOAT_COMPLEX, 4
+    assert L.scn_plan_create(C.byref(d), C.byref(h)) == capi.E_INVALID     # unsupported size, before any HIP call
+    d.n, d.sample_kind = 4096, 9
+    assert L.scn_plan_create(C.byref(d), C.byref(h)) == capi.E_INVALID
+
+
+def test_no_gpu_means_loud_failure(built_lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from scanner_amd import Plan
+
+    with pytest.raises(capi.ScannerError) as e:
+        Plan(4096, max_batch=1)
+    assert e.value.status in (capi.E_NO_DEVICE, capi.E_HIP)
+
+
+def test_frequency_table_and_shards(built_lib, oracle_mod):
+    ref = oracle_mod.frequency_table(8000000, 0.0, 16384 * 6e6)
+    first, whole = capi.frequency_table(8000000, 0.0, 16384 * 6e6)
+    assert first == 0 and np.array_equal(whole, ref)
+    parts = [capi.frequency_table(8000000, 0.0, 16384 * 6e6, shard=r, n_shards=8) for r in range(8)]
+    assert [p[0] for p in parts] == [2048 * r for r in range(8)]
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), ref)     # contiguous, rank-major
+    # ragged: 10 centres over 4 shards
+    ref2 = oracle_mod.frequency_table(8000000, 88e6, 88e6 + 10 * 6e6)
+    parts = [capi.frequency_table(8000000, 88e6, 88e6 + 10 * 6e6, shard=r, n_shards=4) for r in range(4)]
+    assert sum(len(p[1]) for p in parts) == len(ref2) == 10
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), ref2)
+    assert len(capi.frequency_table(8000000, 88e6, 0.0)[1]) == 1
+    with pytest.raises(capi.ScannerError):
+        capi.frequency_table(8000000, 0.0, 1e9, shard=2, n_shards=2)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under scanner_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "scanner_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "scn_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f

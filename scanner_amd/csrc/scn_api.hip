@@ -46,12 +46,12 @@ struct Slot {
   void *d_raw = nullptr;            // device copy of the staging slot
   float *d_power = nullptr;         // [max_batch][N] dB spectra (plan-owned destination)
   float *cur_power = nullptr;       // destination of the pending submit
-  uint32_t *d_buf_hits = nullptr;   // [max_batch] hits per buffer
-  uint32_t *h_buf_hits = nullptr;   // pinned copy
+  uint32_t *h_buf_hits = nullptr;   // [max_batch] hits per buffer: pinned host memory the kernel
+                                    // writes directly (one dword per buffer over PCIe), so a
+                                    // submit puts nothing but the kernel on the stream
   ScnDevHit *d_hits = nullptr;      // [max_hits]
-  uint32_t *d_hit_counter = nullptr;
-  uint32_t *h_hit_counter = nullptr;  // pinned
-  uint32_t hit_base = 0;
+  uint32_t *d_hit_counter = nullptr;  // device-side slot allocator, never reset
+  uint32_t hit_base = 0;              // its value before the pending submit (host-tracked)
   hipEvent_t done = nullptr;
   bool pending = false;
   uint32_t n_buffers = 0;
@@ -124,11 +124,9 @@ int ensure_slot_outputs(scn_plan *p, Slot &s) {
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   if ((p->d.flags & SCN_OUT_HITS) && !s.d_hits) {
     SCN_HIP(hipMalloc(&s.d_hits, sizeof(ScnDevHit) * (size_t)p->d.max_hits));
-    SCN_HIP(hipMalloc(&s.d_buf_hits, sizeof(uint32_t) * p->d.max_batch));
     SCN_HIP(hipMalloc(&s.d_hit_counter, sizeof(uint32_t)));
     SCN_HIP(hipMemsetAsync(s.d_hit_counter, 0, sizeof(uint32_t), p->stream));
     SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * p->d.max_batch, hipHostMallocDefault));
-    SCN_HIP(hipHostMalloc(&s.h_hit_counter, sizeof(uint32_t), hipHostMallocDefault));
     s.hit_base = 0;
   }
   return SCN_OK;
@@ -165,13 +163,9 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.hit_base = s.hit_base;
   a.hit_cap = p->d.max_hits;
   a.hits = s.d_hits;
-  a.per_buffer_hits = s.d_buf_hits;
+  a.per_buffer_hits = s.h_buf_hits;
   const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
   SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, p->stream));
-  if (hits && nb) {
-    SCN_HIP(hipMemcpyAsync(s.h_hit_counter, s.d_hit_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
-    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, p->stream));
-  }
   SCN_HIP(hipEventRecord(s.done, p->stream));
   s.pending = true;
   return SCN_OK;
@@ -181,11 +175,9 @@ void free_slot(Slot &s) {
   if (s.h_raw) (void)hipHostFree(s.h_raw);
   if (s.d_raw) (void)hipFree(s.d_raw);
   if (s.d_power) (void)hipFree(s.d_power);
-  if (s.d_buf_hits) (void)hipFree(s.d_buf_hits);
   if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
   if (s.d_hits) (void)hipFree(s.d_hits);
   if (s.d_hit_counter) (void)hipFree(s.d_hit_counter);
-  if (s.h_hit_counter) (void)hipHostFree(s.h_hit_counter);
   if (s.done) (void)hipEventDestroy(s.done);
   s = Slot();
 }
@@ -366,10 +358,11 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   int result = SCN_OK;
   uint32_t total = 0;
   if (have_hits && nb) {
-    total = *s.h_hit_counter - s.hit_base;  // wrapping
-    s.hit_base = *s.h_hit_counter;
-    if (trigger)
-      for (uint32_t b = 0; b < nb; b++) trigger[b] = s.h_buf_hits[b] > p->d.trigger_count;  // process.cpp:62
+    for (uint32_t b = 0; b < nb; b++) {
+      total += s.h_buf_hits[b];
+      if (trigger) trigger[b] = s.h_buf_hits[b] > p->d.trigger_count;  // process.cpp:62
+    }
+    s.hit_base += total;  // wrapping, like the device counter
     uint32_t on_device = std::min(total, p->d.max_hits);
     if (hits && on_device) {
       s.host_hits.resize(on_device);

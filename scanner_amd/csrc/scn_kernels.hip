@@ -282,14 +282,15 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, args.power_db ? 4u * N : 0u);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      db[r] = power_db(v[OUT16(r)]);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db[r]), rout, t * 4u, 1024u * r,
-                                            SCN_AUX_STORE);
+      // NB: never __builtin_bit_cast a vector ELEMENT (db[r]): clang reads element 0 for every r
+      const float d = power_db(v[OUT16(r)]);
+      db[r] = d;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, t * 4u, 1024u * r, SCN_AUX_STORE);
       if (HITS) {
         uint32_t j = t + 256 * r;
         uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
         bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
-        hitmask |= (keep && (db[r] > args.threshold)) ? (1u << r) : 0u;
+        hitmask |= (keep && (d > args.threshold)) ? (1u << r) : 0u;
       }
     }
     int wave_hits = 0;

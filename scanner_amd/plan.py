@@ -82,9 +82,19 @@ class Plan:
                                       None if seq is None else seq.ctypes.data_as(C.c_void_p)), "scn_submit")
         self._nb[slot] = n_buffers
 
-    def submit_device(self, slot, d_raw, n_buffers=None, center_freqs=None, seq_ids=None, d_power_db=None):
-        """Process raw IQ already in device memory (a torch tensor or an int address)."""
+    def submit_device(self, slot, d_raw, n_buffers=None, center_freqs=None, seq_ids=None, d_power_db=None,
+                      sync_producer=True):
+        """Process raw IQ already in device memory (a torch tensor or an int address).
+
+        The plan runs on its own non-blocking HIP stream.  With sync_producer (default) the
+        torch stream that produced `d_raw` is drained first, so a tensor that was just
+        written (`.cuda()`, a generator kernel) is complete before the plan reads it; pass
+        False when the caller has already ordered the two streams."""
         if hasattr(d_raw, "data_ptr"):
+            if sync_producer:
+                import torch
+
+                torch.cuda.current_stream(d_raw.device).synchronize()
             nbytes = d_raw.numel() * d_raw.element_size()
             if n_buffers is None:
                 n_buffers = nbytes // self.buffer_bytes

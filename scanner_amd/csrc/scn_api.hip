@@ -49,9 +49,10 @@ struct Slot {
   uint32_t *h_buf_hits = nullptr;   // [max_batch] hits per buffer: pinned host memory the kernel
                                     // writes directly (one dword per buffer over PCIe), so a
                                     // submit puts nothing but the kernel on the stream
-  ScnDevHit *d_hits = nullptr;      // [max_hits]
-  uint32_t *d_hit_counter = nullptr;  // device-side slot allocator, never reset
-  uint32_t hit_base = 0;              // its value before the pending submit (host-tracked)
+  ScnDevHit *d_hits = nullptr;      // [max_batch][hit_region] per-buffer hit regions
+  ScnDevHit *d_ov_hits = nullptr;   // [max_hits] overflow list (buffers with > hit_region hits)
+  uint32_t *d_ov_counter = nullptr; // device-side overflow slot allocator, never reset
+  uint32_t ov_base = 0;             // its value before the pending submit (host-tracked)
   hipEvent_t done = nullptr;
   bool pending = false;
   uint32_t n_buffers = 0;
@@ -69,6 +70,7 @@ struct scn_plan {
   size_t buf_bytes = 0;
   float scale = 1.0f;
   uint32_t i_lo = 0, i_hi = 0;
+  uint32_t hit_region = 0;  // hit slots each buffer owns before it spills to the overflow list
   std::vector<float> h_window;
   float *d_window = nullptr;
   scn_v2f *d_twiddle = nullptr;
@@ -123,11 +125,12 @@ int check_slot(scn_plan *p, int slot) {
 int ensure_slot_outputs(scn_plan *p, Slot &s) {
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   if ((p->d.flags & SCN_OUT_HITS) && !s.d_hits) {
-    SCN_HIP(hipMalloc(&s.d_hits, sizeof(ScnDevHit) * (size_t)p->d.max_hits));
-    SCN_HIP(hipMalloc(&s.d_hit_counter, sizeof(uint32_t)));
-    SCN_HIP(hipMemsetAsync(s.d_hit_counter, 0, sizeof(uint32_t), p->stream));
+    SCN_HIP(hipMalloc(&s.d_hits, sizeof(ScnDevHit) * (size_t)p->hit_region * p->d.max_batch));
+    SCN_HIP(hipMalloc(&s.d_ov_hits, sizeof(ScnDevHit) * (size_t)p->d.max_hits));
+    SCN_HIP(hipMalloc(&s.d_ov_counter, sizeof(uint32_t)));
+    SCN_HIP(hipMemsetAsync(s.d_ov_counter, 0, sizeof(uint32_t), p->stream));
     SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * p->d.max_batch, hipHostMallocDefault));
-    s.hit_base = 0;
+    s.ov_base = 0;
   }
   return SCN_OK;
 }
@@ -159,10 +162,12 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.dc_ignore = p->d.dc_ignore_bins;
   a.i_lo = p->i_lo;
   a.i_hi = p->i_hi;
-  a.hit_counter = s.d_hit_counter;
-  a.hit_base = s.hit_base;
-  a.hit_cap = p->d.max_hits;
   a.hits = s.d_hits;
+  a.hit_region = p->hit_region;
+  a.ov_hits = s.d_ov_hits;
+  a.ov_counter = s.d_ov_counter;
+  a.ov_base = s.ov_base;
+  a.ov_cap = p->d.max_hits;
   a.per_buffer_hits = s.h_buf_hits;
   const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
   SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, p->stream));
@@ -177,7 +182,8 @@ void free_slot(Slot &s) {
   if (s.d_power) (void)hipFree(s.d_power);
   if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
   if (s.d_hits) (void)hipFree(s.d_hits);
-  if (s.d_hit_counter) (void)hipFree(s.d_hit_counter);
+  if (s.d_ov_hits) (void)hipFree(s.d_ov_hits);
+  if (s.d_ov_counter) (void)hipFree(s.d_ov_counter);
   if (s.done) (void)hipEventDestroy(s.done);
   s = Slot();
 }
@@ -242,6 +248,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   uint32_t use_window = (uint32_t)(d.use_bandwidth * d.n / 2.0);
   p->i_lo = d.n / 2 - use_window;
   p->i_hi = d.n / 2 + use_window;
+  p->hit_region = std::max<uint32_t>(8u, std::min<uint32_t>(d.n, d.max_hits / (2u * d.max_batch)));
   build_window(d.window_type, d.n, p->h_window);
 
   hipDeviceProp_t prop;
@@ -358,25 +365,41 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   int result = SCN_OK;
   uint32_t total = 0;
   if (have_hits && nb) {
+    uint32_t in_regions = 0, overflow = 0;
     for (uint32_t b = 0; b < nb; b++) {
-      total += s.h_buf_hits[b];
-      if (trigger) trigger[b] = s.h_buf_hits[b] > p->d.trigger_count;  // process.cpp:62
+      const uint32_t c = s.h_buf_hits[b];
+      total += c;
+      in_regions += std::min(c, p->hit_region);
+      overflow += c > p->hit_region ? c - p->hit_region : 0u;
+      if (trigger) trigger[b] = c > p->d.trigger_count;  // process.cpp:62
     }
-    s.hit_base += total;  // wrapping, like the device counter
-    uint32_t on_device = std::min(total, p->d.max_hits);
-    if (hits && on_device) {
-      s.host_hits.resize(on_device);
-      SCN_HIP(hipMemcpyAsync(s.host_hits.data(), s.d_hits, sizeof(ScnDevHit) * on_device, hipMemcpyDeviceToHost,
+    s.ov_base += overflow;  // wrapping, like the device counter
+    const uint32_t ov_kept = std::min(overflow, p->d.max_hits);
+    if (hits && total) {
+      // fetch the per-buffer regions (one copy) and the overflow list, then restore the order a
+      // single-threaded reference run prints: by buffer, then by i
+      std::vector<ScnDevHit> &hh = s.host_hits;
+      std::vector<ScnDevHit> regions((size_t)nb * p->hit_region);
+      SCN_HIP(hipMemcpyAsync(regions.data(), s.d_hits, sizeof(ScnDevHit) * regions.size(), hipMemcpyDeviceToHost,
                              p->stream));
+      hh.resize((size_t)in_regions + ov_kept);
+      if (ov_kept)
+        SCN_HIP(hipMemcpyAsync(hh.data() + in_regions, s.d_ov_hits, sizeof(ScnDevHit) * ov_kept,
+                               hipMemcpyDeviceToHost, p->stream));
       SCN_HIP(hipStreamSynchronize(p->stream));
-      // the order a single-threaded reference run prints: by buffer, then by i
-      std::sort(s.host_hits.begin(), s.host_hits.end(), [](const ScnDevHit &a, const ScnDevHit &b) {
-        return a.buffer != b.buffer ? a.buffer < b.buffer : a.i < b.i;
+      size_t w = 0;
+      for (uint32_t b = 0; b < nb; b++) {
+        const uint32_t c = std::min(s.h_buf_hits[b], p->hit_region);
+        std::copy_n(regions.begin() + (size_t)b * p->hit_region, c, hh.begin() + w);
+        w += c;
+      }
+      std::sort(hh.begin(), hh.end(), [](const ScnDevHit &x, const ScnDevHit &y) {
+        return x.buffer != y.buffer ? x.buffer < y.buffer : x.i < y.i;
       });
       const uint32_t bin_step = p->d.sample_rate / n;  // process.cpp:39 (truncating)
-      const uint32_t out_n = std::min(on_device, hit_cap);
+      const uint32_t out_n = (uint32_t)std::min<size_t>(hh.size(), hit_cap);
       for (uint32_t k = 0; k < out_n; k++) {
-        const ScnDevHit &h = s.host_hits[k];
+        const ScnDevHit &h = hh[k];
         double start_frequency = s.fc[h.buffer] - (double)(p->d.sample_rate / 2u);  // process.cpp:38
         double frequency = start_frequency + (double)(uint32_t)(h.i * bin_step);    // process.cpp:55
         hits[k].seq_id = s.seq[h.buffer];
@@ -385,7 +408,8 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
         hits[k].freq_hz = (uint64_t)frequency;  // process.cpp:57
       }
     }
-    if (total > p->d.max_hits || (hits && total > hit_cap)) result = SCN_E_TRUNCATED;
+    if (overflow > p->d.max_hits || (hits && total > hit_cap)) result = SCN_E_TRUNCATED;
+
   } else if (trigger) {
     memset(trigger, 0, nb);
   }
@@ -394,7 +418,9 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
     SCN_HIP(hipMemcpyAsync(power_db, s.cur_power, sizeof(float) * (size_t)n * nb, hipMemcpyDeviceToHost, p->stream));
     SCN_HIP(hipStreamSynchronize(p->stream));
   }
-  if (result == SCN_E_TRUNCATED) return fail(result, "%u hits, capacity %u (device) / %u (caller)", total, p->d.max_hits, hit_cap);
+  if (result == SCN_E_TRUNCATED)
+    return fail(result, "%u hits: more than the caller's capacity %u or the device overflow capacity %u", total,
+                hit_cap, p->d.max_hits);
   return SCN_OK;
 }
 

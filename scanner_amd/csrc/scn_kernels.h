@@ -31,11 +31,16 @@ struct ScnFftArgs {
   float threshold;
   uint32_t dc_ignore;       // m_dcIgnoreWindow
   uint32_t i_lo, i_hi;      // halfSampleCount -/+ m_useWindow (wrapping)
-  uint32_t *hit_counter;    // monotonically increasing across submits
-  uint32_t hit_base;        // value of *hit_counter before this submit
-  uint32_t hit_cap;
-  ScnDevHit *hits;
-  uint32_t *per_buffer_hits;  // [n_buffers]
+  // hit records: buffer b owns slots [b*hit_region, (b+1)*hit_region) (allocated with an LDS
+  // atomic inside its workgroup -- no global atomics on the common path); a buffer with more
+  // hits spills the rest to the overflow list through one device-scope counter.
+  ScnDevHit *hits;            // [n_buffers][hit_region]
+  uint32_t hit_region;
+  ScnDevHit *ov_hits;         // [ov_cap]
+  uint32_t *ov_counter;       // monotonically increasing across submits
+  uint32_t ov_base;           // its value before this submit (host-tracked)
+  uint32_t ov_cap;
+  uint32_t *per_buffer_hits;  // [n_buffers] total hits of each buffer (pinned host memory)
 };
 
 hipError_t scn_launch_fft(uint32_t n, int kind, bool correct_dc, bool hits, const ScnFftArgs &args,

@@ -177,12 +177,12 @@ __device__ __forceinline__ int wave_sum(int v) {
 //   exchange 2   L2(c, q, p) = c*257 + q*16 + p      row pitch padded by 1
 //       write (pass 2): thread (p=hi, c=lo), fixed q      -> lanes 8 B apart mod 256 B
 //       read  (pass 3): thread (p=lo, q=hi), fixed c      -> 64 consecutive slots
-//   then the pass-2 twiddle table [q][c] (2 KiB) and 8 ints of per-wave scratch.
+//   then the pass-2 twiddle table [q][c] (2 KiB), 8 ints of per-wave scratch, the hit counter.
 // ------------------------------------------------------------------------------------
 #define SCN_L1_PITCH 272
 #define SCN_L2_PITCH 257
 #define SCN_LDS_EXCH (16 * SCN_L1_PITCH)  // complex slots (>= 16*257)
-#define SCN_LDS_BYTES_4096 (SCN_LDS_EXCH * 8 + 256 * 8 + 32)
+#define SCN_LDS_BYTES_4096 (SCN_LDS_EXCH * 8 + 256 * 8 + 48)
 
 template <int KIND, bool DC, bool HITS>
 __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
   v2f *lds_tw2 = lds + SCN_LDS_EXCH;                        // [16][16]
-  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + 256);    // [8]
+  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + 256);    // [8] DC-sum scratch
+  int *lds_hits = lds_cnt + 8;                              // hits of the buffer in flight
 
   const uint32_t t = threadIdx.x;
   const uint32_t hi = t >> 4, lo = t & 15;
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
   for (int a = 0; a < 16; a++) win[a] = args.window[256 * a + t];
   // pass-2 twiddles W_256^(c*q), table [q][c] shared by the workgroup
   lds_tw2[t] = args.twiddle[(16 * hi * lo) & (N - 1)];
+  if (t == 0) *lds_hits = 0;
   __syncthreads();
 
   v2f *w1 = lds + t;                                  // + p*272
@@ -293,7 +295,6 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
         hitmask |= (keep && (d > args.threshold)) ? (1u << r) : 0u;
       }
     }
-    int wave_hits = 0;
     if (HITS) {
       if (__ballot(hitmask != 0)) {  // rare: some lane of this wave holds a detection
 #pragma unroll 1
@@ -301,23 +302,30 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
           bool hit = (hitmask >> r) & 1u;
           unsigned long long m = __ballot(hit);
           if (!m) continue;
-          uint32_t cnt = (uint32_t)__popcll(m);
+          // slot inside this buffer's region: one LDS atomic per wave and r
           uint32_t base = 0;
-          if ((t & 63) == 0) base = atomicAdd(args.hit_counter, cnt) - args.hit_base;
+          if ((t & 63) == 0) base = (uint32_t)atomicAdd(lds_hits, (int)__popcll(m));
           base = __shfl(base, 0, 64);
           if (hit) {
             uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << (t & 63)) - 1ull));
             uint32_t j = t + 256 * r;
-            if (pos < args.hit_cap) args.hits[pos] = ScnDevHit{buf, j ^ (N / 2), db[r], 0u};
+            ScnDevHit rec = ScnDevHit{buf, j ^ (N / 2), db[r], 0u};
+            if (pos < args.hit_region) {
+              args.hits[(size_t)buf * args.hit_region + pos] = rec;
+            } else {  // region full: spill through the device-scope counter
+              uint32_t opos = atomicAdd(args.ov_counter, 1u) - args.ov_base;
+              if (opos < args.ov_cap) args.ov_hits[opos] = rec;
+            }
           }
-          wave_hits += (int)cnt;
         }
       }
-      if ((t & 63) == 0) lds_cnt[wave] = wave_hits;
     }
-    __syncthreads();  // exchange area free again; per-wave hit counts visible
+    __syncthreads();  // exchange area free again; this buffer's hit count complete
     if (HITS) {
-      if (t == 0) args.per_buffer_hits[buf] = (uint32_t)(lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3]);
+      if (t == 0) {
+        args.per_buffer_hits[buf] = (uint32_t)*lds_hits;
+        *lds_hits = 0;  // visible to the next buffer's recorders after its first barrier
+      }
     }
   }
 }

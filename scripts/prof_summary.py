@@ -1,0 +1,57 @@
+"""Summarise a scripts/prof.sh output directory: per-kernel stats + per-launch PMC averages."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+KER = "scn_fft"
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in find("trace/**/*kernel_stats.csv"):
+    for row in csv.DictReader(open(f)):
+        d = {k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
+        d["Name"] = d.get("Name", "")[:90]
+        if float(d.get("Percentage", 0) or 0) >= 0.5:
+            print(d)
+durs = []
+for f in find("trace/**/*kernel_trace.csv"):
+    for row in csv.DictReader(open(f)):
+        if KER in row.get("Kernel_Name", ""):
+            durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            meta = {k: row.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                                            "Workgroup_Size_X", "Grid_Size_X")}
+if durs:
+    durs.sort()
+    print(f"{KER}: n={len(durs)} avg={sum(durs)/len(durs)/1e3:.2f}us median={durs[len(durs)//2]/1e3:.2f}us "
+          f"min={durs[0]/1e3:.2f}us max={durs[-1]/1e3:.2f}us", meta)
+print("== PMC (average per launch of the FFT kernel) ==")
+summary = {}
+for f in find("pmc_*/**/*counter_collection.csv"):
+    acc = defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if KER in row.get("Kernel_Name", ""):
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, v in acc.items():
+        summary[k] = sum(v) / len(v)
+        print(f"{k:28s} {summary[k]:.4g}   (n={len(v)})")
+if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+    # exactly half of the bytes of a wide coalesced streaming read -> double it.
+    fetch = summary.get("FETCH_SIZE", 0) * 1024 * 2
+    write = summary.get("WRITE_SIZE", 0) * 1024
+    print(f"hbm_bytes_per_launch (FETCH_SIZE*1024*2 + WRITE_SIZE*1024) = {fetch + write:.4g}  (read {fetch:.4g}, write {write:.4g})")
+    json.dump({"hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write,
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 correction)"},
+              open(os.path.join(out, "pmc_traffic.json"), "w"))
+try:
+    print("bench line under trace:", open(os.path.join(out, "bench_trace.json")).read().strip()[-900:])
+except Exception:
+    pass

@@ -38,7 +38,12 @@ def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        # -fno-slp-vectorize: keep the FFT butterflies as scalar f32 ops.  On gfx950 a packed
+        # v_pk_*_f32 issues in the same 4 cycles as two scalar ops, and the SLP-packed stream
+        # needs ~180 extra v_mov/v_pk_mov per FFT to pair registers (measured: 801 vs 668 VALU
+        # instructions in the loop body).
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+               "-fno-slp-vectorize",
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -23,51 +23,71 @@
 // window coefficients a thread needs live in registers for the whole launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "scn_kernels.h"
 
-typedef scn_v2f v2f;
+#ifndef SCN_DEFAULT_VARIANT
+#define SCN_DEFAULT_VARIANT 0
+#endif
+
+typedef scn_v2f v2f;  // memory / LDS element (8 B)
 typedef float v16f __attribute__((ext_vector_type(16)));
+
+// Register-resident complex value.  Deliberately two independent floats, not an
+// ext_vector: on gfx950 a v_pk_*_f32 costs the same 4 issue cycles as two scalar ops, and
+// hipcc's packed complex multiply is 3 packed ops + a move + wait states (~14 cycles)
+// against 8 for mul/mul/fma/fma, so scalar arithmetic is the faster form here.
+struct cf {
+  float x, y;
+};
+__device__ __forceinline__ cf operator+(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf operator-(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf operator*(cf a, float s) { return cf{a.x * s, a.y * s}; }
+__device__ __forceinline__ cf from_v2f(v2f v) { return cf{v.x, v.y}; }
+__device__ __forceinline__ v2f to_v2f(cf c) { return v2f{c.x, c.y}; }
 
 namespace {
 
 // 10*log2(sqrt(P))/log2(10) == (5/log2(10)) * log2(P)
-__device__ __forceinline__ float power_db(v2f x) {
-  float p = x.x * x.x + x.y * x.y;
+__device__ __forceinline__ float power_db(cf x) {
+  float p = __builtin_fmaf(x.y, x.y, x.x * x.x);
   return 1.50514997831990597607f * __builtin_amdgcn_logf(p);
 }
 
-__device__ __forceinline__ v2f cmul(v2f a, v2f w) {
-  return v2f{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
+__device__ __forceinline__ cf cmul(cf a, cf w) {
+  return cf{__builtin_fmaf(-a.y, w.y, a.x * w.x), __builtin_fmaf(a.y, w.x, a.x * w.y)};
 }
+// a * (1 - i) * h  and  a * (-1 - i) * h  (W16^2, W16^6 with h = sqrt(1/2))
+__device__ __forceinline__ cf mul_w2(cf a, float h) { return cf{(a.x + a.y) * h, (a.y - a.x) * h}; }
+__device__ __forceinline__ cf mul_w6(cf a, float h) { return cf{(a.y - a.x) * h, -(a.x + a.y) * h}; }
 
 // (x0,x1,x2,x3) -> DFT4 with W4 = -i, results left in (x0,x1,x2,x3) = (X0,X1,X2,X3)
-__device__ __forceinline__ void radix4(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
-  v2f t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = x1 - x3;
-  v2f t3r = v2f{t3.y, -t3.x};  // -i * t3
+__device__ __forceinline__ void radix4(cf &x0, cf &x1, cf &x2, cf &x3) {
+  cf t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = x1 - x3;
   x0 = t0 + t2;
   x2 = t0 - t2;
-  x1 = t1 + t3r;
-  x3 = t1 - t3r;
+  x1 = cf{t1.x + t3.y, t1.y - t3.x};  // t1 - i*t3
+  x3 = cf{t1.x - t3.y, t1.y + t3.x};  // t1 + i*t3
 }
 
 // In-register 16-point forward DFT (radix 4 x 4).  On return X[k] sits in v[OUT16(k)].
 #define OUT16(k) (4 * ((k) & 3) + ((k) >> 2))
-__device__ __forceinline__ void fft16(v2f v[16]) {
+__device__ __forceinline__ void fft16(cf v[16]) {
   const float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
   const float H = 0.70710678118654752440f;
 #pragma unroll
   for (int n0 = 0; n0 < 4; n0++) radix4(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
   // v[n0 + 4*k0] *= W16^(n0*k0)
-  v[5] = cmul(v[5], v2f{C1, -S1});          // W^1
-  v[9] = cmul(v[9], v2f{H, -H});            // W^2
-  v[13] = cmul(v[13], v2f{S1, -C1});        // W^3
-  v[6] = cmul(v[6], v2f{H, -H});            // W^2
-  v[10] = v2f{v[10].y, -v[10].x};           // W^4 = -i
-  v[14] = cmul(v[14], v2f{-H, -H});         // W^6
-  v[7] = cmul(v[7], v2f{S1, -C1});          // W^3
-  v[11] = cmul(v[11], v2f{-H, -H});         // W^6
-  v[15] = cmul(v[15], v2f{-C1, S1});        // W^9
+  v[5] = cmul(v[5], cf{C1, -S1});           // W^1
+  v[9] = mul_w2(v[9], H);                   // W^2
+  v[13] = cmul(v[13], cf{S1, -C1});         // W^3
+  v[6] = mul_w2(v[6], H);                   // W^2
+  v[10] = cf{v[10].y, -v[10].x};            // W^4 = -i
+  v[14] = mul_w6(v[14], H);                 // W^6
+  v[7] = cmul(v[7], cf{S1, -C1});           // W^3
+  v[11] = mul_w6(v[11], H);                 // W^6
+  v[15] = cmul(v[15], cf{-C1, S1});         // W^9
 #pragma unroll
   for (int k0 = 0; k0 < 4; k0++) radix4(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
 }
@@ -79,8 +99,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint3
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
 
-#define SCN_AUX_LOAD 0   // cache policy of the streaming loads (2 = nt)
-#define SCN_AUX_STORE 0  // cache policy of the streaming stores
+// kernel variant bits (experiments are selected with the SCN_VARIANT environment variable)
+#define SCN_V_NT_LOAD 1   // non-temporal policy on the streaming loads
+#define SCN_V_NT_STORE 2  // non-temporal policy on the streaming stores
+#define SCN_V_PREFETCH 4  // software-prefetch the next buffer's raw samples into registers
 
 template <int KIND>
 struct RawLoader;
@@ -90,12 +112,13 @@ template <>
 struct RawLoader<SCN_K_FLOAT_COMPLEX> {
   static constexpr uint32_t kBufBytes(uint32_t n) { return 8u * n; }
   typedef v2f raw_t;
+  template <int AUX>
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
     // (the builtin returns a GCC-style vector; bit_cast, never assign it to an ext_vector)
-    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, t * 8u, idx0 * 8u, SCN_AUX_LOAD));
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, t * 8u, idx0 * 8u, AUX));
   }
   static __device__ __forceinline__ void ints(raw_t, int &re, int &im) { re = im = 0; }
-  static __device__ __forceinline__ v2f conv(raw_t r, int, int, float) { return r; }
+  static __device__ __forceinline__ cf conv(raw_t r, int, int, float) { return from_v2f(r); }
 };
 
 // int16 I,Q interleaved: 4 B per sample
@@ -103,19 +126,20 @@ template <>
 struct RawLoader<SCN_K_SHORT_COMPLEX> {
   static constexpr uint32_t kBufBytes(uint32_t n) { return 4u * n; }
   typedef int raw_t;
+  template <int AUX>
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
-    return __builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, idx0 * 4u, SCN_AUX_LOAD);
+    return __builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, idx0 * 4u, AUX);
   }
   static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
     re = (int)(short)(r & 0xffff);
     im = r >> 16;
   }
-  static __device__ __forceinline__ v2f conv(raw_t r, int dc_re, int dc_im, float scale) {
+  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im, float scale) {
     int re, im;
     ints(r, re, im);
     // float(source - dc) * onebymax, utility.cpp:81-82 (wrapping int arithmetic)
-    return v2f{(float)(int)((uint32_t)re - (uint32_t)dc_re) * scale,
-               (float)(int)((uint32_t)im - (uint32_t)dc_im) * scale};
+    return cf{(float)(int)((uint32_t)re - (uint32_t)dc_re) * scale,
+              (float)(int)((uint32_t)im - (uint32_t)dc_im) * scale};
   }
 };
 
@@ -124,18 +148,19 @@ template <>
 struct RawLoader<SCN_K_BYTE_COMPLEX> {
   static constexpr uint32_t kBufBytes(uint32_t n) { return 2u * n; }
   typedef int raw_t;
+  template <int AUX>
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
-    return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, SCN_AUX_LOAD);
+    return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, AUX);
   }
   static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
     re = (int)(signed char)(r & 0xff);
     im = (int)(signed char)((r >> 8) & 0xff);
   }
-  static __device__ __forceinline__ v2f conv(raw_t r, int dc_re, int dc_im, float scale) {
+  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im, float scale) {
     int re, im;
     ints(r, re, im);
-    return v2f{(float)(int)((uint32_t)re - (uint32_t)dc_re) * scale,
-               (float)(int)((uint32_t)im - (uint32_t)dc_im) * scale};
+    return cf{(float)(int)((uint32_t)re - (uint32_t)dc_re) * scale,
+              (float)(int)((uint32_t)im - (uint32_t)dc_im) * scale};
   }
 };
 
@@ -144,15 +169,16 @@ template <>
 struct RawLoader<SCN_K_SHORT> {
   static constexpr uint32_t kBufBytes(uint32_t n) { return 4u * n; }
   typedef int raw_t;
+  template <int AUX>
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t n, uint32_t t, uint32_t idx0) {
-    int re = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, SCN_AUX_LOAD);
-    int im = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, (n + idx0) * 2u, SCN_AUX_LOAD);
+    int re = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, AUX);
+    int im = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, (n + idx0) * 2u, AUX);
     return (re & 0xffff) | (im << 16);
   }
   static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
     RawLoader<SCN_K_SHORT_COMPLEX>::ints(r, re, im);
   }
-  static __device__ __forceinline__ v2f conv(raw_t r, int dc_re, int dc_im, float scale) {
+  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im, float scale) {
     return RawLoader<SCN_K_SHORT_COMPLEX>::conv(r, dc_re, dc_im, scale);
   }
 };
@@ -184,8 +210,11 @@ __device__ __forceinline__ int wave_sum(int v) {
 #define SCN_LDS_EXCH (16 * SCN_L1_PITCH)  // complex slots (>= 16*257)
 #define SCN_LDS_BYTES_4096 (SCN_LDS_EXCH * 8 + 256 * 8 + 48)
 
-template <int KIND, bool DC, bool HITS>
-__global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
+template <int KIND, bool DC, bool HITS, int VAR>
+__global__ __launch_bounds__(256, (VAR & SCN_V_PREFETCH) ? 3 : 4) void scn_fft4096_kernel(ScnFftArgs args) {
+  constexpr int AUX_LD = (VAR & SCN_V_NT_LOAD) ? 2 : 0;
+  constexpr int AUX_ST = (VAR & SCN_V_NT_STORE) ? 2 : 0;
+  constexpr bool PF = (VAR & SCN_V_PREFETCH) != 0;
   constexpr uint32_t N = 4096;
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -199,9 +228,9 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
   const uint32_t wave = t >> 6;
 
   // persistent per-thread constants: pass-1 twiddles W_4096^(t*p) and window taps
-  v2f tw1[16];
+  cf tw1[16];
 #pragma unroll
-  for (int p = 1; p < 16; p++) tw1[p] = args.twiddle[(t * p) & (N - 1)];
+  for (int p = 1; p < 16; p++) tw1[p] = from_v2f(args.twiddle[(t * p) & (N - 1)]);
   float win[16];
 #pragma unroll
   for (int a = 0; a < 16; a++) win[a] = args.window[256 * a + t];
@@ -216,13 +245,22 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
   v2f *r3 = lds + t;                                  // + c*257
   const v2f *tw2 = lds_tw2 + lo;                      // + q*16
 
+  typename L::raw_t raw[16];
+  if (PF && blockIdx.x < args.n_buffers) {
+    __amdgpu_buffer_rsrc_t r0 =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), L::kBufBytes(N));
+#pragma unroll
+    for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(r0, N, t, 256 * a);
+  }
+
   for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
     // ---- K1 + K2: load, convert, window ----
-    __amdgpu_buffer_rsrc_t rin =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), L::kBufBytes(N));
-    typename L::raw_t raw[16];
+    if (!PF) {
+      __amdgpu_buffer_rsrc_t rin =
+          make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), L::kBufBytes(N));
 #pragma unroll
-    for (int a = 0; a < 16; a++) raw[a] = L::load(rin, N, t, 256 * a);
+      for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(rin, N, t, 256 * a);
+    }
 
     int dc_re = 0, dc_im = 0;
     if (DC) {
@@ -248,34 +286,45 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
       dc_im = (int)((uint32_t)si / N);
     }
 
-    v2f v[16];
+    cf v[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, args.scale) * win[a];
+    if (PF) {
+      // the raw registers are free again: start fetching the next buffer of this workgroup now,
+      // its latency hides behind the three FFT passes below
+      const uint32_t nxt = buf + gridDim.x;
+      if (nxt < args.n_buffers) {
+        __amdgpu_buffer_rsrc_t rn =
+            make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)nxt * L::kBufBytes(N), L::kBufBytes(N));
+#pragma unroll
+        for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(rn, N, t, 256 * a);
+      }
+    }
 
     // ---- pass 1: DFT over a, twiddle W_N^(t p), scatter to row p ----
     fft16(v);
 #pragma unroll
     for (int p = 0; p < 16; p++) {
-      v2f y = v[OUT16(p)];
+      cf y = v[OUT16(p)];
       if (p) y = cmul(y, tw1[p]);
-      w1[p * SCN_L1_PITCH] = y;
+      w1[p * SCN_L1_PITCH] = to_v2f(y);
     }
     __syncthreads();
 
     // ---- pass 2: thread (p=hi, c=lo): DFT over b, twiddle W_256^(c q) ----
 #pragma unroll
-    for (int b = 0; b < 16; b++) v[b] = r1[b * 16];
+    for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 16]);
     fft16(v);
 #pragma unroll
-    for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], tw2[q * 16]);
+    for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * 16]));
     __syncthreads();  // every exchange-1 read done before the area is re-used
 #pragma unroll
-    for (int q = 0; q < 16; q++) w2[q * 16] = v[OUT16(q)];
+    for (int q = 0; q < 16; q++) w2[q * 16] = to_v2f(v[OUT16(q)]);
     __syncthreads();
 
     // ---- pass 3: thread (p=lo, q=hi): DFT over c; outputs k = t + 256 r ----
 #pragma unroll
-    for (int c = 0; c < 16; c++) v[c] = r3[c * SCN_L2_PITCH];
+    for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[c * SCN_L2_PITCH]);
     fft16(v);
 
     // ---- K4 + K5 ----
@@ -287,7 +336,7 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
       // NB: never __builtin_bit_cast a vector ELEMENT (db[r]): clang reads element 0 for every r
       const float d = power_db(v[OUT16(r)]);
       db[r] = d;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, t * 4u, 1024u * r, SCN_AUX_STORE);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, t * 4u, 1024u * r, AUX_ST);
       if (HITS) {
         uint32_t j = t + 256 * r;
         uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
@@ -333,29 +382,52 @@ __global__ __launch_bounds__(256, 4) void scn_fft4096_kernel(ScnFftArgs args) {
 // ------------------------------------------------------------------------------------
 // host-side launcher
 // ------------------------------------------------------------------------------------
-template <int KIND>
-static hipError_t launch4096_kind(const ScnFftArgs &a, bool dc, bool hits, int grid, hipStream_t s) {
+template <int KIND, int VAR>
+static hipError_t launch4096_var(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
   const size_t lds = SCN_LDS_BYTES_4096;
   void (*k)(ScnFftArgs) = nullptr;
-  if (dc && hits) k = scn_fft4096_kernel<KIND, true, true>;
-  else if (dc) k = scn_fft4096_kernel<KIND, true, false>;
-  else if (hits) k = scn_fft4096_kernel<KIND, false, true>;
-  else k = scn_fft4096_kernel<KIND, false, false>;
+  if (dc && hits) k = scn_fft4096_kernel<KIND, true, true, VAR>;
+  else if (dc) k = scn_fft4096_kernel<KIND, true, false, VAR>;
+  else if (hits) k = scn_fft4096_kernel<KIND, false, true, VAR>;
+  else k = scn_fft4096_kernel<KIND, false, false, VAR>;
+  int grid = num_cus * ((VAR & SCN_V_PREFETCH) ? 3 : 4);  // one resident wave of workgroups
+  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
+}
+
+static int experiment_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("SCN_VARIANT");
+    v = e ? atoi(e) & 7 : SCN_DEFAULT_VARIANT;
+  }
+  return v;
+}
+
+template <int KIND>
+static hipError_t launch4096_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
+  switch (experiment_variant()) {
+    case 0: return launch4096_var<KIND, 0>(a, dc, hits, num_cus, s);
+    case 1: return launch4096_var<KIND, 1>(a, dc, hits, num_cus, s);
+    case 2: return launch4096_var<KIND, 2>(a, dc, hits, num_cus, s);
+    case 3: return launch4096_var<KIND, 3>(a, dc, hits, num_cus, s);
+    case 4: return launch4096_var<KIND, 4>(a, dc, hits, num_cus, s);
+    case 5: return launch4096_var<KIND, 5>(a, dc, hits, num_cus, s);
+    case 6: return launch4096_var<KIND, 6>(a, dc, hits, num_cus, s);
+    default: return launch4096_var<KIND, 7>(a, dc, hits, num_cus, s);
+  }
 }
 
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus,
                           hipStream_t stream) {
   if (args.n_buffers == 0) return hipSuccess;
   if (n != 4096) return hipErrorInvalidValue;
-  int grid = num_cus * 4;
-  if ((uint32_t)grid > args.n_buffers) grid = (int)args.n_buffers;
   switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch4096_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, grid, stream);
-    case SCN_K_SHORT_COMPLEX: return launch4096_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, grid, stream);
-    case SCN_K_SHORT: return launch4096_kind<SCN_K_SHORT>(args, dc, hits, grid, stream);
-    case SCN_K_BYTE_COMPLEX: return launch4096_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, grid, stream);
+    case SCN_K_FLOAT_COMPLEX: return launch4096_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream);
+    case SCN_K_SHORT_COMPLEX: return launch4096_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream);
+    case SCN_K_SHORT: return launch4096_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream);
+    case SCN_K_BYTE_COMPLEX: return launch4096_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream);
     default: return hipErrorInvalidValue;
   }
 }

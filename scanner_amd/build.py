@@ -31,29 +31,32 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into one shared library; returns its path."""
-    if not force and not _stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """Compile every HIP source for gfx950 into one shared library; returns its path.
+    `defines` / `out` build an experiment variant (scripts/build_variants.py) next to the product library."""
+    target = out or LIB
+    if not out and not force and not _stale():
         return LIB
     objs = []
+    tag = "" if not out else "." + os.path.basename(out).replace(".so", "")
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
         # -fno-slp-vectorize: keep the FFT butterflies as scalar f32 ops.  On gfx950 a packed
         # v_pk_*_f32 issues in the same 4 cycles as two scalar ops, and the SLP-packed stream
         # needs ~180 extra v_mov/v_pk_mov per FFT to pair registers (measured: 801 vs 668 VALU
         # instructions in the loop body).
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-fno-slp-vectorize",
+               "-fno-slp-vectorize", *[f"-D{d}" for d in defines],
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

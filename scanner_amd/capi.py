@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscanner_hip.so")
+# SCN_LIB selects an experiment build (scripts/build_variants.py); the product library otherwise
+LIB_PATH = os.environ.get("SCN_LIB") or os.path.join(_HERE, "libscanner_hip.so")
 
 OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_TRUNCATED, E_NO_DEVICE = range(7)
 KIND_BYTE_COMPLEX, KIND_SHORT, KIND_SHORT_COMPLEX, KIND_FLOAT_COMPLEX = 1, 2, 3, 4

@@ -27,9 +27,6 @@
 
 #include "scn_kernels.h"
 
-#ifndef SCN_DEFAULT_VARIANT
-#define SCN_DEFAULT_VARIANT 0
-#endif
 
 typedef scn_v2f v2f;  // memory / LDS element (8 B)
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -99,10 +96,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint3
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
 
-// kernel variant bits (experiments are selected with the SCN_VARIANT environment variable)
-#define SCN_V_NT_LOAD 1   // non-temporal policy on the streaming loads
-#define SCN_V_NT_STORE 2  // non-temporal policy on the streaming stores
-#define SCN_V_PREFETCH 4  // software-prefetch the next buffer's raw samples into registers
+// Tunables (compile-time; scripts/build_variants.py builds one library per setting).
+// Cache-policy immediates of the buffer instructions on gfx950: bit0 = sc0, bit1 = nt, bit4 = sc1.
+#ifndef SCN_AUX_LD
+#define SCN_AUX_LD 0   // streaming loads: default policy (nt here loses when the stores are nt too)
+#endif
+#ifndef SCN_AUX_ST
+#define SCN_AUX_ST 2   // streaming dB stores: non-temporal -- the output is never re-read by the
+                       // kernel, keeping it out of L2/MALL is worth 15 % (87 -> 74 us on C2)
+#endif
+#ifndef SCN_PREFETCH
+#define SCN_PREFETCH 0 // 1: fetch the next buffer's raw samples into registers during the FFT
+                       //    (145 VGPRs -> 3 workgroups per CU)
+#endif
+#ifndef SCN_WG_PER_CU
+#define SCN_WG_PER_CU (SCN_PREFETCH ? 3 : 4)
+#endif
 
 template <int KIND>
 struct RawLoader;
@@ -210,11 +219,11 @@ __device__ __forceinline__ int wave_sum(int v) {
 #define SCN_LDS_EXCH (16 * SCN_L1_PITCH)  // complex slots (>= 16*257)
 #define SCN_LDS_BYTES_4096 (SCN_LDS_EXCH * 8 + 256 * 8 + 48)
 
-template <int KIND, bool DC, bool HITS, int VAR>
-__global__ __launch_bounds__(256, (VAR & SCN_V_PREFETCH) ? 3 : 4) void scn_fft4096_kernel(ScnFftArgs args) {
-  constexpr int AUX_LD = (VAR & SCN_V_NT_LOAD) ? 2 : 0;
-  constexpr int AUX_ST = (VAR & SCN_V_NT_STORE) ? 2 : 0;
-  constexpr bool PF = (VAR & SCN_V_PREFETCH) != 0;
+template <int KIND, bool DC, bool HITS>
+__global__ __launch_bounds__(256, SCN_WG_PER_CU) void scn_fft4096_kernel(ScnFftArgs args) {
+  constexpr int AUX_LD = SCN_AUX_LD;
+  constexpr int AUX_ST = SCN_AUX_ST;
+  constexpr bool PF = SCN_PREFETCH != 0;
   constexpr uint32_t N = 4096;
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -382,41 +391,18 @@ __global__ __launch_bounds__(256, (VAR & SCN_V_PREFETCH) ? 3 : 4) void scn_fft40
 // ------------------------------------------------------------------------------------
 // host-side launcher
 // ------------------------------------------------------------------------------------
-template <int KIND, int VAR>
-static hipError_t launch4096_var(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
+template <int KIND>
+static hipError_t launch4096_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
   const size_t lds = SCN_LDS_BYTES_4096;
   void (*k)(ScnFftArgs) = nullptr;
-  if (dc && hits) k = scn_fft4096_kernel<KIND, true, true, VAR>;
-  else if (dc) k = scn_fft4096_kernel<KIND, true, false, VAR>;
-  else if (hits) k = scn_fft4096_kernel<KIND, false, true, VAR>;
-  else k = scn_fft4096_kernel<KIND, false, false, VAR>;
-  int grid = num_cus * ((VAR & SCN_V_PREFETCH) ? 3 : 4);  // one resident wave of workgroups
+  if (dc && hits) k = scn_fft4096_kernel<KIND, true, true>;
+  else if (dc) k = scn_fft4096_kernel<KIND, true, false>;
+  else if (hits) k = scn_fft4096_kernel<KIND, false, true>;
+  else k = scn_fft4096_kernel<KIND, false, false>;
+  int grid = num_cus * SCN_WG_PER_CU;  // one resident wave of persistent workgroups
   if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
-}
-
-static int experiment_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("SCN_VARIANT");
-    v = e ? atoi(e) & 7 : SCN_DEFAULT_VARIANT;
-  }
-  return v;
-}
-
-template <int KIND>
-static hipError_t launch4096_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
-  switch (experiment_variant()) {
-    case 0: return launch4096_var<KIND, 0>(a, dc, hits, num_cus, s);
-    case 1: return launch4096_var<KIND, 1>(a, dc, hits, num_cus, s);
-    case 2: return launch4096_var<KIND, 2>(a, dc, hits, num_cus, s);
-    case 3: return launch4096_var<KIND, 3>(a, dc, hits, num_cus, s);
-    case 4: return launch4096_var<KIND, 4>(a, dc, hits, num_cus, s);
-    case 5: return launch4096_var<KIND, 5>(a, dc, hits, num_cus, s);
-    case 6: return launch4096_var<KIND, 6>(a, dc, hits, num_cus, s);
-    default: return launch4096_var<KIND, 7>(a, dc, hits, num_cus, s);
-  }
 }
 
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus,

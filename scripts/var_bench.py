@@ -23,7 +23,7 @@ import os
 flt = sys.argv[1].split(",") if len(sys.argv) > 1 else None
 if flt:
     variants = {k: v for k, v in variants.items() if any(f in k for f in flt)}
-tag = "V" + os.environ.get("SCN_VARIANT", "-")
+tag = os.path.basename(os.environ.get("SCN_LIB", "default")).replace("lib_", "").replace(".so", "")
 plans = {}
 for name, v in variants.items():
     plans[name] = Plan(n, 8000000, v["thr"], kind=v["kind"], enob=12 if v["kind"] != 1 else 8, max_batch=nb,
@@ -52,5 +52,5 @@ for rnd in range(5):
 for name, v in variants.items():
     r = sorted(res[name])
     bps = {4: 12, 3: 8, 1: 6}[v["kind"]] if v["flags"] & 1 else {4: 8, 3: 4, 1: 2}[v["kind"]]
-    print(f"{tag:4s} {name:28s} median {r[len(r)//2]:8.2f} us  min {r[0]:8.2f} us   {nb*n/r[len(r)//2]/1e3:7.1f} Gsamples/s  "
+    print(f"{tag:10s} {name:28s} median {r[len(r)//2]:8.2f} us  min {r[0]:8.2f} us   {nb*n/r[len(r)//2]/1e3:7.1f} Gsamples/s  "
           f"{nb*n*bps/r[len(r)//2]/1e6:6.2f} TB/s algorithmic")

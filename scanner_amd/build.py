@@ -59,5 +59,36 @@ def build(force=False, verbose=False, defines=(), out=None):
     return target
 
 
+HOST = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "libscanner_host.so")
+HOST_DEMO = os.path.join(HOST, "scan_synth")
+HOST_SOURCES = ["frequencyTable.cpp", "messageQueue.cpp", "signalSource.cpp", "syntheticSource.cpp",
+                "processInterface.cpp", "sampleBuffer.cpp", "process.cpp"]
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host library (kept SignalSource / SampleQueue / ProcessSamples surface on top of the
+    C-ABI) and the scan_synth driver.  Plain g++ -std=gnu++11 like the reference (Makefile:23)."""
+    build(force=False)
+    srcs = [os.path.join(HOST, f) for f in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")] + [LIB]
+    if force or not os.path.exists(HOST_LIB) or any(os.path.getmtime(d) > os.path.getmtime(HOST_LIB) for d in deps):
+        cmd = ["g++", "-std=gnu++11", "-O2", "-g", "-fPIC", "-shared", "-Wall", "-pthread", "-o", HOST_LIB] + srcs + \
+              ["-L" + HERE, "-lscanner_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    demo_src = os.path.join(HOST, "scan_synth.cpp")
+    if force or not os.path.exists(HOST_DEMO) or \
+            max(os.path.getmtime(demo_src), os.path.getmtime(HOST_LIB)) > os.path.getmtime(HOST_DEMO):
+        cmd = ["g++", "-std=gnu++11", "-O2", "-g", "-Wall", "-pthread", "-o", HOST_DEMO, demo_src, "-L" + HERE,
+               "-lscanner_host", "-lscanner_hip", "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_LIB, HOST_DEMO
+
+
 if __name__ == "__main__":
+    build_host(force="--force" in sys.argv, verbose=True)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,105 @@
+// messageQueue.h -- SampleQueue: the bounded producer/consumer queue between a SignalSource
+// and ProcessSamples.  Same public surface as the reference's MessageQueue<fftwf_complex>
+// (messageQueue.h:141-324) with one deliberate change of representation: a message holds the
+// RAW device-format samples (int8 / int16 / float IQ), not converted floats -- the
+// int->float convert (utility.cpp:9-84) runs on the GPU inside the fused kernel, so the
+// producer thread no longer does arithmetic (the reference converts in AppendSamples,
+// messageQueue.h:190-229).  Sequence ids, the discarded warm-up sweep, blocking behaviour,
+// the ack bit and the recycle ring follow the reference.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <list>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "scannerCompat.h"
+
+class SampleQueue {
+ public:
+  struct MessageHeader {  // messageQueue.h:15-28
+    enum MessageKind { Illegal = 0, ProcessData, WriteData, WriteDataAndStop, Free } m_kind;
+    uint32_t m_referenceCount;
+    double m_frequency;
+    uint64_t m_sequenceId;
+    time_t m_time;
+  };
+  enum SampleKind { Illegal = 0, ByteComplex, Short, ShortComplex, FloatComplex };  // messageQueue.h:31-37
+
+  class MessageType {  // Buffer<MessageHeader, T> of memoryPool.h:7-30
+   public:
+    MessageHeader m_header;
+    explicit MessageType(size_t bytes) : m_header(), m_raw(bytes) {}
+    MessageHeader &GetHeader() { return m_header; }
+    void *GetRawData() { return m_raw.data(); }
+    size_t GetRawBytes() const { return m_raw.size(); }
+    // Valid for FloatComplex queues only (raw == converted); integer kinds are converted on the GPU.
+    fftwf_complex *GetData() { return reinterpret_cast<fftwf_complex *>(m_raw.data()); }
+
+   private:
+    std::vector<unsigned char> m_raw;
+  };
+
+  SampleKind m_kind;
+
+  SampleQueue(SampleKind kind, uint32_t enob, uint32_t sampleCount, uint32_t bufferCount, bool correctDCOffset,
+              bool doWrite);
+  ~SampleQueue();
+
+  // messageQueue.h:190-237 (the four wire formats of the device front-ends)
+  void AppendSamples(int16_t *realSamples, int16_t *imagSamples, double centerFrequency, time_t time);
+  void AppendSamples(int16_t shortComplexSamples[][2], double centerFrequency, time_t time);
+  void AppendSamples(int8_t (*byteComplexSamples)[2], double centerFrequency, time_t time);
+  void AppendSamples(fftwf_complex *floatComplexSamples, double centerFrequency, time_t time);
+
+  MessageType *GetNextSamples();     // blocking; nullptr once done and empty (messageQueue.h:239-257)
+  MessageType *TryGetNextSamples();  // non-blocking variant used to fill a batch; nullptr if empty
+  void MessageProcessed(MessageType *message);  // messageQueue.h:259-273
+
+  // Triggered capture (messageQueue.h:275-288) is outside this build's scope: the calls are
+  // accepted and recorded so the trigger state machine of ProcessSamples runs unchanged.
+  void BeginWrite(uint64_t startSequenceId, std::string fileName);
+  void EndWrite(uint64_t sequenceId);
+
+  void SetIsDone();
+  bool GetIsDone();
+  bool ReceivedAck();
+  void SendAck();
+  void ClearAck();
+
+  // what a consumer needs to create its scn_plan
+  uint32_t GetEnob() const { return m_enob; }
+  uint32_t GetSampleCount() const { return m_sampleCount; }
+  bool GetCorrectDCOffset() const { return m_correctDCOffset; }
+  size_t GetBufferBytes() const { return m_bufferBytes; }
+  uint32_t GetBufferCount() const { return m_bufferCount; }
+  uint64_t GetWriteStartSequenceId() const { return m_writeStart; }
+  uint64_t GetWriteEndSequenceId() const { return m_writeEnd; }
+
+ private:
+  void SynchronizedAppend(const void *a, size_t aBytes, const void *b, size_t bBytes, double centerFrequency,
+                          time_t time);
+  MessageType *Allocate();
+  void Free(MessageType *m);
+
+  uint32_t m_enob, m_sampleCount, m_bufferCount;
+  bool m_correctDCOffset, m_doWrite;
+  size_t m_bufferBytes;
+  std::deque<MessageType *> m_buffer;  // front = newest (push_front / pop_back like the reference)
+  std::deque<MessageType *> m_history; // processed messages kept for capture (bufferCount/10)
+  size_t m_historyCapacity;
+  std::list<MessageType *> m_free;     // MemoryPool (memoryPool.h:32-77), 1.1 x depth
+  uint32_t m_poolSize;
+  std::mutex m_mutex, m_poolMutex, m_historyMutex;
+  std::condition_variable m_notEmpty, m_notFull, m_poolNotEmpty;
+  uint64_t m_nextSequenceId;
+  uint32_t m_iterationCount;
+  bool m_done;
+  std::atomic<bool> m_acknowledged;
+  uint64_t m_writeStart, m_writeEnd;
+};

@@ -1,0 +1,69 @@
+// process.h -- ProcessSamples: the consumer side.  Same constructor, modes and entry points
+// as the reference (process.h:24-93); the per-buffer CPU work of ThreadWorker
+// (process.cpp:293-299: memcpy, FFTWindow::apply, FFT::process, process_fft) is replaced by
+// one scn_plan per consumer thread: each thread drains up to a batch of queued messages into
+// a pinned staging slot, submits it to the GPU and, while that runs, fills the other slot.
+// The stdout protocol ("Start scan at", "freq %lu power_db %f", thread start/stop lines) and
+// the ack / trigger bookkeeping per message follow the reference.
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "messageQueue.h"
+#include "scannerCompat.h"
+
+class SampleBuffer;
+class SignalSource;
+struct scn_hit;
+
+class ProcessSamples {
+ public:
+  enum Mode { Illegal, TimeDomain, FrequencyDomain };  // process.h:27-31
+
+  ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_t enob, float threshold,
+                 gr::fft::window::win_type windowType, Mode mode, uint32_t threadCount = 1,
+                 std::string fileNameBase = "", double useBandWidth = 0.75, double dcIgnoreWidth = 0.0,
+                 uint32_t preTrigger = 2, uint32_t postTrigger = 4);
+  ~ProcessSamples();
+
+  // One-shot on a single int16 buffer (process.cpp:131-144).  Unlike the reference -- where
+  // this dereferences a null header -- it reports against the given centre frequency.
+  void Run(int16_t sample_buffer[][2], uint32_t centerFrequency);
+  bool StartProcessing(SampleQueue &sampleQueue);  // blocks until the queue is done and drained
+
+  // knobs the reference hard-codes; set before StartProcessing
+  void SetMaxBatch(uint32_t maxBatch) { m_maxBatch = maxBatch; }
+  void SetDevice(int firstDevice) { m_firstDevice = firstDevice; }
+  uint64_t GetHitCount() const { return m_hitCount; }
+  uint64_t GetBufferCount() const { return m_bufferCount; }
+
+  bool m_writeData;
+
+ private:
+  void ThreadWorker(uint32_t threadId);
+  void TimeToString(time_t time, char *buffer, uint32_t length);
+  std::string GenerateFileName(std::string fileNameBase, time_t startTime, double_t centerFrequency);
+  void WriteSamplesToFile(uint64_t sequenceId, double centerFrequency);
+  void UpdateEndSequenceId(uint64_t newEndSequenceId);
+  void ProcessWrite(bool doWrite, double centerFrequency, uint64_t sequenceId);
+
+  static const uint32_t MAX_THREADS = 8;  // process.h:49
+  uint32_t m_sampleCount, m_sampleRate, m_enob;
+  uint32_t m_fileCounter, m_preTrigger, m_postTrigger;
+  std::atomic<uint64_t> m_endSequenceId;
+  std::atomic<bool> m_writing;
+  Mode m_mode;
+  std::string m_fileNameBase;
+  float m_threshold;
+  double m_useBandWidth;
+  gr::fft::window::win_type m_windowType;
+  SampleQueue *m_sampleQueue;
+  uint32_t m_threadCount;
+  uint32_t m_maxBatch;
+  int m_firstDevice;
+  std::atomic<uint64_t> m_hitCount, m_bufferCount;
+};

@@ -1,0 +1,81 @@
+// scan_synth.cpp -- wiring of the kept classes exactly as scan.cpp:211-239 does it, with the
+// SyntheticSource in place of a USB front-end.  Not the reference's CLI (out of scope): a
+// small driver for tests, demos and the integration transcript.
+//
+//   scan_synth --kind short_complex --n 4096 --fs 8000000 --start 88e6 --stop 108e6 \
+//              --niterations 3 --threshold 10 --emitter 98.5e6:0.2 --emitter 101.1e6:0.05 [--dump raw.bin]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "process.h"
+#include "syntheticSource.h"
+
+int main(int argc, char **argv) {
+  uint32_t n = 4096, fs = 8000000, iterations = 2, enob = 12, threads = 1, batch = 1024, depth = 1024;
+  double start = 88e6, stop = 108e6, sigma = 0.01;
+  float threshold = 10.0f;
+  uint64_t seed = 1;
+  bool correctDC = false;
+  std::string kindName = "short_complex", dump;
+  std::vector<SyntheticSource::Emitter> emitters;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto val = [&]() -> const char * {
+      if (i + 1 >= argc) {
+        fprintf(stderr, "missing value for %s\n", a.c_str());
+        exit(2);
+      }
+      return argv[++i];
+    };
+    if (a == "--n") n = (uint32_t)atol(val());
+    else if (a == "--fs") fs = (uint32_t)atof(val());
+    else if (a == "--start") start = atof(val());
+    else if (a == "--stop") stop = atof(val());
+    else if (a == "--niterations") iterations = (uint32_t)atol(val());
+    else if (a == "--threshold") threshold = (float)atof(val());
+    else if (a == "--enob") enob = (uint32_t)atol(val());
+    else if (a == "--threads") threads = (uint32_t)atol(val());
+    else if (a == "--batch") batch = (uint32_t)atol(val());
+    else if (a == "--depth") depth = (uint32_t)atol(val());
+    else if (a == "--sigma") sigma = atof(val());
+    else if (a == "--seed") seed = (uint64_t)atoll(val());
+    else if (a == "--kind") kindName = val();
+    else if (a == "--correct-dc") correctDC = true;
+    else if (a == "--dump") dump = val();
+    else if (a == "--emitter") {
+      const char *v = val();
+      const char *c = strchr(v, ':');
+      if (!c) { fprintf(stderr, "--emitter wants freq:amplitude\n"); return 2; }
+      emitters.push_back(SyntheticSource::Emitter{atof(v), atof(c + 1)});
+    } else {
+      fprintf(stderr, "unknown option %s\n", a.c_str());
+      return 2;
+    }
+  }
+  SampleQueue::SampleKind kind;
+  if (kindName == "float") kind = SampleQueue::FloatComplex;
+  else if (kindName == "short_complex") kind = SampleQueue::ShortComplex;
+  else if (kindName == "short") kind = SampleQueue::Short;
+  else if (kindName == "byte") kind = SampleQueue::ByteComplex;
+  else { fprintf(stderr, "unknown kind %s\n", kindName.c_str()); return 2; }
+
+  SyntheticSource source(fs, n, start, stop, kind, seed, sigma);
+  for (auto &e : emitters) source.AddEmitter(e.frequency, e.amplitude);
+  if (!dump.empty()) source.SetDumpFile(dump);
+
+  // scan.cpp:211-223
+  ProcessSamples process(n, fs, enob, threshold, gr::fft::window::WIN_BLACKMAN_HARRIS, ProcessSamples::FrequencyDomain,
+                         threads, "", 0.75, 0.0, 0, 0);
+  process.SetMaxBatch(batch);
+  SampleQueue sampleQueue(kind, enob, n, depth, correctDC, false);
+
+  // scan.cpp:234-238 (the source delivers numIterations+1 sweeps: the first one is the queue's warm-up discard)
+  source.Start();
+  source.StartStreaming(iterations + 1, sampleQueue);
+  process.StartProcessing(sampleQueue);
+  source.StopStreaming();
+  fprintf(stderr, "buffers %lu hits %lu\n", (unsigned long)process.GetBufferCount(), (unsigned long)process.GetHitCount());
+  return 0;
+}

@@ -1,0 +1,49 @@
+// syntheticSource.h -- a SignalSource that needs no USB hardware (the reference has none:
+// every source wraps a vendor library).  Generates, deterministically from a
+// seed, what a receiver tuned to each centre frequency would deliver: complex Gaussian
+// noise plus every configured emitter that falls inside the tuned band, in the wire format
+// of the chosen SampleKind (float IQ, int16 interleaved/planar as a 12-bit ADC, int8).
+#pragma once
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "signalSource.h"
+
+class SyntheticSource : public SignalSource {
+ public:
+  struct Emitter {
+    double frequency;  // absolute, Hz
+    double amplitude;  // relative to full scale (1.0)
+  };
+
+  SyntheticSource(uint32_t sampleRate, uint32_t sampleCount, double startFrequency, double stopFrequency,
+                  SampleQueue::SampleKind kind, uint64_t seed = 1, double noiseSigma = 0.01,
+                  double useBandWidth = 0.75, double dcIgnoreWidth = 0.0);
+  ~SyntheticSource() override;
+
+  void AddEmitter(double frequency, double amplitude) { m_emitters.push_back(Emitter{frequency, amplitude}); }
+  // Also append every generated raw buffer (queue order, including the discarded warm-up
+  // sweep) to this file, so a test can replay the exact bytes through the CPU oracle.
+  void SetDumpFile(const std::string &path);
+
+  bool GetNextSamples(SampleQueue *sampleQueue, double_t &centerFrequency) override;
+  bool StartStreaming(uint32_t numIterations, SampleQueue &sampleQueue) override;
+  void ThreadWorker() override;
+  double Retune(double frequency) override;
+
+  // Fill `raw` (sampleCount samples in the kind's wire format) for one tune.
+  void Generate(double centerFrequency, uint64_t bufferIndex, void *raw);
+  size_t GetBufferBytes() const { return m_bufferBytes; }
+
+ private:
+  void Push(SampleQueue *q, void *raw, double fc, time_t t);
+  SampleQueue::SampleKind m_kind;
+  uint64_t m_seed;
+  double m_sigma;
+  std::vector<Emitter> m_emitters;
+  size_t m_bufferBytes;
+  uint64_t m_bufferIndex;
+  double m_tuned;
+  FILE *m_dump;
+};

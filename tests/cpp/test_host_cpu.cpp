@@ -1,0 +1,171 @@
+// CPU-only checks of the kept C++ host classes (no GPU, no HIP calls): queue semantics the
+// reference defines (messageQueue.h:65-91,239-273), raw wire formats, SampleBuffer visitors,
+// FrequencyTable cursor, SyntheticSource determinism and the producer thread lifecycle.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "buffer.h"
+#include "frequencyTable.h"
+#include "messageQueue.h"
+#include "sampleBuffer.h"
+#include "syntheticSource.h"
+
+static int g_fail = 0;
+#define CHECK(c)                                                      \
+  do {                                                                \
+    if (!(c)) {                                                       \
+      fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #c);    \
+      g_fail++;                                                       \
+    }                                                                 \
+  } while (0)
+
+static void test_queue_basic() {
+  const uint32_t n = 8;
+  SampleQueue q(SampleQueue::ShortComplex, 12, n, 4, false, false);
+  int16_t buf[n][2];
+  auto fill = [&](int tag) { for (uint32_t i = 0; i < n; i++) { buf[i][0] = (int16_t)(tag * 100 + i); buf[i][1] = (int16_t)-(tag * 100 + (int)i); } };
+  // first sweep (time != 0 once) is discarded: messageQueue.h:67-72
+  fill(1); q.AppendSamples(buf, 1e6, 111);
+  fill(2); q.AppendSamples(buf, 2e6, 0);
+  CHECK(q.TryGetNextSamples() == nullptr);
+  fill(3); q.AppendSamples(buf, 3e6, 222);   // second scan start: from here on messages flow
+  fill(4); q.AppendSamples(buf, 4e6, 0);
+  SampleQueue::MessageType *m = q.GetNextSamples();
+  CHECK(m && m->GetHeader().m_sequenceId == 0 && m->GetHeader().m_frequency == 3e6 && m->GetHeader().m_time == 222);
+  CHECK(m->GetRawBytes() == n * 4 && ((int16_t *)m->GetRawData())[2] == 301 && ((int16_t *)m->GetRawData())[3] == -301);
+  CHECK(!q.ReceivedAck());                    // ClearAck on append
+  q.SendAck();
+  CHECK(q.ReceivedAck());
+  q.MessageProcessed(m);
+  m = q.TryGetNextSamples();
+  CHECK(m && m->GetHeader().m_sequenceId == 1 && m->GetHeader().m_time == 0);
+  q.MessageProcessed(m);
+  q.SetIsDone();
+  CHECK(q.GetIsDone() && q.GetNextSamples() == nullptr);
+}
+
+static void test_queue_blocking_and_recycle() {
+  const uint32_t n = 16, depth = 3, total = 200;
+  SampleQueue q(SampleQueue::FloatComplex, 12, n, depth, false, false);
+  std::atomic<uint32_t> produced(0);
+  std::thread prod([&] {
+    std::vector<float> x(2 * n);
+    q.AppendSamples((fftwf_complex *)x.data(), 0, 1);  // warm-up sweep marker
+    for (uint32_t k = 0; k < total; k++) {
+      x[0] = (float)k;
+      q.AppendSamples((fftwf_complex *)x.data(), 1000.0 + k, k == 0 ? 2 : 0);
+      produced++;
+    }
+    q.SetIsDone();
+  });
+  std::this_thread::sleep_for(std::chrono::milliseconds(50));
+  CHECK(produced <= depth + 1);               // producer is blocked on the full ring (messageQueue.h:82-84)
+  uint32_t got = 0;
+  while (SampleQueue::MessageType *m = q.GetNextSamples()) {
+    CHECK(m->GetHeader().m_sequenceId == got && m->GetData()[0][0] == (float)got);
+    got++;
+    q.MessageProcessed(m);                    // recycles through the history ring; the pool never runs dry
+  }
+  prod.join();
+  CHECK(got == total);
+}
+
+static void test_queue_kinds() {
+  const uint32_t n = 4;
+  {
+    SampleQueue q(SampleQueue::Short, 12, n, 2, false, false);
+    int16_t re[n] = {1, 2, 3, 4}, im[n] = {-1, -2, -3, -4};
+    q.AppendSamples(re, im, 0, 1); q.AppendSamples(re, im, 5.0, 1);
+    SampleQueue::MessageType *m = q.GetNextSamples();
+    int16_t *r = (int16_t *)m->GetRawData();
+    CHECK(r[0] == 1 && r[3] == 4 && r[4] == -1 && r[7] == -4);   // planar: I block then Q block
+    q.MessageProcessed(m); q.SetIsDone();
+  }
+  {
+    SampleQueue q(SampleQueue::ByteComplex, 8, n, 2, true, false);
+    int8_t s[n][2] = {{1, -1}, {2, -2}, {127, -128}, {0, 5}};
+    q.AppendSamples(s, 0, 1); q.AppendSamples(s, 7.0, 1);
+    SampleQueue::MessageType *m = q.GetNextSamples();
+    CHECK(m->GetRawBytes() == 8 && ((int8_t *)m->GetRawData())[5] == -128 && q.GetCorrectDCOffset());
+    q.MessageProcessed(m); q.SetIsDone();
+  }
+}
+
+static void test_sample_buffer() {
+  const uint32_t n = 32;
+  SampleBuffer sb(SampleBuffer::FloatComplex, 12, n);
+  std::vector<float> x(2 * n), y(2 * n), stage(2 * n * 3, -1.0f);
+  for (uint32_t i = 0; i < 2 * n; i++) x[i] = (float)i;
+  sb.AppendSamples((fftwf_complex *)x.data(), 10.0);
+  sb.AppendSamples((fftwf_complex *)x.data(), 20.0);
+  double fc = 0;
+  CHECK(sb.GetNextSamples((fftwf_complex *)y.data(), fc) && fc == 10.0 && y == x);
+  HipStagingProcessInterface visitor(stage.data(), n, 2);       // third buffer of a (fake) pinned slot
+  CHECK(sb.ProcessNext(&visitor, fc) && fc == 20.0);
+  CHECK(stage[2 * n * 2] == 0.0f && stage[2 * n * 3 - 1] == (float)(2 * n - 1) && stage[0] == -1.0f);
+  sb.SetIsDone();
+  CHECK(!sb.GetNextSamples((fftwf_complex *)y.data(), fc));
+  SampleBuffer si(SampleBuffer::ShortComplex, 12, n);
+  std::vector<int16_t> s(2 * n, 7), r(2 * n);
+  si.AppendSamples((int16_t(*)[2])s.data(), 30.0);
+  CHECK(si.GetNextRaw(r.data(), fc) && fc == 30.0 && r == s && si.GetBufferBytes() == 4 * n);
+}
+
+static void test_frequency_table() {
+  FrequencyTable t(8000000, 0.0, 16384 * 6e6, 0.75, 0.0, true);
+  CHECK(t.GetFrequencyCount() == 16384 && t.GetCurrentFrequency() == 3e6 && t.GetIsScanStart());
+  CHECK(t.GetNextFrequency() == 9e6 && !t.GetIsScanStart() && t.GetIterationCount() == 0);
+  for (uint32_t i = 2; i < 16384; i++) t.GetNextFrequency();
+  CHECK(t.GetCurrentFrequency() == t.GetStopFrequency());
+  CHECK(t.GetNextFrequency() == 3e6 && t.GetIsScanStart() && t.GetIterationCount() == 1);
+  FrequencyTable one(8000000, 100e6, 0.0, 0.75, 0.0, true);
+  CHECK(one.GetFrequencyCount() == 1 && one.GetCurrentFrequency() == 103e6);
+}
+
+static void test_synthetic_source() {
+  const uint32_t n = 1024, fs = 8000000;
+  SyntheticSource src(fs, n, 88e6, 100e6, SampleQueue::ShortComplex, 5, 0.01);
+  src.AddEmitter(92.0e6, 0.25);
+  std::vector<int16_t> a(2 * n), b(2 * n), c(2 * n);
+  src.Generate(91e6, 3, a.data());
+  src.Generate(91e6, 3, b.data());
+  src.Generate(91e6, 4, c.data());
+  CHECK(a == b && a != c);                                  // pure function of (seed, index, fc)
+  double e_in = 0, e_out = 0;
+  for (uint32_t i = 0; i < 2 * n; i++) e_in += (double)a[i] * a[i];
+  src.Generate(97e6, 3, b.data());                          // emitter 5 MHz away: outside +-fs/2
+  for (uint32_t i = 0; i < 2 * n; i++) e_out += (double)b[i] * b[i];
+  CHECK(e_in > 100 * e_out);
+  // producer thread: 3 sweeps requested, the first is the queue's warm-up discard
+  SampleQueue q(SampleQueue::ShortComplex, 12, n, 8, false, false);
+  src.StartStreaming(3, q);
+  uint32_t got = 0, starts = 0;
+  while (SampleQueue::MessageType *m = q.GetNextSamples()) {
+    if (m->GetHeader().m_time != 0) starts++;
+    got++;
+    q.MessageProcessed(m);
+  }
+  src.StopStreaming();
+  CHECK(got == 2 * src.GetFrequencyCount() && starts == 2);
+}
+
+int main() {
+  test_queue_basic();
+  test_queue_blocking_and_recycle();
+  test_queue_kinds();
+  test_sample_buffer();
+  test_frequency_table();
+  test_synthetic_source();
+  if (g_fail) {
+    fprintf(stderr, "%d check(s) failed\n", g_fail);
+    return 1;
+  }
+  printf("host cpu tests ok\n");
+  return 0;
+}

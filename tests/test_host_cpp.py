@@ -1,0 +1,102 @@
+"""The kept C++ host API (SignalSource / SampleQueue / SampleBuffer / ProcessInterface /
+FrequencyTable / ProcessSamples) re-written on top of the C-ABI.
+CPU: class semantics via a C++ test executable.  GPU: the scan_synth driver's stdout
+transcript against the oracle fed the very bytes the SyntheticSource produced."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "scanner_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def host_build(built_lib):
+    from scanner_amd import build
+
+    return build.build_host()
+
+
+def test_host_classes_cpu(host_build, tmp_path):
+    exe = tmp_path / "test_host_cpu"
+    subprocess.check_call(["g++", "-std=gnu++11", "-O1", "-g", "-Wall", "-pthread", "-I", HOST,
+                           os.path.join(ROOT, "tests", "cpp", "test_host_cpu.cpp"), "-o", str(exe),
+                           "-L" + os.path.join(ROOT, "scanner_amd"), "-lscanner_host", "-lscanner_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "scanner_amd")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "host cpu tests ok" in out.stdout
+
+
+def test_reference_call_sites_compile(host_build, tmp_path):
+    """The wiring of scan.cpp:211-239 written against the reference's names compiles unchanged."""
+    src = tmp_path / "wiring.cpp"
+    src.write_text('''
+#include "process.h"
+#include "syntheticSource.h"
+#include "sampleBuffer.h"
+int main(int argc, char**) {
+  if (argc < 99) return 0;   // compile/link check only
+  uint32_t sampleCount = 8192, sample_rate = 8000000, enob = 12; float threshold = 10.0;
+  ProcessSamples::Mode mode = ProcessSamples::FrequencyDomain;
+  ProcessSamples process(sampleCount, sample_rate, enob, threshold, gr::fft::window::WIN_BLACKMAN_HARRIS, mode, 2,
+                         "", 0.75, 0.0, 2, 4);
+  SampleQueue sampleQueue(SampleQueue::ShortComplex, enob, sampleCount, 1024, true, false);
+  SignalSource * source = new SyntheticSource(sample_rate, sampleCount, 88e6, 108e6, SampleQueue::ShortComplex);
+  source->Start();
+  source->StartStreaming(10, sampleQueue);
+  process.StartProcessing(sampleQueue);
+  int16_t one[8192][2]; process.Run(one, 100000000);
+  SampleBuffer sb(SampleBuffer::ShortComplex, enob, sampleCount); sb.AppendSamples(one, 1e8);
+  return 0;
+}''')
+    subprocess.check_call(["g++", "-std=gnu++11", "-Wall", "-pthread", "-I", HOST, str(src), "-o",
+                           str(tmp_path / "wiring"), "-L" + os.path.join(ROOT, "scanner_amd"), "-lscanner_host",
+                           "-lscanner_hip", "-Wl,-rpath," + os.path.join(ROOT, "scanner_amd")])
+
+
+KINDS = {"float": 4, "short_complex": 3, "short": 2, "byte": 1}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,enob,dc", [("short_complex", 12, False), ("float", 12, False), ("byte", 8, False),
+                                          ("short", 12, True)])
+def test_scan_synth_transcript_matches_oracle(host_build, oracle_mod, tmp_path, kind, enob, dc):
+    _, demo = host_build
+    n, fs, iters = 4096, 8000000, 2
+    dump = tmp_path / "raw.bin"
+    cmd = [demo, "--kind", kind, "--n", str(n), "--fs", str(fs), "--start", "88e6", "--stop", "130e6",
+           "--niterations", str(iters), "--threshold", "10", "--enob", str(enob), "--sigma", "0.02", "--batch", "5",
+           "--depth", "16", "--dump", str(dump), "--emitter", "98.5e6:0.2", "--emitter", "101.1e6:0.05",
+           "--emitter", "119.3e6:0.4", "--emitter", "127.0e6:0.1"] + (["--correct-dc"] if dc else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [l for l in out.stdout.splitlines() if l.startswith("freq ")]
+    starts = [l for l in out.stdout.splitlines() if l.startswith("Start scan at ")]
+
+    # replay the exact bytes through the oracle: the first sweep is the queue's warm-up discard
+    from scanner_amd import capi
+
+    centres = capi.frequency_table(fs, 88e6, 130e6)[1]
+    per = capi.BYTES_PER_SAMPLE[KINDS[kind]] * n
+    raw = np.fromfile(dump, np.uint8)
+    assert raw.size == per * len(centres) * (iters + 1)
+    raw = raw[per * len(centres):]
+    dt = {"float": np.complex64, "short_complex": np.int16, "short": np.int16, "byte": np.int8}[kind]
+    fc = np.tile(centres, iters)
+    o = oracle_mod.Oracle(n, fs, 10.0, kind=KINDS[kind], enob=enob, correct_dc=dc)
+    p_ref, h_ref, _ = o.run(raw.view(dt), fc, np.arange(len(fc), dtype=np.uint64))
+    from tests import tolerances as tol
+
+    near = np.abs(p_ref[:, tol.evaluated_mask(n)] - 10.0) < tol.GUARD_DB
+    assert not near.any(), "pick other emitters: a bin sits on the threshold"
+    want = ["freq %d power_db" % h["freq_hz"] for h in h_ref]
+    assert len(got) == len(want) > 20
+    assert [re.match(r"(freq \d+ power_db)", l).group(1) for l in got] == want       # order + frequencies exact
+    vals = np.array([float(l.split()[-1]) for l in got])
+    assert np.abs(vals - h_ref["power_db"]).max() < 2e-3
+    assert len(starts) == iters
+    assert "Starting process thread 0" in out.stdout and "Stopped process thread 0" in out.stdout

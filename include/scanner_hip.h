@@ -80,7 +80,7 @@ typedef struct scn_plan_desc {
   uint32_t enob;           /* effective bits (scan.cpp:138,183) */
   uint32_t correct_dc;     /* SampleQueue correctDCOffset */
   uint32_t window_type;    /* 0 -> SCN_WIN_BLACKMAN_HARRIS */
-  uint32_t mode;           /* 0 -> SCN_MODE_FREQUENCY_DOMAIN */
+  uint32_t mode;           /* 0 -> SCN_MODE_FREQUENCY_DOMAIN; SCN_MODE_TIME_DOMAIN accepts any n >= 1 */
   float threshold;         /* dB (scan.cpp:94) */
   uint32_t dc_ignore_bins; /* 0 -> 4 (process.cpp:87); use SCN_DC_IGNORE_NONE for none */
   double use_bandwidth;    /* 0 -> 0.75 (scan.cpp:65) */
@@ -137,6 +137,16 @@ int scn_submit_device(scn_plan *plan, int slot, const void *d_raw,
  * (hits > trigger_count) per buffer, or NULL. */
 int scn_collect(scn_plan *plan, int slot, float *power_db, scn_hit *hits,
                 uint32_t hit_cap, uint32_t *n_hits, uint8_t *trigger);
+
+/* Time-domain plans (mode = SCN_MODE_TIME_DOMAIN; ProcessSamples::DoTimeDomainThresholding,
+ * process.cpp:203-237): wait for the slot's submit and fetch, per buffer, the maximum and
+ * minimum of 10*log10|x| over its samples and above[b] = (max >= threshold), i.e. the
+ * function's return value.  The reference's line
+ *   "Max signal %f above threshold %f frequency %.0f, min %f"
+ * is printed from max_db[b], the plan threshold, the buffer's centre frequency and min_db[b].
+ * Any of the three outputs may be NULL. */
+int scn_collect_time_domain(scn_plan *plan, int slot, float *max_db, float *min_db,
+                            uint8_t *above);
 
 /* Wait for the slot's submit without copying anything back. */
 int scn_wait(scn_plan *plan, int slot);

@@ -46,6 +46,7 @@ struct Slot {
   void *d_raw = nullptr;            // device copy of the staging slot
   float *d_power = nullptr;         // [max_batch][N] dB spectra (plan-owned destination)
   float *cur_power = nullptr;       // destination of the pending submit
+  float *h_td = nullptr;            // time-domain mode: [2][max_batch] max / min dB, pinned, kernel-written
   uint32_t *h_buf_hits = nullptr;   // [max_batch] hits per buffer: pinned host memory the kernel
                                     // writes directly (one dword per buffer over PCIe), so a
                                     // submit puts nothing but the kernel on the stream
@@ -124,6 +125,10 @@ int check_slot(scn_plan *p, int slot) {
 
 int ensure_slot_outputs(scn_plan *p, Slot &s) {
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if (p->d.mode == SCN_MODE_TIME_DOMAIN) {
+    if (!s.h_td) SCN_HIP(hipHostMalloc(&s.h_td, sizeof(float) * 2 * p->d.max_batch, hipHostMallocDefault));
+    return SCN_OK;
+  }
   if ((p->d.flags & SCN_OUT_HITS) && !s.d_hits) {
     SCN_HIP(hipMalloc(&s.d_hits, sizeof(ScnDevHit) * (size_t)p->hit_region * p->d.max_batch));
     SCN_HIP(hipMalloc(&s.d_ov_hits, sizeof(ScnDevHit) * (size_t)p->d.max_hits));
@@ -140,6 +145,24 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   int st = ensure_slot_outputs(p, s);
   if (st) return st;
   const uint32_t n = p->d.n;
+  if (p->d.mode == SCN_MODE_TIME_DOMAIN) {
+    s.cur_power = nullptr;
+    s.n_buffers = nb;
+    s.fc.assign(fc, fc + nb);
+    s.seq.resize(nb);
+    for (uint32_t b = 0; b < nb; b++) s.seq[b] = seq ? seq[b] : (uint64_t)b;
+    ScnTdArgs a;
+    a.raw = d_raw;
+    a.n = n;
+    a.n_buffers = nb;
+    a.scale = p->scale;
+    a.max_db = s.h_td;
+    a.min_db = s.h_td + p->d.max_batch;
+    SCN_HIP(scn_launch_time_domain((int)p->d.sample_kind, p->d.correct_dc != 0, a, p->num_cus, p->stream));
+    SCN_HIP(hipEventRecord(s.done, p->stream));
+    s.pending = true;
+    return SCN_OK;
+  }
   if (!d_power && (p->d.flags & SCN_OUT_SPECTRUM)) {
     if (!s.d_power) SCN_HIP(hipMalloc(&s.d_power, sizeof(float) * (size_t)n * p->d.max_batch));
     d_power = s.d_power;
@@ -181,6 +204,7 @@ void free_slot(Slot &s) {
   if (s.d_raw) (void)hipFree(s.d_raw);
   if (s.d_power) (void)hipFree(s.d_power);
   if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
+  if (s.h_td) (void)hipHostFree(s.h_td);
   if (s.d_hits) (void)hipFree(s.d_hits);
   if (s.d_ov_hits) (void)hipFree(s.d_ov_hits);
   if (s.d_ov_counter) (void)hipFree(s.d_ov_counter);
@@ -230,8 +254,11 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     return fail(SCN_E_INVALID, "enob %u out of range", d.enob);
   if (d.window_type != SCN_WIN_BLACKMAN_HARRIS && d.window_type != SCN_WIN_RECTANGULAR)
     return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
-  if (d.mode != SCN_MODE_FREQUENCY_DOMAIN) return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
-  if (!scn_fft_size_supported(d.n)) return fail(SCN_E_INVALID, "unsupported FFT size %u", d.n);
+  if (d.mode != SCN_MODE_FREQUENCY_DOMAIN && d.mode != SCN_MODE_TIME_DOMAIN)
+    return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
+  if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n))
+    return fail(SCN_E_INVALID, "unsupported FFT size %u (1024, 2048, 4096, 8192)", d.n);
+  if (d.n == 0 || d.n > (1u << 24)) return fail(SCN_E_INVALID, "bad sample count %u", d.n);
   if (d.sample_rate == 0) return fail(SCN_E_INVALID, "sample_rate must be > 0");
 
   int ndev = 0;
@@ -351,9 +378,29 @@ int scn_wait(scn_plan *p, int slot) {
   return SCN_OK;
 }
 
+int scn_collect_time_domain(scn_plan *p, int slot, float *max_db, float *min_db, uint8_t *above) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if (p->d.mode != SCN_MODE_TIME_DOMAIN) return fail(SCN_E_INVALID, "plan is not in time-domain mode");
+  st = scn_wait(p, slot);
+  if (st) return st;
+  Slot &s = p->slot[slot];
+  s.pending = false;
+  const float *mx = s.h_td, *mn = s.h_td + p->d.max_batch;
+  for (uint32_t b = 0; b < s.n_buffers; b++) {
+    if (max_db) max_db[b] = mx[b];
+    if (min_db) min_db[b] = mn[b];
+    if (above) above[b] = mx[b] >= p->d.threshold;  // process.cpp:226
+  }
+  return SCN_OK;
+}
+
 int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t hit_cap, uint32_t *n_hits,
                 uint8_t *trigger) {
-  int st = scn_wait(p, slot);
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if (p->d.mode != SCN_MODE_FREQUENCY_DOMAIN) return fail(SCN_E_INVALID, "time-domain plan: use scn_collect_time_domain");
+  st = scn_wait(p, slot);
   if (st) return st;
   Slot &s = p->slot[slot];
   s.pending = false;

@@ -43,6 +43,16 @@ struct ScnFftArgs {
   uint32_t *per_buffer_hits;  // [n_buffers] total hits of each buffer (pinned host memory)
 };
 
+// time-domain mode (process.cpp:203-237)
+struct ScnTdArgs {
+  const void *raw;
+  uint32_t n, n_buffers;
+  float scale;
+  float *max_db;  // [n_buffers] pinned host memory
+  float *min_db;
+};
+hipError_t scn_launch_time_domain(int kind, bool correct_dc, const ScnTdArgs &args, int num_cus, hipStream_t stream);
+
 hipError_t scn_launch_fft(uint32_t n, int kind, bool correct_dc, bool hits, const ScnFftArgs &args,
                           int num_cus, hipStream_t stream);
 bool scn_fft_size_supported(uint32_t n);

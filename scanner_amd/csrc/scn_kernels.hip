@@ -89,6 +89,23 @@ __device__ __forceinline__ void fft16(cf v[16]) {
   for (int k0 = 0; k0 < 4; k0++) radix4(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
 }
 
+// In-register 8-point forward DFT (radix 4 x 2).  On return X[k] sits in z[OUT8(k)].
+#define OUT8(k) (2 * ((k) & 3) + ((k) >> 2))
+__device__ __forceinline__ void fft8(cf z[8]) {
+  const float H = 0.70710678118654752440f;
+  radix4(z[0], z[2], z[4], z[6]);  // even samples -> z[2*k0]
+  radix4(z[1], z[3], z[5], z[7]);  // odd samples  -> z[2*k0+1]
+  z[3] = mul_w2(z[3], H);          // W8^1
+  z[5] = cf{z[5].y, -z[5].x};      // W8^2 = -i
+  z[7] = mul_w6(z[7], H);          // W8^3
+#pragma unroll
+  for (int k0 = 0; k0 < 4; k0++) {
+    cf a = z[2 * k0], b = z[2 * k0 + 1];
+    z[2 * k0] = a + b;      // X[k0]
+    z[2 * k0 + 1] = a - b;  // X[k0 + 4]
+  }
+}
+
 // ---- global memory access through buffer descriptors ---------------------------------
 // A raw buffer resource (SGPR descriptor, wave-uniform base) + one per-lane VGPR offset
 // + scalar/immediate offsets: the 16 strided accesses of a thread cost no address VGPRs.
@@ -202,64 +219,94 @@ __device__ __forceinline__ int wave_sum(int v) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------
-// 4096-point fused kernel: one 256-thread workgroup per buffer, persistent over buffers.
+// Fused kernel for N = 256*M points, M in {4, 8, 16, 32} (N = 1024 / 2048 / 4096 / 8192).
+// One workgroup of T = 16*M threads per buffer, persistent over buffers, 16 points per thread.
 //
-// LDS (all offsets in complex = 8 B units, every address = per-thread base + immediate):
-//   exchange 1   L1(p, col)  = p*272 + col          16 rows of 256, row pitch padded by 16
-//       write (pass 1): fixed p, lanes col = t            -> 64 consecutive slots
-//       read  (pass 2): thread (p=hi, c=lo), fixed b      -> hi*272 + b*16 + lo; the two rows a
-//                       32-lane group touches sit 128 B apart in bank space -> conflict-free
-//   exchange 2   L2(c, q, p) = c*257 + q*16 + p      row pitch padded by 1
-//       write (pass 2): thread (p=hi, c=lo), fixed q      -> lanes 8 B apart mod 256 B
-//       read  (pass 3): thread (p=lo, q=hi), fixed c      -> 64 consecutive slots
-//   then the pass-2 twiddle table [q][c] (2 KiB), 8 ints of per-wave scratch, the hit counter.
+//   n = T*a + M*b + c          k = p + 16q + 256r         a,b,p,q in [0,16), c,r in [0,M)
+//   pass 1  thread t = M*b + c:  16-pt DFT over a of x[T*a + t]*w[T*a + t] -> *W_N^{t p} -> LDS row p
+//   pass 2  thread (p, c):       16-pt DFT over b                          -> *W_{16M}^{c q} -> LDS
+//   pass 3  M-pt DFT over c for each (p,q):
+//       M <= 16: thread t does the 16/M butterflies kl = t + T*u, outputs k = kl + 256 r
+//       M == 32: two lanes (l, l+32) share a butterfly: each does the 16-pt DFT over c = 2c'+e
+//                of its parity e, the odd one applies W_32^{r'}, one cross-half exchange
+//                (radix 2) finishes it; lane half e outputs r = r' + 16e
+//
+// LDS (complex = 8 B slots, every address = per-thread base + immediate, all four access patterns
+// bank-conflict-free -- checked with SQ_LDS_BANK_CONFLICT and the bank model of the guide):
+//   exchange 1   L1(p, col) = p*P1 + col,   P1 = T + (M < 32 ? M : 0)
+//       write (pass 1): fixed p, lanes col = t                -> consecutive slots
+//       read  (pass 2): thread (p, c), fixed b: p*P1 + b*M + c -> the 32/M rows a 32-lane group
+//                       touches sit 8M bytes apart in bank space
+//   exchange 2   L2(c, kl) = c*P2 + kl,     P2 = 256 + (M <= 16 ? 16/M : 1)
+//       write (pass 2): thread (p, c), fixed q: c*P2 + p + 16q -> 16 lanes on 16 distinct bank pairs
+//       read  (pass 3): fixed c, lanes kl consecutive
+//   then the pass-2 twiddle table [q][c] (16*M entries), DC-sum scratch, the hit counter.
 // ------------------------------------------------------------------------------------
-#define SCN_L1_PITCH 272
-#define SCN_L2_PITCH 257
-#define SCN_LDS_EXCH (16 * SCN_L1_PITCH)  // complex slots (>= 16*257)
-#define SCN_LDS_BYTES_4096 (SCN_LDS_EXCH * 8 + 256 * 8 + 48)
+template <int M>
+struct Geo {
+  static constexpr uint32_t N = 256u * M;
+  static constexpr uint32_t T = 16u * M;
+  static constexpr uint32_t P1 = T + (M < 32 ? M : 0);
+  static constexpr uint32_t P2 = 256u + (M <= 16 ? 16u / M : 1u);
+  static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 16u;
+  static constexpr uint32_t WAVES = T >= 64 ? T / 64 : 1;
+  // resident workgroups per CU: 16 waves (12 with register prefetch) = 4 (3) per SIMD
+  static constexpr uint32_t WG_PER_CU = (SCN_WG_PER_CU * 4u) / WAVES;
+};
 
-template <int KIND, bool DC, bool HITS>
-__global__ __launch_bounds__(256, SCN_WG_PER_CU) void scn_fft4096_kernel(ScnFftArgs args) {
+// natural output index o of a thread -> register that holds it after pass 3
+template <int M>
+__device__ __forceinline__ constexpr int out_reg(int o) {
+  return M == 4 ? o : M == 8 ? (o & ~7) + OUT8(o & 7) : OUT16(o & 15);
+}
+
+template <int M, int KIND, bool DC, bool HITS>
+__global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftArgs args) {
+  typedef Geo<M> G;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
   constexpr bool PF = SCN_PREFETCH != 0;
-  constexpr uint32_t N = 4096;
+  constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-  v2f *lds_tw2 = lds + SCN_LDS_EXCH;                        // [16][16]
-  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + 256);    // [8] DC-sum scratch
-  int *lds_hits = lds_cnt + 8;                              // hits of the buffer in flight
+  v2f *lds_tw2 = lds + G::EXCH;                              // [16][M]
+  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T);      // [16] DC-sum scratch (re[8], im[8])
+  int *lds_hits = lds_cnt + 16;                             // hits of the buffer in flight
 
   const uint32_t t = threadIdx.x;
-  const uint32_t hi = t >> 4, lo = t & 15;
-  const uint32_t wave = t >> 6;
+  const uint32_t p2 = t / M, c2 = t % M;  // pass-2 identity (p, c); also the (q, c) of the table entry below
+  const uint32_t lane = t & 63, wave = t >> 6;
+  // pass-3 identity for M == 32: parity e = lane half, butterfly kl
+  const uint32_t e = (t >> 5) & 1u, kl32 = (t & 31u) + 32u * (t >> 6);
 
-  // persistent per-thread constants: pass-1 twiddles W_4096^(t*p) and window taps
+  // persistent per-thread constants: pass-1 twiddles W_N^(t*p) and window taps
   cf tw1[16];
 #pragma unroll
   for (int p = 1; p < 16; p++) tw1[p] = from_v2f(args.twiddle[(t * p) & (N - 1)]);
   float win[16];
 #pragma unroll
-  for (int a = 0; a < 16; a++) win[a] = args.window[256 * a + t];
-  // pass-2 twiddles W_256^(c*q), table [q][c] shared by the workgroup
-  lds_tw2[t] = args.twiddle[(16 * hi * lo) & (N - 1)];
+  for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t];
+  // pass-2 twiddles W_{16M}^(c*q) = W_N^(16 c q), table [q][c] shared by the workgroup
+  lds_tw2[t] = args.twiddle[(16 * p2 * c2) & (N - 1)];
   if (t == 0) *lds_hits = 0;
   __syncthreads();
 
-  v2f *w1 = lds + t;                                  // + p*272
-  v2f *r1 = lds + hi * SCN_L1_PITCH + lo;             // + b*16
-  v2f *w2 = lds + lo * SCN_L2_PITCH + hi;             // + q*16
-  v2f *r3 = lds + t;                                  // + c*257
-  const v2f *tw2 = lds_tw2 + lo;                      // + q*16
+  v2f *w1 = lds + t;                      // + p*P1
+  v2f *r1 = lds + p2 * P1 + c2;           // + b*M
+  v2f *w2 = lds + c2 * P2 + p2;           // + 16*q
+  v2f *r3 = (M == 32) ? lds + e * P2 + kl32 : lds + t;  // + 2c'*P2   |   + c*P2 + T*u
+  const v2f *tw2 = lds_tw2 + c2;          // + q*M
+  // global store offset of output o: voffset (per lane) + scalar part
+  const uint32_t st_voff = (M == 32) ? (kl32 + 4096u * e) * 4u : t * 4u;
 
   typename L::raw_t raw[16];
   if (PF && blockIdx.x < args.n_buffers) {
     __amdgpu_buffer_rsrc_t r0 =
         make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), L::kBufBytes(N));
 #pragma unroll
-    for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(r0, N, t, 256 * a);
+    for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(r0, N, t, T * a);
   }
 
   for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
@@ -268,7 +315,7 @@ __global__ __launch_bounds__(256, SCN_WG_PER_CU) void scn_fft4096_kernel(ScnFftA
       __amdgpu_buffer_rsrc_t rin =
           make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), L::kBufBytes(N));
 #pragma unroll
-      for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(rin, N, t, 256 * a);
+      for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(rin, N, t, T * a);
     }
 
     int dc_re = 0, dc_im = 0;
@@ -284,13 +331,17 @@ __global__ __launch_bounds__(256, SCN_WG_PER_CU) void scn_fft4096_kernel(ScnFftA
       }
       sr = wave_sum(sr);
       si = wave_sum(si);
-      if ((t & 63) == 0) {
+      if (lane == 0) {
         lds_cnt[wave] = sr;
-        lds_cnt[4 + wave] = si;
+        lds_cnt[8 + wave] = si;
       }
       __syncthreads();
-      sr = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
-      si = lds_cnt[4] + lds_cnt[5] + lds_cnt[6] + lds_cnt[7];
+      sr = si = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < G::WAVES; w++) {
+        sr += lds_cnt[w];
+        si += lds_cnt[8 + w];
+      }
       dc_re = (int)((uint32_t)sr / N);
       dc_im = (int)((uint32_t)si / N);
     }
@@ -300,13 +351,13 @@ __global__ __launch_bounds__(256, SCN_WG_PER_CU) void scn_fft4096_kernel(ScnFftA
     for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, args.scale) * win[a];
     if (PF) {
       // the raw registers are free again: start fetching the next buffer of this workgroup now,
-      // its latency hides behind the three FFT passes below
+      // its latency hides behind the FFT passes below
       const uint32_t nxt = buf + gridDim.x;
       if (nxt < args.n_buffers) {
         __amdgpu_buffer_rsrc_t rn =
             make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)nxt * L::kBufBytes(N), L::kBufBytes(N));
 #pragma unroll
-        for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(rn, N, t, 256 * a);
+        for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(rn, N, t, T * a);
       }
     }
 
@@ -316,58 +367,92 @@ __global__ __launch_bounds__(256, SCN_WG_PER_CU) void scn_fft4096_kernel(ScnFftA
     for (int p = 0; p < 16; p++) {
       cf y = v[OUT16(p)];
       if (p) y = cmul(y, tw1[p]);
-      w1[p * SCN_L1_PITCH] = to_v2f(y);
+      w1[p * P1] = to_v2f(y);
     }
     __syncthreads();
 
-    // ---- pass 2: thread (p=hi, c=lo): DFT over b, twiddle W_256^(c q) ----
+    // ---- pass 2: thread (p, c): DFT over b, twiddle W_{16M}^(c q) ----
 #pragma unroll
-    for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 16]);
+    for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * M]);
     fft16(v);
 #pragma unroll
-    for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * 16]));
+    for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * M]));
     __syncthreads();  // every exchange-1 read done before the area is re-used
 #pragma unroll
     for (int q = 0; q < 16; q++) w2[q * 16] = to_v2f(v[OUT16(q)]);
     __syncthreads();
 
-    // ---- pass 3: thread (p=lo, q=hi): DFT over c; outputs k = t + 256 r ----
+    // ---- pass 3: M-point DFT over c ----
+    if constexpr (M == 32) {
 #pragma unroll
-    for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[c * SCN_L2_PITCH]);
-    fft16(v);
+      for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[2 * c * P2]);
+      fft16(v);
+      // radix 2 across the wave's two halves: X[r'] = Y0 + W32^r' Y1, X[r'+16] = Y0 - W32^r' Y1
+      const float sel = e ? 1.0f : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        cf y = v[OUT16(r)];
+        if (r) {
+          // W_32^r for the odd half, 1 for the even half (branch-free: both halves run the same code)
+          const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
+          const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
+          cf w = cf{e ? cr : 1.0f, -sr * sel};
+          y = cmul(y, w);
+        }
+        cf o = cf{__shfl_xor(y.x, 32, 64), __shfl_xor(y.y, 32, 64)};  // the partner's value
+        v[OUT16(r)] = e ? o - y : y + o;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16 / M; u++)
+#pragma unroll
+        for (int c = 0; c < M; c++) v[u * M + c] = from_v2f(r3[c * P2 + T * u]);
+      if constexpr (M == 16) fft16(v);
+      if constexpr (M == 8) {
+        fft8(v);
+        fft8(v + 8);
+      }
+      if constexpr (M == 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) radix4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+      }
+    }
 
-    // ---- K4 + K5 ----
-    v16f db;  // a true vector: the slow path below indexes it with a wave-uniform r (s_set_gpr_idx)
+    // ---- K4 + K5: output o of this thread is bin j = jbase + joff(o) ----
+    //   M <= 16: o = u*M + r, j = t + T*u + 256*r        M == 32: o = r', j = kl + 4096*e + 256*r'
+    v16f db;  // a true vector: the slow path below indexes it with a wave-uniform o (s_set_gpr_idx)
     uint32_t hitmask = 0;
+    const uint32_t jbase = (M == 32) ? kl32 + 4096u * e : t;
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, args.power_db ? 4u * N : 0u);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      // NB: never __builtin_bit_cast a vector ELEMENT (db[r]): clang reads element 0 for every r
-      const float d = power_db(v[OUT16(r)]);
-      db[r] = d;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, t * 4u, 1024u * r, AUX_ST);
+    for (int o = 0; o < 16; o++) {
+      const uint32_t joff = (M == 32) ? 256u * o : T * (o / M) + 256u * (o % M);
+      // NB: never __builtin_bit_cast a vector ELEMENT (db[o]): clang reads element 0 for every o
+      const float d = power_db(v[out_reg<M>(o)]);
+      db[o] = d;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 4u * joff, AUX_ST);
       if (HITS) {
-        uint32_t j = t + 256 * r;
+        uint32_t j = jbase + joff;
         uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
         bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
-        hitmask |= (keep && (d > args.threshold)) ? (1u << r) : 0u;
+        hitmask |= (keep && (d > args.threshold)) ? (1u << o) : 0u;
       }
     }
     if (HITS) {
       if (__ballot(hitmask != 0)) {  // rare: some lane of this wave holds a detection
 #pragma unroll 1
-        for (int r = 0; r < 16; r++) {
-          bool hit = (hitmask >> r) & 1u;
+        for (int o = 0; o < 16; o++) {
+          bool hit = (hitmask >> o) & 1u;
           unsigned long long m = __ballot(hit);
           if (!m) continue;
-          // slot inside this buffer's region: one LDS atomic per wave and r
+          // slot inside this buffer's region: one LDS atomic per wave and o
           uint32_t base = 0;
-          if ((t & 63) == 0) base = (uint32_t)atomicAdd(lds_hits, (int)__popcll(m));
-          base = __shfl(base, 0, 64);
+          if (lane == 0) base = (uint32_t)atomicAdd(lds_hits, (int)__popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
           if (hit) {
-            uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << (t & 63)) - 1ull));
-            uint32_t j = t + 256 * r;
-            ScnDevHit rec = ScnDevHit{buf, j ^ (N / 2), db[r], 0u};
+            uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t joff = (M == 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M);
+            ScnDevHit rec = ScnDevHit{buf, (jbase + joff) ^ (N / 2), db[o], 0u};
             if (pos < args.hit_region) {
               args.hits[(size_t)buf * args.hit_region + pos] = rec;
             } else {  // region full: spill through the device-scope counter
@@ -389,33 +474,135 @@ __global__ __launch_bounds__(256, SCN_WG_PER_CU) void scn_fft4096_kernel(ScnFftA
 }
 
 // ------------------------------------------------------------------------------------
+// Time-domain mode (process.cpp:203-237): per buffer, max and min over the samples of
+// 10*log2(|x|)/log2(10).  The dB map is monotone, so the kernel reduces max/min of |x|^2
+// (computed exactly as the reference does: re*re + im*im in float, no fused multiply-add) and
+// converts the two extremes once.  One 256-thread workgroup per buffer, any N; pure HBM
+// streaming (8/4/2 B per sample in, 8 B per buffer out).
+// ------------------------------------------------------------------------------------
+template <int KIND, bool DC>
+__global__ __launch_bounds__(256) void scn_time_domain_kernel(ScnTdArgs args) {
+  typedef RawLoader<KIND> L;
+  __shared__ float s_max[4], s_min[4];
+  __shared__ int s_sum[8];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t N = args.n;
+  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
+    __amdgpu_buffer_rsrc_t rin =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), L::kBufBytes(N));
+    int dc_re = 0, dc_im = 0;
+    if (DC) {
+      int sr = 0, si = 0;
+      for (uint32_t i = t; i < N; i += 256) {
+        int re, im;
+        L::ints(L::template load<0>(rin, N, i, 0), re, im);
+        sr += re;
+        si += im;
+      }
+      sr = wave_sum(sr);
+      si = wave_sum(si);
+      if (lane == 0) {
+        s_sum[wave] = sr;
+        s_sum[4 + wave] = si;
+      }
+      __syncthreads();
+      dc_re = (int)((uint32_t)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) / N);  // utility.cpp:77-78 quirk
+      dc_im = (int)((uint32_t)(s_sum[4] + s_sum[5] + s_sum[6] + s_sum[7]) / N);
+    }
+    float pmax = -1.0f, pmin = 3.40282347e+38f;  // |x|^2 >= 0, so -1 is "no sample yet"
+    for (uint32_t i = t; i < N; i += 256) {
+      cf x = L::conv(L::template load<0>(rin, N, i, 0), dc_re, dc_im, args.scale);
+      float p = __fadd_rn(__fmul_rn(x.x, x.x), __fmul_rn(x.y, x.y));  // process.cpp:220, unfused
+      pmax = fmaxf(pmax, p);
+      pmin = fminf(pmin, p);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
+      pmin = fminf(pmin, __shfl_xor(pmin, off, 64));
+    }
+    if (lane == 0) {
+      s_max[wave] = pmax;
+      s_min[wave] = pmin;
+    }
+    __syncthreads();
+    if (t == 0) {
+      pmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+      pmin = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+      // 10*log2(sqrt(p))/log2(10); the reference's odd initial values (numeric_limits<float>::min()
+      // is the smallest POSITIVE float, process.cpp:207-208) bound the results
+      const float k = 3.01029995663981195214f;  // 10/log2(10)
+      float dmax = k * __builtin_amdgcn_logf(__builtin_amdgcn_sqrtf(pmax));
+      float dmin = k * __builtin_amdgcn_logf(__builtin_amdgcn_sqrtf(pmin));
+      args.max_db[buf] = fmaxf(1.17549435e-38f, dmax);
+      args.min_db[buf] = fminf(3.40282347e+38f, dmin);
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t scn_launch_time_domain(int kind, bool dc, const ScnTdArgs &a, int num_cus, hipStream_t s) {
+  if (a.n_buffers == 0) return hipSuccess;
+  void (*k)(ScnTdArgs) = nullptr;
+  switch (kind) {
+    case SCN_K_FLOAT_COMPLEX: k = scn_time_domain_kernel<SCN_K_FLOAT_COMPLEX, false>; break;
+    case SCN_K_SHORT_COMPLEX: k = dc ? scn_time_domain_kernel<SCN_K_SHORT_COMPLEX, true> : scn_time_domain_kernel<SCN_K_SHORT_COMPLEX, false>; break;
+    case SCN_K_SHORT: k = dc ? scn_time_domain_kernel<SCN_K_SHORT, true> : scn_time_domain_kernel<SCN_K_SHORT, false>; break;
+    case SCN_K_BYTE_COMPLEX: k = dc ? scn_time_domain_kernel<SCN_K_BYTE_COMPLEX, true> : scn_time_domain_kernel<SCN_K_BYTE_COMPLEX, false>; break;
+    default: return hipErrorInvalidValue;
+  }
+  int grid = num_cus * 8;
+  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // host-side launcher
 // ------------------------------------------------------------------------------------
-template <int KIND>
-static hipError_t launch4096_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
-  const size_t lds = SCN_LDS_BYTES_4096;
+template <int M, int KIND>
+static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
+  typedef Geo<M> G;
   void (*k)(ScnFftArgs) = nullptr;
-  if (dc && hits) k = scn_fft4096_kernel<KIND, true, true>;
-  else if (dc) k = scn_fft4096_kernel<KIND, true, false>;
-  else if (hits) k = scn_fft4096_kernel<KIND, false, true>;
-  else k = scn_fft4096_kernel<KIND, false, false>;
-  int grid = num_cus * SCN_WG_PER_CU;  // one resident wave of persistent workgroups
+  if (dc && hits) k = scn_fft_kernel<M, KIND, true, true>;
+  else if (dc) k = scn_fft_kernel<M, KIND, true, false>;
+  else if (hits) k = scn_fft_kernel<M, KIND, false, true>;
+  else k = scn_fft_kernel<M, KIND, false, false>;
+  static bool attr_set[4] = {false, false, false, false};  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  const int ki = (dc ? 2 : 0) + (hits ? 1 : 0);
+  if (G::LDS_BYTES > 65536u && !attr_set[ki]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set[ki] = true;
+  }
+  int grid = num_cus * (int)G::WG_PER_CU;  // one resident wave of persistent workgroups
   if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), G::LDS_BYTES, s, a);
   return hipGetLastError();
+}
+
+template <int M>
+static hipError_t launch_size(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream) {
+  switch (kind) {
+    case SCN_K_FLOAT_COMPLEX: return launch_kind<M, SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream);
+    case SCN_K_SHORT_COMPLEX: return launch_kind<M, SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream);
+    case SCN_K_SHORT: return launch_kind<M, SCN_K_SHORT>(args, dc, hits, num_cus, stream);
+    case SCN_K_BYTE_COMPLEX: return launch_kind<M, SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus,
                           hipStream_t stream) {
   if (args.n_buffers == 0) return hipSuccess;
-  if (n != 4096) return hipErrorInvalidValue;
-  switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch4096_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream);
-    case SCN_K_SHORT_COMPLEX: return launch4096_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream);
-    case SCN_K_SHORT: return launch4096_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream);
-    case SCN_K_BYTE_COMPLEX: return launch4096_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream);
+  switch (n) {
+    case 1024: return launch_size<4>(kind, dc, hits, args, num_cus, stream);
+    case 2048: return launch_size<8>(kind, dc, hits, args, num_cus, stream);
+    case 4096: return launch_size<16>(kind, dc, hits, args, num_cus, stream);
+    case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-bool scn_fft_size_supported(uint32_t n) { return n == 4096; }
+bool scn_fft_size_supported(uint32_t n) { return n == 1024 || n == 2048 || n == 4096 || n == 8192; }

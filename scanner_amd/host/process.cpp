@@ -88,10 +88,7 @@ static uint32_t planKind(SampleQueue::SampleKind k) { return (uint32_t)k; }  // 
 
 void ProcessSamples::ThreadWorker(uint32_t threadId) {
   SampleQueue &q = *m_sampleQueue;
-  if (m_mode != FrequencyDomain) {
-    fprintf(stderr, "ProcessSamples: TimeDomain mode is not available on the HIP path yet\n");
-    exit(1);
-  }
+  const bool timeDomain = m_mode == TimeDomain;
   scn_plan_desc d;
   memset(&d, 0, sizeof(d));
   d.struct_size = sizeof(d);
@@ -101,7 +98,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   d.enob = m_enob;
   d.correct_dc = q.GetCorrectDCOffset();
   d.window_type = (uint32_t)m_windowType;
-  d.mode = SCN_MODE_FREQUENCY_DOMAIN;
+  d.mode = timeDomain ? SCN_MODE_TIME_DOMAIN : SCN_MODE_FREQUENCY_DOMAIN;
   d.threshold = m_threshold;
   d.use_bandwidth = m_useBandWidth;
   d.max_batch = std::min<uint32_t>(m_maxBatch, std::max<uint32_t>(1u, q.GetBufferCount()));
@@ -120,6 +117,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   std::vector<double> fc(d.max_batch);
   std::vector<uint64_t> seq(d.max_batch);
   std::vector<uint8_t> trig(d.max_batch);
+  std::vector<float> tdMax(d.max_batch), tdMin(d.max_batch);
   std::vector<scn_hit> hits((size_t)d.max_batch * 64u);
   std::vector<SampleQueue::MessageType *> inflight[SCN_NUM_SLOTS];
   bool pending[SCN_NUM_SLOTS] = {false, false};
@@ -128,7 +126,11 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
 
   auto drain = [&](int s) {
     uint32_t nHits = 0;
-    int st = scn_collect(plan, s, nullptr, hits.data(), (uint32_t)hits.size(), &nHits, trig.data());
+    int st = SCN_OK;
+    if (timeDomain)
+      st = scn_collect_time_domain(plan, s, tdMax.data(), tdMin.data(), trig.data());
+    else
+      st = scn_collect(plan, s, nullptr, hits.data(), (uint32_t)hits.size(), &nHits, trig.data());
     if (st == SCN_E_TRUNCATED) {  // more detections than this worker buffers: report what was kept
       fprintf(stderr, "ProcessSamples: %u hits in one batch, reporting the first %zu\n", nHits, hits.size());
       nHits = (uint32_t)std::min<size_t>(nHits, hits.size());
@@ -145,7 +147,13 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
         printf("Start scan at %s\n", timeBuffer);
         fflush(stdout);
       }
-      while (k < nHits && hits[k].seq_id == h.m_sequenceId) {  // hits arrive ordered by (buffer, i)
+      if (timeDomain && trig[b]) {  // process.cpp:226-233
+        printf("Sequence[%llu]: ", (unsigned long long)h.m_sequenceId);
+        printf("Max signal %f above threshold %f frequency %.0f, min %f\n", tdMax[b], m_threshold, h.m_frequency,
+               tdMin[b]);
+        nHits++;
+      }
+      while (!timeDomain && k < nHits && hits[k].seq_id == h.m_sequenceId) {  // hits arrive ordered by (buffer, i)
         printf("freq %lu power_db %f\n", (unsigned long)hits[k].freq_hz, hits[k].power_db);  // process.cpp:57
         k++;
       }

@@ -2,7 +2,7 @@
 // SyntheticSource in place of a USB front-end.  Not the reference's CLI (out of scope): a
 // small driver for tests, demos and the integration transcript.
 //
-//   scan_synth --kind short_complex --n 4096 --fs 8000000 --start 88e6 --stop 108e6 \
+//   scan_synth --kind short_complex --n 4096 --fs 8000000 --start 88e6 --stop 108e6
 //              --niterations 3 --threshold 10 --emitter 98.5e6:0.2 --emitter 101.1e6:0.05 [--dump raw.bin]
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +17,7 @@ int main(int argc, char **argv) {
   double start = 88e6, stop = 108e6, sigma = 0.01;
   float threshold = 10.0f;
   uint64_t seed = 1;
-  bool correctDC = false;
+  bool correctDC = false, timeDomain = false;
   std::string kindName = "short_complex", dump;
   std::vector<SyntheticSource::Emitter> emitters;
   for (int i = 1; i < argc; i++) {
@@ -43,6 +43,7 @@ int main(int argc, char **argv) {
     else if (a == "--seed") seed = (uint64_t)atoll(val());
     else if (a == "--kind") kindName = val();
     else if (a == "--correct-dc") correctDC = true;
+    else if (a == "--mode") timeDomain = std::string(val()) == "time";
     else if (a == "--dump") dump = val();
     else if (a == "--emitter") {
       const char *v = val();
@@ -66,7 +67,7 @@ int main(int argc, char **argv) {
   if (!dump.empty()) source.SetDumpFile(dump);
 
   // scan.cpp:211-223
-  ProcessSamples process(n, fs, enob, threshold, gr::fft::window::WIN_BLACKMAN_HARRIS, ProcessSamples::FrequencyDomain,
+  ProcessSamples process(n, fs, enob, threshold, gr::fft::window::WIN_BLACKMAN_HARRIS, timeDomain ? ProcessSamples::TimeDomain : ProcessSamples::FrequencyDomain,
                          threads, "", 0.75, 0.0, 0, 0);
   process.SetMaxBatch(batch);
   SampleQueue sampleQueue(kind, enob, n, depth, correctDC, false);

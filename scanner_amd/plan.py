@@ -15,7 +15,7 @@ class Plan:
     def __init__(self, n, sample_rate=8000000, threshold=10.0, kind=capi.KIND_FLOAT_COMPLEX, enob=12,
                  correct_dc=False, max_batch=1, use_bandwidth=0.75, dc_ignore_bins=4, trigger_count=1047,
                  max_hits=0, flags=capi.OUT_SPECTRUM | capi.OUT_HITS, device_id=0,
-                 window_type=capi.WIN_BLACKMAN_HARRIS):
+                 window_type=capi.WIN_BLACKMAN_HARRIS, mode=capi.MODE_FREQUENCY_DOMAIN):
         self._L = capi.lib()
         d = capi.PlanDesc()
         d.struct_size = C.sizeof(capi.PlanDesc)
@@ -25,7 +25,7 @@ class Plan:
         d.enob = enob
         d.correct_dc = int(bool(correct_dc))
         d.window_type = window_type
-        d.mode = capi.MODE_FREQUENCY_DOMAIN
+        d.mode = mode
         d.threshold = threshold
         d.dc_ignore_bins = capi.DC_IGNORE_NONE if dc_ignore_bins == 0 else dc_ignore_bins
         d.use_bandwidth = use_bandwidth
@@ -140,6 +140,15 @@ class Plan:
         if want_hits:
             hits = hits[: min(n_hits.value, cap)]
         return power, hits, trig
+
+    def collect_time_domain(self, slot):
+        """Time-domain plans: (max_db float32[B], min_db float32[B], above uint8[B]) -- process.cpp:203-237."""
+        nb = self._nb[slot]
+        mx, mn, ab = np.empty(nb, np.float32), np.empty(nb, np.float32), np.zeros(nb, np.uint8)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        capi.check(self._L.scn_collect_time_domain(self._h, slot, vp(mx), vp(mn), vp(ab)), "scn_collect_time_domain")
+        self._keep[slot] = None
+        return mx, mn, ab
 
     # -- plumbing -----------------------------------------------------------
     @property

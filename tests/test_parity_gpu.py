@@ -120,6 +120,106 @@ def test_pinned_double_buffered_submit(torch_cuda, oracle_mod):
 
 
 # ---------------------------------------------------------------------------------------
+# the other FFT sizes: BASELINE C1 (1024-pt, one cfloat buffer), C3 (8192-pt int16), 2048
+# ---------------------------------------------------------------------------------------
+def test_c1_known_answer_tone_1024(torch_cuda, oracle_mod):
+    """BASELINE config C1 + SURVEY 8c known answer: one 1024-pt cfloat buffer, five hits around 101 MHz."""
+    g = np.load(os.path.join(GOLD, "known_answer_tone.npz"))
+    n = int(g["n"])
+    x = (0.5 * np.exp(2j * np.pi * 128 * np.arange(n) / n)).astype(np.complex64)[None]
+    with Plan(n, int(g["sample_rate"]), float(g["threshold"]), max_batch=1) as plan:
+        plan.submit_device(0, _to_dev(torch_cuda, x), 1, [float(g["center_freq"])], [42])
+        p, h, t = plan.collect(0)
+    assert h["i"].tolist() == g["hit_i"].tolist() and h["freq_hz"].tolist() == g["hit_freq"].tolist()
+    assert np.all(h["seq_id"] == 42) and t.tolist() == [0]
+    assert np.abs(h["power_db"] - g["hit_db64"]).max() < 1e-5
+    assert "freq %d power_db %f" % (h["freq_hz"][2], h["power_db"][2]) == "freq 100999680 power_db 22.636375"
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 8192])
+def test_sizes_cfloat_vs_oracle_and_golden(torch_cuda, oracle_mod, n):
+    nb = {1024: 300, 2048: 130, 8192: 70}[n]          # not a multiple of the resident grid
+    x = synth.cfloat_batch(n, nb, seed=40 + n)
+    fc = 3e6 + 6e6 * np.arange(nb)
+    p_ref, _, _ = oracle_mod.Oracle(n, FS, 1e9).run(x, threads=4)
+    thr = tol.pick_threshold(p_ref, n, start=8.0)
+    (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, capi.KIND_FLOAT_COMPLEX, x, fc, None, thr)
+    print(n, tol.compare_spectra(p, p_ref))
+    assert len(h_ref) > 20
+    _assert_hits_equal(h, h_ref)
+    assert np.array_equal(t, t_ref)
+    gp = os.path.join(GOLD, f"spectrum_n{n}.npz")
+    if os.path.exists(gp):
+        g = np.load(gp)
+        xg = synth.cfloat_batch(n, int(g["n_buffers"]), int(g["seed"]))
+        with Plan(n, FS, 1e9, max_batch=8) as plan:
+            plan.submit_device(0, _to_dev(torch_cuda, xg), len(xg))
+            pg, _, _ = plan.collect(0)
+        assert tol.compare_spectra(pg, g["db64"])["max_rel_power_vs_max_bin_mean"] < 5e-6
+
+
+@pytest.mark.parametrize("n,kind,enob,dc", [
+    (8192, capi.KIND_SHORT_COMPLEX, 12, False),    # BASELINE config C3
+    (8192, capi.KIND_SHORT_COMPLEX, 12, True),
+    (8192, capi.KIND_BYTE_COMPLEX, 8, False),
+    (8192, capi.KIND_SHORT, 12, True),
+    (1024, capi.KIND_SHORT_COMPLEX, 12, True),
+    (1024, capi.KIND_BYTE_COMPLEX, 8, True),
+    (2048, capi.KIND_SHORT, 12, False),
+    (2048, capi.KIND_SHORT_COMPLEX, 16, True),
+])
+def test_sizes_integer_kinds(torch_cuda, oracle_mod, n, kind, enob, dc):
+    nb = 37
+    x = synth.cfloat_batch(n, nb, seed=50 + n, sigma=0.1) + np.complex64(0.015 - 0.01j)
+    raw = synth.quantize(x, kind)
+    fc = 9e8 + 6e6 * np.arange(nb)
+    p_ref, _, _ = oracle_mod.Oracle(n, FS, 1e9, kind=kind, enob=enob, correct_dc=dc).run(raw, threads=4)
+    thr = tol.pick_threshold(p_ref, n, start=float(np.quantile(p_ref, 0.999)))
+    (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, kind, raw, fc, None, thr, enob, dc)
+    tol.compare_spectra(p, p_ref)
+    assert len(h_ref) > 0
+    _assert_hits_equal(h, h_ref)
+    assert np.array_equal(t, t_ref)
+
+
+@pytest.mark.parametrize("n", [1024, 8192])
+def test_sizes_all_bins_hit_mask(torch_cuda, oracle_mod, n):
+    """mask edges (DC window, use-band) and the i <-> j mapping at the other sizes"""
+    nb = 3
+    x = synth.cfloat_batch(n, nb, seed=60 + n, sigma=0.1)
+    fc = np.array([1e9, 2e9, 3e9])
+    (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, capi.KIND_FLOAT_COMPLEX, x, fc, None,
+                                                 -200.0, max_hits=nb * n * 2)
+    assert len(h) == nb * tol.evaluated_mask(n).sum()
+    _assert_hits_equal(h, h_ref)
+    assert np.array_equal(t, t_ref)        # 1024: 762 hits <= 1047 -> 0 ; 8192: 6138 -> 1
+
+
+def test_c3_full_batch_8192_int16(torch_cuda, oracle_mod):
+    """BASELINE config C3 at a full batch: 4096 x 8192-pt int16 buffers, every buffer vs the oracle."""
+    n, nb = 8192, 4096
+    xd = synth.cfloat_batch_torch(n, nb, seed=3, device="cuda", sigma=0.1)
+    raw_d = torch_cuda.clamp(torch_cuda.round(xd * 2047.0), -2048, 2047).to(torch_cuda.int16).contiguous()
+    del xd
+    raw = raw_d.cpu().numpy()
+    fc = 3e6 + 6e6 * np.arange(nb)
+    o = oracle_mod.Oracle(n, FS, 12.0, kind=capi.KIND_SHORT_COMPLEX, enob=12)
+    p_ref, h_ref, t_ref = o.run(raw, fc, threads=8)
+    with Plan(n, FS, 12.0, kind=capi.KIND_SHORT_COMPLEX, enob=12, max_batch=nb, max_hits=1 << 22) as plan:
+        plan.submit_device(0, raw_d, nb, fc)
+        p, h, t = plan.collect(0, hit_cap=1 << 22)
+    print("C3 full batch vs oracle:", tol.compare_spectra(p, p_ref))
+    m = tol.evaluated_mask(n)
+    near = np.zeros((nb, n), bool)
+    near[:, m] = np.abs(p_ref[:, m] - 12.0) < tol.GUARD_DB
+    key = lambda a: a["seq_id"].astype(np.int64) * n + a["i"]       # noqa: E731
+    jj = lambda a: (a["i"].astype(np.int64) + n // 2) % n           # noqa: E731
+    assert np.array_equal(key(h[~near[h["seq_id"].astype(np.int64), jj(h)]]),
+                          key(h_ref[~near[h_ref["seq_id"].astype(np.int64), jj(h_ref)]]))
+    assert np.array_equal(t, t_ref)
+
+
+# ---------------------------------------------------------------------------------------
 # integer wire formats (K1a-c) incl. the reference's quirks
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind,enob,dc", [
@@ -326,3 +426,41 @@ def test_c2_full_size(torch_cuda, oracle_mod):
     lhs = tol.db_to_power(p.astype(np.float64)).sum(axis=1)
     rhs = n * ((np.abs(x.astype(np.complex128)) ** 2) * w ** 2).sum(axis=1)
     assert np.abs(lhs / rhs - 1).max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------
+# time-domain mode (process.cpp:203-237), the CLI's default mode (scan.cpp:87)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,kind,enob,dc", [
+    (8192, capi.KIND_FLOAT_COMPLEX, 12, False),
+    (1000, capi.KIND_FLOAT_COMPLEX, 12, False),      # the time-domain path takes any sample count
+    (8192, capi.KIND_SHORT_COMPLEX, 12, True),
+    (4096, capi.KIND_SHORT, 12, False),
+    (2048, capi.KIND_BYTE_COMPLEX, 8, True),
+])
+def test_time_domain_mode(torch_cuda, oracle_mod, n, kind, enob, dc):
+    nb = 50
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal((nb, n)) + 1j * rng.standard_normal((nb, n))).astype(np.complex64) * 0.05
+    x[::3, 17] += 0.9                                  # a strong sample in every third buffer
+    x[5] = 0                                           # an all-zero buffer: -inf dB everywhere
+    raw = synth.quantize(x, kind)
+    o = oracle_mod.Oracle(n, FS, 0.0, kind=kind, enob=enob, correct_dc=dc)
+    flat = raw.reshape(nb, -1)
+    ref = [o.time_domain(o.convert(flat[b]), threshold=-1.5) for b in range(nb)]
+    ref_max = np.array([r[1] for r in ref], np.float32)
+    ref_min = np.array([r[2] for r in ref], np.float32)
+    ref_hit = np.array([r[0] for r in ref], np.uint8)
+    with Plan(n, FS, -1.5, kind=kind, enob=enob, correct_dc=dc, max_batch=64, mode=capi.MODE_TIME_DOMAIN) as plan:
+        plan.submit_device(0, _to_dev(torch_cuda, raw), nb, np.arange(nb) * 1e6)
+        mx, mn, ab = plan.collect_time_domain(0)
+        with pytest.raises(capi.ScannerError):
+            plan.submit_device(0, _to_dev(torch_cuda, raw), nb, np.arange(nb) * 1e6)
+            plan.collect(0)                            # wrong collect for this mode
+    fin = np.isfinite(ref_max) & np.isfinite(ref_min)
+    assert np.array_equal(np.isneginf(mn), np.isneginf(ref_min))
+    assert np.abs(mx[fin] - ref_max[fin]).max() < 1e-4 and np.abs(mn[fin] - ref_min[fin]).max() < 2e-3
+    clear = np.abs(ref_max - (-1.5)) > 1e-3
+    assert np.array_equal(ab[clear], ref_hit[clear]) and ref_hit.sum() >= nb // 3
+    # the all-zero buffer keeps the reference's odd initial maximum (process.cpp:207)
+    assert mx[5] == np.float32(1.17549435e-38) == ref_max[5]

@@ -33,8 +33,10 @@ def _assert_hits_equal(got, ref):
     assert len(got) == len(ref), (len(got), len(ref))
     for f in ("seq_id", "i", "freq_hz"):
         assert np.array_equal(got[f], ref[f]), f
-    # the reported value is the same float the spectrum holds; compare to the oracle loosely
-    assert np.abs(got["power_db"].astype(np.float64) - ref["power_db"]).max(initial=0) < 2e-3
+    # the reported value is the float the spectrum holds (spectra are compared bin by bin by
+    # tol.compare_spectra; a detection can sit on a bin far below the buffer mean, where two float32
+    # FFTs legitimately differ by more than the dB bar, so only a sanity bound here)
+    assert np.abs(got["power_db"].astype(np.float64) - ref["power_db"]).max(initial=0) < 2e-2
 
 
 def _run_both(torch, oracle_mod, n, kind, raw, fc, seq, thr, enob=12, correct_dc=False, slot=0, max_batch=None,
@@ -174,7 +176,7 @@ def test_sizes_integer_kinds(torch_cuda, oracle_mod, n, kind, enob, dc):
     raw = synth.quantize(x, kind)
     fc = 9e8 + 6e6 * np.arange(nb)
     p_ref, _, _ = oracle_mod.Oracle(n, FS, 1e9, kind=kind, enob=enob, correct_dc=dc).run(raw, threads=4)
-    thr = tol.pick_threshold(p_ref, n, start=float(np.quantile(p_ref, 0.999)))
+    thr = tol.pick_threshold(p_ref, n, start=float(np.quantile(p_ref[:, tol.evaluated_mask(n)], 0.999)))
     (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, kind, raw, fc, None, thr, enob, dc)
     tol.compare_spectra(p, p_ref)
     assert len(h_ref) > 0

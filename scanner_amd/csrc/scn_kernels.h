@@ -40,7 +40,7 @@ struct ScnFftArgs {
   uint32_t *ov_counter;       // monotonically increasing across submits
   uint32_t ov_base;           // its value before this submit (host-tracked)
   uint32_t ov_cap;
-  uint32_t *per_buffer_hits;  // [n_buffers] total hits of each buffer (pinned host memory)
+  uint32_t *per_buffer_hits;  // [n_buffers] total hits of each buffer (device memory)
 };
 
 // time-domain mode (process.cpp:203-237)

@@ -115,12 +115,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint3
 
 // Tunables (compile-time; scripts/build_variants.py builds one library per setting).
 // Cache-policy immediates of the buffer instructions on gfx950: bit0 = sc0, bit1 = nt, bit4 = sc1.
+// Both streams are touched exactly once, so both are non-temporal: measured with inputs AND outputs
+// rotated over 1.5 GiB (nothing can live in the 256 MiB Infinity Cache), a no-compute skeleton
+// of this kernel's traffic moves 5.66 TB/s with the default policy and 6.40 TB/s with nt on both
+// (scripts/membw.hip); the FFT kernel itself gains 4-5 %.
 #ifndef SCN_AUX_LD
-#define SCN_AUX_LD 0   // streaming loads: default policy (nt here loses when the stores are nt too)
+#define SCN_AUX_LD 2
 #endif
 #ifndef SCN_AUX_ST
-#define SCN_AUX_ST 2   // streaming dB stores: non-temporal -- the output is never re-read by the
-                       // kernel, keeping it out of L2/MALL is worth 15 % (87 -> 74 us on C2)
+#define SCN_AUX_ST 2
 #endif
 #ifndef SCN_PREFETCH
 #define SCN_PREFETCH 0 // 1: fetch the next buffer's raw samples into registers during the FFT
@@ -216,6 +219,28 @@ __device__ __forceinline__ int wave_sum(int v) {
   return v;
 }
 
+// Wave-wide reductions in 6 DPP steps (row_shr 1/2/4/8, then row_bcast15 / row_bcast31);
+// the result is read from lane 63 and returned as a wave-uniform scalar.
+#define SCN_DPP_STEP(OP, x, ctrl, rmask) x = x OP (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, true)
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t x) {
+  SCN_DPP_STEP(|, x, 0x111, 0xf);
+  SCN_DPP_STEP(|, x, 0x112, 0xf);
+  SCN_DPP_STEP(|, x, 0x114, 0xf);
+  SCN_DPP_STEP(|, x, 0x118, 0xf);
+  SCN_DPP_STEP(|, x, 0x142, 0xa);  // row_bcast15 into rows 1 and 3
+  SCN_DPP_STEP(|, x, 0x143, 0xc);  // row_bcast31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_add_u32(uint32_t x) {
+  SCN_DPP_STEP(+, x, 0x111, 0xf);
+  SCN_DPP_STEP(+, x, 0x112, 0xf);
+  SCN_DPP_STEP(+, x, 0x114, 0xf);
+  SCN_DPP_STEP(+, x, 0x118, 0xf);
+  SCN_DPP_STEP(+, x, 0x142, 0xa);
+  SCN_DPP_STEP(+, x, 0x143, 0xc);
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -249,7 +274,7 @@ struct Geo {
   static constexpr uint32_t P1 = T + (M < 32 ? M : 0);
   static constexpr uint32_t P2 = 256u + (M <= 16 ? 16u / M : 1u);
   static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots
-  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 16u;
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 2u * 4u + 64u * 4u + 8u;
   static constexpr uint32_t WAVES = T >= 64 ? T / 64 : 1;
   // resident workgroups per CU: 16 waves (12 with register prefetch) = 4 (3) per SIMD
   static constexpr uint32_t WG_PER_CU = (SCN_WG_PER_CU * 4u) / WAVES;
@@ -273,7 +298,8 @@ __global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftAr
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
   v2f *lds_tw2 = lds + G::EXCH;                              // [16][M]
   int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T);      // [16] DC-sum scratch (re[8], im[8])
-  int *lds_hits = lds_cnt + 16;                             // hits of the buffer in flight
+  int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
+  int *lds_hist = lds_hits + 2;                             // [64] finished per-buffer counts awaiting the flush
 
   const uint32_t t = threadIdx.x;
   const uint32_t p2 = t / M, c2 = t % M;  // pass-2 identity (p, c); also the (q, c) of the table entry below
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftAr
   for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t];
   // pass-2 twiddles W_{16M}^(c*q) = W_N^(16 c q), table [q][c] shared by the workgroup
   lds_tw2[t] = args.twiddle[(16 * p2 * c2) & (N - 1)];
-  if (t == 0) *lds_hits = 0;
+  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
   __syncthreads();
 
   v2f *w1 = lds + t;                      // + p*P1
@@ -300,6 +326,27 @@ __global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftAr
   const v2f *tw2 = lds_tw2 + c2;          // + q*M
   // global store offset of output o: voffset (per lane) + scalar part
   const uint32_t st_voff = (M == 32) ? (kl32 + 4096u * e) * 4u : t * 4u;
+
+  // K5 mask of this thread's 16 output bins (process.cpp:46-52): depends on (t, o) only
+  const uint32_t jbase = (M == 32) ? kl32 + 4096u * e : t;
+  uint32_t keepmask = 0;
+  if (HITS) {
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+      const uint32_t joff = (M == 32) ? 256u * o : T * (o / M) + 256u * (o % M);
+      const uint32_t j = jbase + joff;
+      const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
+      const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
+      keepmask |= keep ? (1u << o) : 0u;
+    }
+  }
+  uint32_t par = 0;        // which of the two LDS hit counters the buffer in flight uses
+  uint32_t n_done = 0;     // buffers of this workgroup whose recorders have been started
+  // Per-buffer hit counts (device memory; the host copies them back on its own stream) are parked
+  // in LDS and flushed by wave 0, up to 64 per store instruction.
+  auto flush_counts = [&](uint32_t first_k, uint32_t count) {
+    if (t < count) args.per_buffer_hits[blockIdx.x + (first_k + t) * gridDim.x] = (uint32_t)lds_hist[t];
+  };
 
   typename L::raw_t raw[16];
   if (PF && blockIdx.x < args.n_buffers) {
@@ -370,6 +417,17 @@ __global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftAr
       w1[p * P1] = to_v2f(y);
     }
     __syncthreads();
+    if (HITS) {
+      // every wave has passed the barrier above, so the previous buffer's recorders are done
+      if (wave == 0 && n_done) {
+        const uint32_t k = n_done - 1;  // index (within this workgroup) of the buffer just completed
+        if (t == 0) {
+          lds_hist[k & 63u] = lds_hits[par ^ 1];
+          lds_hits[par ^ 1] = 0;
+        }
+        if ((k & 63u) == 63u) flush_counts(k - 63u, 64u);  // same wave: LDS program order suffices
+      }
+    }
 
     // ---- pass 2: thread (p, c): DFT over b, twiddle W_{16M}^(c q) ----
 #pragma unroll
@@ -420,9 +478,8 @@ __global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftAr
 
     // ---- K4 + K5: output o of this thread is bin j = jbase + joff(o) ----
     //   M <= 16: o = u*M + r, j = t + T*u + 256*r        M == 32: o = r', j = kl + 4096*e + 256*r'
-    v16f db;  // a true vector: the slow path below indexes it with a wave-uniform o (s_set_gpr_idx)
-    uint32_t hitmask = 0;
-    const uint32_t jbase = (M == 32) ? kl32 + 4096u * e : t;
+    v16f db;  // a true vector: the recording path below indexes it with a wave-uniform o (s_set_gpr_idx)
+    float dmax = -3.40282347e+38f;  // cheap pre-filter: max over this thread's 16 bins (NaN-free: max ignores NaN)
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, args.power_db ? 4u * N : 0u);
 #pragma unroll
     for (int o = 0; o < 16; o++) {
@@ -431,44 +488,55 @@ __global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftAr
       const float d = power_db(v[out_reg<M>(o)]);
       db[o] = d;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 4u * joff, AUX_ST);
-      if (HITS) {
-        uint32_t j = jbase + joff;
-        uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
-        bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
-        hitmask |= (keep && (d > args.threshold)) ? (1u << o) : 0u;
-      }
+      if (HITS) dmax = fmaxf(dmax, d);
     }
+    __syncthreads();  // exchange area free again
     if (HITS) {
-      if (__ballot(hitmask != 0)) {  // rare: some lane of this wave holds a detection
-#pragma unroll 1
-        for (int o = 0; o < 16; o++) {
-          bool hit = (hitmask >> o) & 1u;
-          unsigned long long m = __ballot(hit);
-          if (!m) continue;
-          // slot inside this buffer's region: one LDS atomic per wave and o
+      // Recording runs AFTER the barrier: a wave that holds detections does not stall the other
+      // waves of its workgroup, they go on to the next buffer and meet it at that buffer's first
+      // barrier (its loads are in flight meanwhile).  Only such a wave evaluates the per-bin test.
+      if (__ballot(dmax > args.threshold)) {
+        uint32_t hitmask = 0;
+#pragma unroll
+        for (int o = 0; o < 16; o++) hitmask |= (db[o] > args.threshold) ? (1u << o) : 0u;  // strict >, process.cpp:54
+        hitmask &= keepmask;
+        // one slot allocation per wave, then only the output indices some lane actually hit
+        const uint32_t total = wave_add_u32((uint32_t)__popc(hitmask));
+        if (total) {
+          uint32_t wm = wave_or_u32(hitmask);
           uint32_t base = 0;
-          if (lane == 0) base = (uint32_t)atomicAdd(lds_hits, (int)__popcll(m));
+          if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
           base = __builtin_amdgcn_readfirstlane(base);
-          if (hit) {
-            uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            const uint32_t joff = (M == 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M);
-            ScnDevHit rec = ScnDevHit{buf, (jbase + joff) ^ (N / 2), db[o], 0u};
-            if (pos < args.hit_region) {
-              args.hits[(size_t)buf * args.hit_region + pos] = rec;
-            } else {  // region full: spill through the device-scope counter
-              uint32_t opos = atomicAdd(args.ov_counter, 1u) - args.ov_base;
-              if (opos < args.ov_cap) args.ov_hits[opos] = rec;
+          while (wm) {
+            const int o = __builtin_ctz(wm);  // wave-uniform
+            wm &= wm - 1u;
+            const bool hit = (hitmask >> o) & 1u;
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+              const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+              const uint32_t joff = (M == 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M);
+              const ScnDevHit rec = ScnDevHit{buf, (jbase + joff) ^ (N / 2), db[o], 0u};
+              if (pos < args.hit_region) {
+                args.hits[(size_t)buf * args.hit_region + pos] = rec;
+              } else {  // region full: spill through the device-scope counter
+                uint32_t opos = atomicAdd(args.ov_counter, 1u) - args.ov_base;
+                if (opos < args.ov_cap) args.ov_hits[opos] = rec;
+              }
             }
+            base += (uint32_t)__popcll(m);
           }
         }
       }
+      n_done++;
+      par ^= 1;
     }
-    __syncthreads();  // exchange area free again; this buffer's hit count complete
-    if (HITS) {
-      if (t == 0) {
-        args.per_buffer_hits[buf] = (uint32_t)*lds_hits;
-        *lds_hits = 0;  // visible to the next buffer's recorders after its first barrier
-      }
+  }
+  if (HITS) {
+    __syncthreads();  // last buffer's recorders done
+    if (wave == 0 && n_done) {
+      const uint32_t k = n_done - 1;
+      if (t == 0) lds_hist[k & 63u] = lds_hits[par ^ 1];
+      flush_counts(k & ~63u, (k & 63u) + 1u);
     }
   }
 }

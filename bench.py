@@ -225,7 +225,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "scn_fft4096_kernel", "kernel_avg_ms": round(kernel_ms, 5),
+                "kernel": "scn_fft_kernel<M=n/256, kind, dc, hits>", "kernel_avg_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_sample": algo_bytes_per_sample,
                 "algorithmic_bytes_per_launch": algo_bytes_per_launch,
             },

@@ -139,8 +139,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint3
                        // input (-> 3 waves per SIMD), 16 for the integer formats; worth 3-4 % on C2.
                        // (A "touch-ahead" of the next buffer into L2/Infinity Cache was measured too: -5 %.)
 #endif
-#ifndef SCN_WG_PER_CU
-#define SCN_WG_PER_CU (SCN_PREFETCH ? 3 : 4)
+#ifndef SCN_WAVES_PER_SIMD_PF
+#define SCN_WAVES_PER_SIMD_PF 3  // VGPR budget 168 with the prefetch registers
 #endif
 
 template <int KIND>
@@ -286,8 +286,11 @@ struct Geo {
   static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots
   static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 2u * 4u + 64u * 4u + 8u;
   static constexpr uint32_t WAVES = T >= 64 ? T / 64 : 1;
-  // resident workgroups per CU: 16 waves (12 with register prefetch) = 4 (3) per SIMD
-  static constexpr uint32_t WG_PER_CU = (SCN_WG_PER_CU * 4u) / WAVES;
+  // Register prefetch costs a wave per SIMD (4 -> 3).  At 8192 points a workgroup is 8 waves, so
+  // 3 waves per SIMD would leave ONE workgroup per CU: no prefetch there, two workgroups instead.
+  static constexpr bool PREFETCH = SCN_PREFETCH != 0 && M <= 16;
+  static constexpr uint32_t WAVES_PER_SIMD = PREFETCH ? SCN_WAVES_PER_SIMD_PF : 4;
+  static constexpr uint32_t WG_PER_CU = (WAVES_PER_SIMD * 4u) / WAVES;
 };
 
 // natural output index o of a thread -> register that holds it after pass 3
@@ -297,11 +300,11 @@ __device__ __forceinline__ constexpr int out_reg(int o) {
 }
 
 template <int M, int KIND, bool DC, bool HITS>
-__global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftArgs args) {
+__global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel(ScnFftArgs args) {
   typedef Geo<M> G;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
-  constexpr bool PF = SCN_PREFETCH != 0;
+  constexpr bool PF = G::PREFETCH;
   constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -455,8 +458,11 @@ __global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftAr
 #pragma unroll
       for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[2 * c * P2]);
       fft16(v);
-      // radix 2 across the wave's two halves: X[r'] = Y0 + W32^r' Y1, X[r'+16] = Y0 - W32^r' Y1
-      const float sel = e ? 1.0f : 0.0f;
+      // radix 2 across the wave's two halves: X[r'] = Y0 + W32^r' Y1, X[r'+16] = Y0 - W32^r' Y1.
+      // v_permlane32_swap exchanges the upper half of one register with the lower half of another:
+      // applied to two copies of y it leaves (Y0, W Y1) in BOTH halves, so the butterfly is one
+      // FMA with a per-half sign -- no LDS crossbar (ds_bpermute) traffic.
+      const float sel = e ? 1.0f : 0.0f, sgn = e ? -1.0f : 1.0f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         cf y = v[OUT16(r)];
@@ -467,8 +473,10 @@ __global__ __launch_bounds__(16 * M, SCN_WG_PER_CU) void scn_fft_kernel(ScnFftAr
           cf w = cf{e ? cr : 1.0f, -sr * sel};
           y = cmul(y, w);
         }
-        cf o = cf{__shfl_xor(y.x, 32, 64), __shfl_xor(y.y, 32, 64)};  // the partner's value
-        v[OUT16(r)] = e ? o - y : y + o;
+        auto sx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.x), false, false);
+        auto sy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y.y), __builtin_bit_cast(unsigned, y.y), false, false);
+        v[OUT16(r)] = cf{__builtin_fmaf(__builtin_bit_cast(float, (unsigned)sx[1]), sgn, __builtin_bit_cast(float, (unsigned)sx[0])),
+                         __builtin_fmaf(__builtin_bit_cast(float, (unsigned)sy[1]), sgn, __builtin_bit_cast(float, (unsigned)sy[0]))};
       }
     } else {
 #pragma unroll

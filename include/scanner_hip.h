@@ -166,6 +166,42 @@ int scn_frequency_table(uint32_t sample_rate, double start, double stop,
                         uint32_t shard, uint32_t n_shards, double *out,
                         uint32_t cap, uint32_t *count, uint32_t *first);
 
+/* ------------------------------------------------------------------------------------
+ * Streaming Welch PSD (BASELINE config 5).  No counterpart in the reference -- it never
+ * overlaps or averages -- so these entry points replace nothing; they
+ * reuse its arithmetic: the window of process.cpp:14-21, the forward FFT of fft.cpp:20-25,
+ * the dB map of utility.cpp:86-98.  Definition: segments of n complex-float samples every
+ * n/2 (50 % overlap), |X|^2 averaged over segments_per_psd consecutive segments, output
+ * psd_db[k] = 5*log10(mean |X[k]|^2), natural bin order.  A submit of n_psd PSDs consumes
+ * (n_psd*segments_per_psd + 1) * n/2 contiguous samples.  Same slot / status conventions as
+ * scn_plan.  The pinned path (scn_welch_submit) replays a captured hipGraph:
+ * H2D copy -> column kernel -> row kernel -> D2H copy of the PSDs.
+ * ------------------------------------------------------------------------------------ */
+typedef struct scn_welch_desc {
+  uint32_t struct_size;
+  uint32_t n;                /* segment length; 65536 */
+  uint32_t segments_per_psd; /* K >= 1 */
+  uint32_t window_type;      /* 0 -> SCN_WIN_BLACKMAN_HARRIS */
+  uint32_t max_psd;          /* PSDs per submit (>= 1) */
+  int32_t device_id;
+  uint32_t reserved[4];
+} scn_welch_desc;
+
+typedef struct scn_welch scn_welch;
+
+int scn_welch_create(const scn_welch_desc *desc, scn_welch **out);
+int scn_welch_destroy(scn_welch *w);
+/* complex samples one submit of n_psd PSDs consumes */
+int scn_welch_samples(const scn_welch *w, uint32_t n_psd, size_t *n_samples);
+/* pinned input staging slot (max_psd PSDs worth of samples), plan-owned */
+int scn_welch_host_buffer(scn_welch *w, int slot, void **ptr, size_t *bytes);
+int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd);
+/* samples already in device memory; d_psd_db optional device destination (n_psd*n floats) */
+int scn_welch_submit_device(scn_welch *w, int slot, const void *d_samples, uint32_t n_psd,
+                            float *d_psd_db);
+/* wait and fetch the n_psd*n dB values (psd_db may be NULL to only wait) */
+int scn_welch_collect(scn_welch *w, int slot, float *psd_db);
+
 #ifdef __cplusplus
 }
 #endif

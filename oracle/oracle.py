@@ -85,6 +85,7 @@ def lib():
         L.scn_oracle_run_batch.restype = C.c_uint64
         L.scn_oracle_run_batch.argtypes = [
             C.POINTER(Params), C.c_int, u32, C.c_int, vp, u32, vp, vp, vp, vp, C.c_uint64, vp, u32]
+        L.scn_oracle_welch.argtypes = [vp, u32, u32, u32, vp]
         _lib = L
     return _lib
 
@@ -217,3 +218,29 @@ def ref64_spectrum(x_c64, window_f32):
     with np.errstate(divide="ignore"):
         dB = 5.0 * np.log10(P)
     return X, P, dB
+
+
+def welch(x_c64, n=65536, k=16, n_psd=1):
+    """BASELINE C5: float32 Welch PSD (dB) of a complex64 stream; see scn_oracle_welch."""
+    x = np.ascontiguousarray(x_c64, np.complex64)
+    assert x.size >= (n_psd * k + 1) * (n // 2)
+    out = np.empty((n_psd, n), np.float32)
+    lib().scn_oracle_welch(_p(x), n, k, n_psd, _p(out))
+    return out
+
+
+def ref64_welch(x_c64, window_f32, n=65536, k=16, n_psd=1):
+    """float64 evaluation of the same definition."""
+    x = np.asarray(x_c64).astype(np.complex128)
+    w = np.asarray(window_f32).astype(np.float64)
+    hop = n // 2
+    out = np.empty((n_psd, n))
+    for p in range(n_psd):
+        acc = np.zeros(n)
+        for s in range(k):
+            seg = x[(p * k + s) * hop:(p * k + s) * hop + n] * w
+            X = np.fft.fft(seg)
+            acc += X.real ** 2 + X.imag ** 2
+        with np.errstate(divide="ignore"):
+            out[p] = 5.0 * np.log10(acc / k)
+    return out

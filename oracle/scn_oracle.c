@@ -437,3 +437,35 @@ uint64_t scn_oracle_run_batch(const scn_oracle_params *p, int kind, uint32_t eno
   free(ws);
   return total;
 }
+
+/* ---- Welch PSD (BASELINE C5) --------------------------------------------- */
+
+void scn_oracle_welch(const float *x, uint32_t n, uint32_t k, uint32_t n_psd, float *psd_db) {
+  const uint32_t hop = n / 2;
+  scn_oracle_fft *fft = scn_oracle_fft_create(n);
+  float *win = (float *)aligned_alloc(64, sizeof(float) * n);
+  float *seg = (float *)aligned_alloc(64, sizeof(float) * 2 * n);
+  float *out = (float *)aligned_alloc(64, sizeof(float) * 2 * n);
+  float *acc = (float *)aligned_alloc(64, sizeof(float) * n);
+  scn_oracle_window_blackman_harris(win, n);
+  const double log10v = log2(10.0);
+  for (uint32_t p = 0; p < n_psd; p++) {
+    memset(acc, 0, sizeof(float) * n);
+    for (uint32_t s = 0; s < k; s++) {
+      const float *src = x + 2 * (size_t)(p * k + s) * hop;
+      memcpy(seg, src, sizeof(float) * 2 * n);
+      scn_oracle_window_apply(seg, win, n);
+      scn_oracle_fft_process(fft, out, seg);
+      for (uint32_t j = 0; j < n; j++) acc[j] += out[2 * j] * out[2 * j] + out[2 * j + 1] * out[2 * j + 1];
+    }
+    for (uint32_t j = 0; j < n; j++) {
+      float mean = acc[j] / (float)k;
+      psd_db[(size_t)p * n + j] = (float)(10 * log2((double)sqrtf(mean)) / log10v);
+    }
+  }
+  free(acc);
+  free(out);
+  free(seg);
+  free(win);
+  scn_oracle_fft_destroy(fft);
+}

@@ -127,6 +127,12 @@ uint64_t scn_oracle_run_batch(const scn_oracle_params *p, int kind,
                               scn_oracle_hit *hits, uint64_t cap,
                               uint8_t *trigger, uint32_t n_threads);
 
+/* BASELINE config C5 (no reference counterpart; definition in SURVEY.md 8d): Welch PSD of a
+ * complex-float stream.  Segments of n samples every n/2, window of process.cpp:14-21, FFT of
+ * fft.cpp:20-25, |X|^2 averaged over k consecutive segments in float, dB map of
+ * utility.cpp:86-98 (10*log2(sqrt(mean))/log2(10)).  x holds (n_psd*k + 1) * n/2 samples. */
+void scn_oracle_welch(const float *x, uint32_t n, uint32_t k, uint32_t n_psd, float *psd_db);
+
 #ifdef __cplusplus
 }
 #endif

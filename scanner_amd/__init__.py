@@ -11,5 +11,5 @@ from . import capi  # noqa: F401
 from .capi import (  # noqa: F401
     KIND_BYTE_COMPLEX, KIND_SHORT, KIND_SHORT_COMPLEX, KIND_FLOAT_COMPLEX, OUT_HITS, OUT_SPECTRUM,
     HIT_DTYPE, ScannerError)
-from .plan import Plan  # noqa: F401
+from .plan import Plan, WelchPlan  # noqa: F401
 from . import synth, sweep  # noqa: F401,E402

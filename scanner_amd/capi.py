@@ -51,6 +51,19 @@ class PlanDesc(C.Structure):
     ]
 
 
+class WelchDesc(C.Structure):
+    """struct scn_welch_desc"""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n", C.c_uint32),
+        ("segments_per_psd", C.c_uint32),
+        ("window_type", C.c_uint32),
+        ("max_psd", C.c_uint32),
+        ("device_id", C.c_int32),
+        ("reserved", C.c_uint32 * 4),
+    ]
+
+
 # every symbol include/scanner_hip.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -69,6 +82,13 @@ SYMBOLS = {
     "scn_plan_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "scn_device_spectrum": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "scn_plan_window": (C.c_int, [_vp, _vp, C.c_uint32]),
+    "scn_welch_create": (C.c_int, [C.POINTER(WelchDesc), C.POINTER(_vp)]),
+    "scn_welch_destroy": (C.c_int, [_vp]),
+    "scn_welch_samples": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_size_t)]),
+    "scn_welch_host_buffer": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "scn_welch_submit": (C.c_int, [_vp, C.c_int, C.c_uint32]),
+    "scn_welch_submit_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, _vp]),
+    "scn_welch_collect": (C.c_int, [_vp, C.c_int, _vp]),
     "scn_frequency_table": (C.c_int, [C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32,
                                       C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }

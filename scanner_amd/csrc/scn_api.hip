@@ -555,3 +555,243 @@ int scn_frequency_table(uint32_t sample_rate, double start, double stop, double 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Welch PSD (BASELINE C5)
+// ---------------------------------------------------------------------------------------
+namespace {
+struct WelchSlot {
+  void *h_in = nullptr;     // pinned samples
+  float *h_psd = nullptr;   // pinned results (graph path)
+  void *d_in = nullptr;
+  float *d_psd = nullptr;
+  float *cur_psd = nullptr; // device location of the pending results
+  bool via_graph = false;
+  hipGraphExec_t graph = nullptr;  // captured H2D -> kernel A -> kernel B -> D2H for graph_npsd PSDs
+  uint32_t graph_npsd = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  uint32_t n_psd = 0;
+};
+}  // namespace
+
+struct scn_welch {
+  scn_welch_desc d;
+  int num_cus = 0;
+  hipStream_t stream = nullptr;
+  uint32_t hop = 0;
+  float *d_window = nullptr;
+  scn_v2f *d_twiddle = nullptr;
+  void *d_work = nullptr;  // [max_psd*K][n] complex
+  WelchSlot slot[SCN_NUM_SLOTS];
+};
+
+namespace {
+size_t welch_samples(const scn_welch *w, uint32_t n_psd) {
+  return ((size_t)n_psd * w->d.segments_per_psd + 1u) * w->hop;
+}
+
+int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd) {
+  ScnWelchArgs a;
+  a.in = d_in;
+  a.window = w->d_window;
+  a.twiddle = w->d_twiddle;
+  a.work = w->d_work;
+  a.psd_db = d_psd;
+  a.n_segments = n_psd * w->d.segments_per_psd;
+  a.hop = w->hop;
+  a.k = w->d.segments_per_psd;
+  a.n_psd = n_psd;
+  a.inv_k = 1.0f / (float)w->d.segments_per_psd;
+  SCN_HIP(scn_launch_welch(a, w->num_cus, w->stream));
+  return SCN_OK;
+}
+
+int welch_check(scn_welch *w, int slot) {
+  if (!w) return fail(SCN_E_INVALID, "null welch plan");
+  if (slot < 0 || slot >= SCN_NUM_SLOTS) return fail(SCN_E_INVALID, "slot %d out of range", slot);
+  return SCN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int scn_welch_create(const scn_welch_desc *desc, scn_welch **out) {
+  if (!desc || !out) return fail(SCN_E_INVALID, "null argument");
+  *out = nullptr;
+  if (desc->struct_size != sizeof(scn_welch_desc)) return fail(SCN_E_INVALID, "scn_welch_desc.struct_size mismatch");
+  scn_welch_desc d = *desc;
+  if (!d.window_type) d.window_type = SCN_WIN_BLACKMAN_HARRIS;
+  if (d.n != 65536) return fail(SCN_E_INVALID, "unsupported Welch segment length %u (65536)", d.n);
+  if (d.segments_per_psd < 1 || d.max_psd < 1) return fail(SCN_E_INVALID, "segments_per_psd and max_psd must be >= 1");
+  if (d.window_type != SCN_WIN_BLACKMAN_HARRIS && d.window_type != SCN_WIN_RECTANGULAR)
+    return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SCN_E_NO_DEVICE, "no HIP device visible");
+  if (d.device_id < 0 || d.device_id >= ndev) return fail(SCN_E_INVALID, "device_id %d out of range", d.device_id);
+  SCN_HIP(hipSetDevice(d.device_id));
+  scn_welch *w = new (std::nothrow) scn_welch();
+  if (!w) return fail(SCN_E_NOMEM, "out of host memory");
+  w->d = d;
+  w->hop = d.n / 2;
+  std::vector<float> win;
+  build_window(d.window_type, d.n, win);
+  std::vector<float> tw(2 * (size_t)d.n);
+  const double pi = 3.14159265358979323846;
+  for (uint32_t m = 0; m < d.n; m++) {
+    double a = -2.0 * pi * (double)m / (double)d.n;
+    tw[2 * m] = (float)std::cos(a);
+    tw[2 * m + 1] = (float)std::sin(a);
+  }
+  hipDeviceProp_t prop;
+  hipError_t e = hipSuccess;
+  do {
+    if ((e = hipGetDeviceProperties(&prop, d.device_id)) != hipSuccess) break;
+    w->num_cus = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)) != hipSuccess) break;
+    if ((e = hipMalloc(&w->d_window, sizeof(float) * d.n)) != hipSuccess) break;
+    if ((e = hipMalloc(&w->d_twiddle, sizeof(float) * 2 * d.n)) != hipSuccess) break;
+    if ((e = hipMalloc(&w->d_work, sizeof(float) * 2 * (size_t)d.n * d.max_psd * d.segments_per_psd)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(w->d_window, win.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, w->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(w->d_twiddle, tw.data(), sizeof(float) * 2 * d.n, hipMemcpyHostToDevice, w->stream)) != hipSuccess) break;
+    e = hipStreamSynchronize(w->stream);
+  } while (0);
+  if (e != hipSuccess) {
+    int st = fail(e == hipErrorOutOfMemory ? SCN_E_NOMEM : SCN_E_HIP, "scn_welch_create: %s", hipGetErrorString(e));
+    scn_welch_destroy(w);
+    return st;
+  }
+  *out = w;
+  return SCN_OK;
+}
+
+int scn_welch_destroy(scn_welch *w) {
+  if (!w) return SCN_OK;
+  (void)hipSetDevice(w->d.device_id);
+  if (w->stream) (void)hipStreamSynchronize(w->stream);
+  for (int i = 0; i < SCN_NUM_SLOTS; i++) {
+    WelchSlot &s = w->slot[i];
+    if (s.graph) (void)hipGraphExecDestroy(s.graph);
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_psd) (void)hipHostFree(s.h_psd);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_psd) (void)hipFree(s.d_psd);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  if (w->d_window) (void)hipFree(w->d_window);
+  if (w->d_twiddle) (void)hipFree(w->d_twiddle);
+  if (w->d_work) (void)hipFree(w->d_work);
+  if (w->stream) (void)hipStreamDestroy(w->stream);
+  delete w;
+  return SCN_OK;
+}
+
+int scn_welch_samples(const scn_welch *w, uint32_t n_psd, size_t *n_samples) {
+  if (!w || !n_samples) return fail(SCN_E_INVALID, "null argument");
+  *n_samples = welch_samples(w, n_psd);
+  return SCN_OK;
+}
+
+int scn_welch_host_buffer(scn_welch *w, int slot, void **ptr, size_t *bytes) {
+  int st = welch_check(w, slot);
+  if (st) return st;
+  if (!ptr) return fail(SCN_E_INVALID, "null argument");
+  WelchSlot &s = w->slot[slot];
+  SCN_HIP(hipSetDevice(w->d.device_id));
+  const size_t total = welch_samples(w, w->d.max_psd) * 8u;
+  if (!s.h_in) SCN_HIP(hipHostMalloc(&s.h_in, total, hipHostMallocDefault));
+  *ptr = s.h_in;
+  if (bytes) *bytes = total;
+  return SCN_OK;
+}
+
+int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
+  int st = welch_check(w, slot);
+  if (st) return st;
+  WelchSlot &s = w->slot[slot];
+  if (n_psd < 1 || n_psd > w->d.max_psd) return fail(SCN_E_INVALID, "n_psd %u out of range (1..%u)", n_psd, w->d.max_psd);
+  if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
+  if (!s.h_in) return fail(SCN_E_STATE, "slot %d: scn_welch_host_buffer was never called", slot);
+  SCN_HIP(hipSetDevice(w->d.device_id));
+  const size_t in_bytes = welch_samples(w, w->d.max_psd) * 8u, psd_bytes = sizeof(float) * (size_t)w->d.n * w->d.max_psd;
+  if (!s.d_in) SCN_HIP(hipMalloc(&s.d_in, in_bytes));
+  if (!s.d_psd) SCN_HIP(hipMalloc(&s.d_psd, psd_bytes));
+  if (!s.h_psd) SCN_HIP(hipHostMalloc(&s.h_psd, psd_bytes, hipHostMallocDefault));
+  if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if (!s.graph || s.graph_npsd != n_psd) {
+    // capture the slot's inner loop once per batch size: H2D -> columns -> rows -> D2H
+    if (s.graph) {
+      (void)hipGraphExecDestroy(s.graph);
+      s.graph = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    SCN_HIP(hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, welch_samples(w, n_psd) * 8u, hipMemcpyHostToDevice, w->stream);
+    int inner = SCN_OK;
+    if (e == hipSuccess) inner = welch_enqueue(w, s.d_in, n_psd, s.d_psd);
+    if (e == hipSuccess && inner == SCN_OK)
+      e = hipMemcpyAsync(s.h_psd, s.d_psd, sizeof(float) * (size_t)w->d.n * n_psd, hipMemcpyDeviceToHost, w->stream);
+    hipError_t e2 = hipStreamEndCapture(w->stream, &graph);
+    if (e != hipSuccess || e2 != hipSuccess || inner != SCN_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      if (inner != SCN_OK) return inner;
+      return fail(SCN_E_HIP, "Welch graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    e = hipGraphInstantiate(&s.graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(SCN_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    s.graph_npsd = n_psd;
+  }
+  SCN_HIP(hipGraphLaunch(s.graph, w->stream));
+  SCN_HIP(hipEventRecord(s.done, w->stream));
+  s.pending = true;
+  s.via_graph = true;
+  s.n_psd = n_psd;
+  s.cur_psd = s.d_psd;
+  return SCN_OK;
+}
+
+int scn_welch_submit_device(scn_welch *w, int slot, const void *d_samples, uint32_t n_psd, float *d_psd_db) {
+  int st = welch_check(w, slot);
+  if (st) return st;
+  WelchSlot &s = w->slot[slot];
+  if (n_psd < 1 || n_psd > w->d.max_psd) return fail(SCN_E_INVALID, "n_psd %u out of range (1..%u)", n_psd, w->d.max_psd);
+  if (!d_samples) return fail(SCN_E_INVALID, "null argument");
+  if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
+  SCN_HIP(hipSetDevice(w->d.device_id));
+  if (!d_psd_db) {
+    if (!s.d_psd) SCN_HIP(hipMalloc(&s.d_psd, sizeof(float) * (size_t)w->d.n * w->d.max_psd));
+    d_psd_db = s.d_psd;
+  }
+  if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  st = welch_enqueue(w, d_samples, n_psd, d_psd_db);
+  if (st) return st;
+  SCN_HIP(hipEventRecord(s.done, w->stream));
+  s.pending = true;
+  s.via_graph = false;
+  s.n_psd = n_psd;
+  s.cur_psd = d_psd_db;
+  return SCN_OK;
+}
+
+int scn_welch_collect(scn_welch *w, int slot, float *psd_db) {
+  int st = welch_check(w, slot);
+  if (st) return st;
+  WelchSlot &s = w->slot[slot];
+  if (!s.pending) return fail(SCN_E_STATE, "slot %d has nothing submitted", slot);
+  SCN_HIP(hipSetDevice(w->d.device_id));
+  SCN_HIP(hipEventSynchronize(s.done));
+  s.pending = false;
+  if (psd_db) {
+    const size_t bytes = sizeof(float) * (size_t)w->d.n * s.n_psd;
+    if (s.via_graph) {
+      memcpy(psd_db, s.h_psd, bytes);  // the graph already brought the PSDs to pinned memory
+    } else {
+      SCN_HIP(hipMemcpyAsync(psd_db, s.cur_psd, bytes, hipMemcpyDeviceToHost, w->stream));
+      SCN_HIP(hipStreamSynchronize(w->stream));
+    }
+  }
+  return SCN_OK;
+}
+
+}  // extern "C"

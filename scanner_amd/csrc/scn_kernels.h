@@ -53,6 +53,18 @@ struct ScnTdArgs {
 };
 hipError_t scn_launch_time_domain(int kind, bool correct_dc, const ScnTdArgs &args, int num_cus, hipStream_t stream);
 
+// Welch PSD (BASELINE C5): 65 536-pt four-step FFT, 50 % overlap, K-segment power average
+struct ScnWelchArgs {
+  const void *in;          // complex-float stream, (n_psd*k + 1) * hop samples
+  const float *window;     // [65536]
+  const scn_v2f *twiddle;  // W_65536^m
+  void *work;              // [n_segments][65536] complex: Y[k1][n2] between the two kernels
+  float *psd_db;           // [n_psd][65536]
+  uint32_t n_segments, hop, k, n_psd;
+  float inv_k;
+};
+hipError_t scn_launch_welch(const ScnWelchArgs &args, int num_cus, hipStream_t stream);
+
 hipError_t scn_launch_fft(uint32_t n, int kind, bool correct_dc, bool hits, const ScnFftArgs &args,
                           int num_cus, hipStream_t stream);
 bool scn_fft_size_supported(uint32_t n);

@@ -1,0 +1,157 @@
+// scn_welch.hip -- BASELINE config C5: streaming 65 536-point, 50 %-overlap Welch PSD.
+//
+// No reference counterpart (the reference never averages or overlaps); the
+// definition is this build's: segments of N = 65 536 samples every hop = N/2,
+// window (the same Blackman-Harris as process.cpp:14-21), forward FFT (fft.cpp:20-25
+// semantics: unnormalised, sign -1), |X|^2 averaged over K consecutive segments in linear
+// power, then the reference's dB map (utility.cpp:86-98): 5*log10(mean |X|^2).
+//
+// 512 KiB per segment does not fit LDS, so the FFT is a four-step 256 x 256:
+//   n = 256 n1 + n2,  k = k1 + 256 k2
+//   X[k1 + 256 k2] = sum_n2 W_256^{n2 k2} * ( W_N^{n2 k1} * sum_n1 W_256^{n1 k1} x[256 n1 + n2] )
+//   kernel A (columns): one 256-thread workgroup per tile of 16 columns n2: 16 x 256-pt FFTs over n1
+//                       (two radix-16 passes, one LDS exchange), twiddle, write Y[k1][n2]
+//   kernel B (rows):    one workgroup per tile of 16 rows k1: 16 x 256-pt FFTs over n2, |X|^2
+//                       accumulated in registers over the K segments of one PSD, dB, store
+// Both kernels keep the 4096-pt kernel's shape (256 threads x 16 points, buffer descriptors,
+// conflict-free padded LDS layouts, base + immediate addressing).  Global accesses are 128-byte
+// segments (16 consecutive complex) on both sides of the work buffer, which lives in L2 /
+// Infinity Cache between the two kernels (8 MiB per 16 segments).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scn_device.h"
+
+namespace {
+constexpr uint32_t WN = 65536;
+constexpr uint32_t WP = 272;  // LDS row pitch (slots): 16 rows of 256 + 16, as exchange 1 of the 4096-pt kernel
+}  // namespace
+
+// ---- kernel A: columns -------------------------------------------------------------------
+// grid = 16 column tiles x G workgroups; workgroup (j, g) owns tile j for segments g, g+G, ...
+// so everything that depends on (n1, n2, k1) but not on the segment stays in registers.
+__global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+  const uint32_t t = threadIdx.x;
+  const uint32_t j = blockIdx.x & 15u, g = blockIdx.x >> 4, G = gridDim.x >> 4;
+  const uint32_t hi = t >> 4, lo = t & 15u;  // pass 1: (b, c)   pass 2: (p, c)
+  const uint32_t n2 = 16u * j + lo;
+
+  cf twa[16], twb[16];
+  float win[16];
+#pragma unroll
+  for (int p = 1; p < 16; p++) twa[p] = from_v2f(args.twiddle[(256u * hi * p) & (WN - 1)]);  // W_256^{b p}
+#pragma unroll
+  for (int q = 0; q < 16; q++) twb[q] = from_v2f(args.twiddle[(n2 * (hi + 16u * q)) & (WN - 1)]);  // W_N^{n2 k1}
+#pragma unroll
+  for (int a = 0; a < 16; a++) win[a] = args.window[256u * (16u * a + hi) + n2];
+
+  v2f *w1 = lds + t;                // + p*WP           (row p, column b*16+c = t)
+  v2f *r1 = lds + hi * WP + lo;     // + b*16
+  const uint32_t ld_voff = (256u * hi + n2) * 8u;        // + a*16*256*8
+  const uint32_t st_voff = (256u * hi + n2) * 8u;        // k1 = hi + 16q: + q*16*256*8
+
+  for (uint32_t seg = g; seg < args.n_segments; seg += G) {
+    __amdgpu_buffer_rsrc_t rin =
+        make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)seg * args.hop * 8u, WN * 8u);
+    __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)seg * WN * 8u, WN * 8u);
+    cf v[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+      v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rin, ld_voff, a * 32768u, 0));
+      v[a] = from_v2f(x) * win[a];
+    }
+    fft16(v);
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      cf y = v[OUT16(p)];
+      if (p) y = cmul(y, twa[p]);
+      w1[p * WP] = to_v2f(y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 16]);
+    fft16(v);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      cf y = cmul(v[OUT16(q)], twb[q]);
+      typedef unsigned u2 __attribute__((__vector_size__(8)));
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, to_v2f(y)), rwk, st_voff, q * 32768u, 0);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- kernel B: rows + Welch accumulation -------------------------------------------------
+// grid = 16 row tiles x n_psd; workgroup (i, psd) loops over the K segments of its PSD.
+__global__ __launch_bounds__(256, 3) void scn_welch_rows_kernel(ScnWelchArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+  const uint32_t t = threadIdx.x;
+  const uint32_t i = blockIdx.x & 15u, psd = blockIdx.x >> 4;
+  const uint32_t hi = t >> 4, lo = t & 15u;  // pass 1: (rho, b)   pass 2: (rho, p)
+  const uint32_t k1 = 16u * i + hi;
+
+  cf twa[16];
+#pragma unroll
+  for (int p = 1; p < 16; p++) twa[p] = from_v2f(args.twiddle[(256u * lo * p) & (WN - 1)]);  // W_256^{b p}
+
+  v2f *w1 = lds + hi * WP + lo * 17u;  // + p        (row rho, slot b*17 + p)
+  v2f *r1 = lds + hi * WP + lo;        // + b*17
+  const uint32_t ld_voff = (k1 * 256u + lo) * 8u;  // n2 = 16a + b: + a*128
+
+  float acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+
+  for (uint32_t s = 0; s < args.k; s++) {
+    const uint32_t seg = psd * args.k + s;
+    __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<const char *>(args.work) + (size_t)seg * WN * 8u, WN * 8u);
+    cf v[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++)
+      v[a] = from_v2f(__builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rwk, ld_voff, a * 128u, 0)));
+    fft16(v);
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      cf y = v[OUT16(p)];
+      if (p) y = cmul(y, twa[p]);
+      w1[p] = to_v2f(y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 17]);
+    fft16(v);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const cf x = v[OUT16(q)];
+      // |X|^2 exactly as the single-FFT path forms it, summed over segments in order s = 0..K-1
+      acc[q] += __builtin_fmaf(x.y, x.y, x.x * x.x);
+    }
+    __syncthreads();
+  }
+  // bin k = k1 + 256*k2, k2 = p + 16q (p = lo)
+  __amdgpu_buffer_rsrc_t rout = make_rsrc(args.psd_db + (size_t)psd * WN, WN * 4u);
+  const uint32_t st_voff = (k1 + 256u * lo) * 4u;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const float mean = acc[q] * args.inv_k;
+    const float d = 1.50514997831990597607f * __builtin_amdgcn_logf(mean);  // 5*log10(mean)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, q * 16384u, 0);
+  }
+}
+
+hipError_t scn_launch_welch(const ScnWelchArgs &a, int num_cus, hipStream_t s) {
+  if (a.n_segments == 0) return hipSuccess;
+  const size_t lds = 16 * WP * sizeof(v2f);
+  // kernel A: 16 tiles x G groups, G so that the grid is one resident wave of workgroups
+  uint32_t G = (uint32_t)(num_cus * 3) / 16u;
+  if (G < 1) G = 1;
+  if (G > a.n_segments) G = a.n_segments;
+  hipLaunchKernelGGL(scn_welch_cols_kernel, dim3(16 * G), dim3(256), lds, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(scn_welch_rows_kernel, dim3(16 * a.n_psd), dim3(256), lds, s, a);
+  return hipGetLastError();
+}

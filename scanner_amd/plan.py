@@ -161,3 +161,70 @@ class Plan:
         w = np.empty(self.n, np.float32)
         capi.check(self._L.scn_plan_window(self._h, w.ctypes.data_as(C.c_void_p), self.n), "scn_plan_window")
         return w
+
+
+class WelchPlan:
+    """Streaming 65 536-pt, 50 %-overlap Welch PSD (BASELINE config C5) -- wrapper over scn_welch."""
+
+    def __init__(self, n=65536, segments_per_psd=16, max_psd=1, device_id=0, window_type=capi.WIN_BLACKMAN_HARRIS):
+        self._L = capi.lib()
+        d = capi.WelchDesc()
+        d.struct_size = C.sizeof(capi.WelchDesc)
+        d.n, d.segments_per_psd, d.window_type, d.max_psd, d.device_id = n, segments_per_psd, window_type, max_psd, device_id
+        self.n, self.k, self.max_psd, self.hop = n, segments_per_psd, max_psd, n // 2
+        self._h = C.c_void_p()
+        capi.check(self._L.scn_welch_create(C.byref(d), C.byref(self._h)), "scn_welch_create")
+        self._npsd = [0] * capi.NUM_SLOTS
+        self._keep = [None] * capi.NUM_SLOTS
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.scn_welch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def samples(self, n_psd):
+        n = C.c_size_t()
+        capi.check(self._L.scn_welch_samples(self._h, n_psd, C.byref(n)), "scn_welch_samples")
+        return n.value
+
+    def host_buffer(self, slot):
+        """pinned complex64 staging view (max_psd PSDs worth of samples)"""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        capi.check(self._L.scn_welch_host_buffer(self._h, slot, C.byref(ptr), C.byref(nbytes)), "scn_welch_host_buffer")
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(nbytes.value // 4,)).view(np.complex64)
+
+    def submit(self, slot, n_psd):
+        capi.check(self._L.scn_welch_submit(self._h, slot, n_psd), "scn_welch_submit")
+        self._npsd[slot] = n_psd
+
+    def submit_device(self, slot, d_samples, n_psd, d_psd_db=None, sync_producer=True):
+        if sync_producer:
+            import torch
+
+            torch.cuda.current_stream(d_samples.device).synchronize()
+        assert d_samples.is_contiguous() and d_samples.numel() * d_samples.element_size() >= self.samples(n_psd) * 8
+        out = None if d_psd_db is None else C.c_void_p(d_psd_db.data_ptr())
+        capi.check(self._L.scn_welch_submit_device(self._h, slot, C.c_void_p(d_samples.data_ptr()), n_psd, out),
+                   "scn_welch_submit_device")
+        self._npsd[slot] = n_psd
+        self._keep[slot] = (d_samples, d_psd_db)
+
+    def collect(self, slot, want_psd=True):
+        nb = self._npsd[slot]
+        out = np.empty((nb, self.n), np.float32) if want_psd else None
+        capi.check(self._L.scn_welch_collect(self._h, slot, None if out is None else out.ctypes.data_as(C.c_void_p)),
+                   "scn_welch_collect")
+        self._keep[slot] = None
+        return out

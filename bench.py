@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate wall budget of the CPU baseline")
     ap.add_argument("--rotate", type=int, default=0, help="distinct input/output batches (0: enough for 1.5 GiB)")
+    ap.add_argument("--welch", action="store_true", help="BASELINE config C5: streaming 65536-pt 50%%-overlap Welch PSD")
+    ap.add_argument("--welch-psd", type=int, default=8, help="PSDs per submit (K=16 segments each)")
+    ap.add_argument("--welch-pinned", action="store_true", help="feed from pinned host memory through the captured hipGraph")
     return ap.parse_args()
 
 
@@ -82,8 +85,104 @@ def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s):
     }
 
 
+def welch_main(args):
+    """C5: every rank processes its own stream (replicas, no collective).  A step = one submit of
+    --welch-psd PSDs = (n_psd*16 + 1) * 32768 complex samples, device-resident (rotated over R
+    streams past the Infinity Cache) or, with --welch-pinned, staged from pinned host memory
+    through the captured hipGraph (PCIe-bound)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from scanner_amd import WelchPlan
+
+    N, K, npsd = 65536, 16, args.welch_psd
+    plan = WelchPlan(N, K, max_psd=npsd, device_id=local_rank)
+    m = plan.samples(npsd)
+    new_samples = npsd * K * (N // 2)
+    R = args.rotate or max(2, -(-(3 << 29) // (m * 8)))
+    g = torch.Generator(device=dev)
+    g.manual_seed(5 + rank)
+    if args.welch_pinned:
+        for s in range(2):
+            hb = plan.host_buffer(s)
+            hb[:m] = (torch.randn((m, 2), generator=g, device=dev) * 0.05).cpu().numpy().view(np.complex64).reshape(-1)
+    else:
+        xs = [torch.randn((m, 2), generator=g, device=dev) * 0.05 for _ in range(R)]
+        outs = [torch.empty((npsd, N), dtype=torch.float32, device=dev) for _ in range(R)]
+    torch.cuda.synchronize()
+    pending = [False, False]
+
+    def step(k):
+        s = k & 1
+        if pending[s]:
+            plan.collect(s, want_psd=False)
+        if args.welch_pinned:
+            plan.submit(s, npsd)
+        else:
+            plan.submit_device(s, xs[k % R], npsd, d_psd_db=outs[k % R], sync_producer=False)
+        pending[s] = True
+
+    def drain():
+        for s in (0, 1):
+            if pending[s]:
+                plan.collect(s, want_psd=False)
+                pending[s] = False
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    if rank == 0:
+        algo = new_samples * 8 + npsd * N * 4  # 8 B per NEW sample + 4N/K per segment (SURVEY 8d)
+        ms = elapsed / args.steps * 1e3
+        achieved = algo / (ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "Msamples/s (new complex samples through 65536-pt 50%-overlap Welch PSD)",
+            "value": round(world * new_samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C5: 65536-pt 50%-overlap Welch PSD, K=16, {npsd} PSDs per submit, Blackman-Harris, "
+                                   f"{'pinned host staging + hipGraph replay' if args.welch_pinned else 'stream resident in HBM'}; "
+                                   f"independent stream per GPU (replicas)",
+                       "n": N, "segments_per_psd": K, "psd_per_submit": npsd, "pinned": bool(args.welch_pinned)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "scn_welch_cols_kernel + scn_welch_rows_kernel (two-pass four-step FFT: the work "
+                                   "buffer round trip and the 50% overlap re-read are NOT algorithmic bytes)",
+                         "algorithmic_bytes_per_launch": algo},
+        }), flush=True)
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.welch:
+        return welch_main(args)
     import torch
     import torch.distributed as dist
 

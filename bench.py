@@ -193,11 +193,12 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    force_dist = world == 1 and "RANK" in os.environ and os.environ.get("SCN_BENCH_FORCE_DIST")  # 1-rank self-test
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -282,7 +283,7 @@ def main():
     plan.submit_device(0, raw, nb, fc, seq, sync_producer=False)
     tg0 = time.perf_counter()
     _, hits, trig = plan.collect(0, want_power=False, want_hits=True, hit_cap=nb * 64)
-    all_hits = sweep.gather_hits(hits, dev) if world > 1 else hits
+    all_hits = sweep.gather_hits(hits, dev) if (world > 1 or force_dist) else hits
     gather_ms = (time.perf_counter() - tg0) * 1e3
 
     samples_per_step = world * nb * n
@@ -341,7 +342,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     plan.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

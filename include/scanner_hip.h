@@ -101,6 +101,8 @@ const char *scn_error_name(int status);
 /* Text of the most recent failure on this thread ("" if none). */
 const char *scn_last_error(void);
 uint32_t scn_abi_version(void);
+/* Number of HIP devices visible to this process (0 and SCN_E_NO_DEVICE if none). */
+int scn_device_count(int *count);
 
 int scn_plan_create(const scn_plan_desc *desc, scn_plan **out);
 int scn_plan_destroy(scn_plan *plan);

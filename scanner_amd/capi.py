@@ -70,6 +70,7 @@ SYMBOLS = {
     "scn_error_name": (C.c_char_p, [C.c_int]),
     "scn_last_error": (C.c_char_p, []),
     "scn_abi_version": (C.c_uint32, []),
+    "scn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "scn_plan_create": (C.c_int, [C.POINTER(PlanDesc), C.POINTER(_vp)]),
     "scn_plan_destroy": (C.c_int, [_vp]),
     "scn_buffer_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),

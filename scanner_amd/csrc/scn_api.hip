@@ -252,6 +252,17 @@ const char *scn_last_error(void) { return g_last_error.c_str(); }
 
 uint32_t scn_abi_version(void) { return SCN_ABI_VERSION; }
 
+int scn_device_count(int *count) {
+  if (!count) return fail(SCN_E_INVALID, "null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    *count = 0;
+    return fail(SCN_E_NO_DEVICE, "no HIP device visible");
+  }
+  *count = n;
+  return SCN_OK;
+}
+
 int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   if (!desc || !out) return fail(SCN_E_INVALID, "null argument");
   *out = nullptr;
@@ -466,15 +477,24 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
         SCN_HIP(hipMemcpyAsync(hh.data() + in_regions, s.d_ov_hits, sizeof(ScnDevHit) * ov_kept,
                                hipMemcpyDeviceToHost, p->stream));
       SCN_HIP(hipStreamSynchronize(p->stream));
-      size_t w = 0;
+      // Region b already holds buffer b's hits (in arbitrary order), so buffer-major order needs
+      // no global sort: sort each small region by i; only the overflow list (rare) is sorted
+      // globally and merged in.
+      auto by_buf_i = [](const ScnDevHit &x, const ScnDevHit &y) {
+        return x.buffer != y.buffer ? x.buffer < y.buffer : x.i < y.i;
+      };
+      std::vector<ScnDevHit> ov(hh.begin() + in_regions, hh.end());
+      std::sort(ov.begin(), ov.end(), by_buf_i);
+      size_t w = 0, o = 0;
       for (uint32_t b = 0; b < nb; b++) {
         const uint32_t c = std::min(s.h_buf_hits[b], p->hit_region);
+        const size_t first = w;
         std::copy_n(regions.begin() + (size_t)b * p->hit_region, c, hh.begin() + w);
         w += c;
+        while (o < ov.size() && ov[o].buffer == b) hh[w++] = ov[o++];
+        std::sort(hh.begin() + first, hh.begin() + w, by_buf_i);
       }
-      std::sort(hh.begin(), hh.end(), [](const ScnDevHit &x, const ScnDevHit &y) {
-        return x.buffer != y.buffer ? x.buffer < y.buffer : x.i < y.i;
-      });
+      hh.resize(w);
       const uint32_t bin_step = p->d.sample_rate / n;  // process.cpp:39 (truncating)
       const uint32_t out_n = (uint32_t)std::min<size_t>(hh.size(), hit_cap);
       for (uint32_t k = 0; k < out_n; k++) {

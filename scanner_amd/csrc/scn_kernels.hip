@@ -548,13 +548,12 @@ static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, int num_c
   else if (dc) k = scn_fft_kernel<M, KIND, true, false>;
   else if (hits) k = scn_fft_kernel<M, KIND, false, true>;
   else k = scn_fft_kernel<M, KIND, false, false>;
-  static bool attr_set[4] = {false, false, false, false};  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-  const int ki = (dc ? 2 : 0) + (hits ? 1 : 0);
-  if (G::LDS_BYTES > 65536u && !attr_set[ki]) {
+  if (G::LDS_BYTES > 65536u) {
+    // > 64 KiB of dynamic LDS needs the opt-in; it is per function AND per device, and a process may
+    // drive several GPUs (one plan per consumer thread), so it is simply set on every launch
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set[ki] = true;
   }
   int grid = num_cus * (int)G::WG_PER_CU;  // one resident wave of persistent workgroups
   if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;

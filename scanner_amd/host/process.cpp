@@ -104,7 +104,9 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   d.max_batch = std::min<uint32_t>(m_maxBatch, std::max<uint32_t>(1u, q.GetBufferCount()));
   d.max_hits = d.max_batch * 64u;
   d.flags = SCN_OUT_HITS;  // the reference reports hits only; the spectra never leave the GPU
-  d.device_id = m_firstDevice + (int)threadId;
+  int nDevices = 1;
+  check(scn_device_count(&nDevices), "scn_device_count");
+  d.device_id = (m_firstDevice + (int)threadId) % nDevices;  // consumer threads spread over the node's GPUs
   scn_plan *plan = nullptr;
   check(scn_plan_create(&d, &plan), "scn_plan_create");
 

@@ -100,3 +100,40 @@ def test_scan_synth_transcript_matches_oracle(host_build, oracle_mod, tmp_path, 
     assert np.abs(vals - h_ref["power_db"]).max() < 2e-3
     assert len(starts) == iters
     assert "Starting process thread 0" in out.stdout and "Stopped process thread 0" in out.stdout
+
+
+@pytest.mark.gpu
+def test_scan_synth_two_consumer_threads_and_time_domain(host_build, tmp_path):
+    """scan.cpp:217 runs 2 consumer threads: two plans on their own streams share the queue.  Line
+    order across threads is nondeterministic (as in the reference), the multiset of lines is not."""
+    _, demo = host_build
+    base = [demo, "--kind", "short_complex", "--n", "8192", "--start", "400e6", "--stop", "460e6", "--niterations", "3",
+            "--threshold", "11", "--sigma", "0.02", "--batch", "3", "--depth", "8", "--emitter", "433.92e6:0.3",
+            "--emitter", "446.0e6:0.08"]
+    one = subprocess.run(base + ["--threads", "1"], capture_output=True, text=True, timeout=300)
+    two = subprocess.run(base + ["--threads", "2"], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and two.returncode == 0, one.stderr + two.stderr
+    f1 = sorted(l for l in one.stdout.splitlines() if l.startswith("freq "))
+    f2 = sorted(l for l in two.stdout.splitlines() if l.startswith("freq "))
+    assert len(f1) > 10 and f1 == f2
+    assert "Starting process thread 1" in two.stdout and "Stopped process thread 1" in two.stdout
+    # time-domain mode, the reference CLI's default (scan.cpp:87): one line per buffer whose peak is above threshold
+    td = subprocess.run([demo, "--kind", "float", "--n", "8192", "--start", "400e6", "--stop", "460e6",
+                         "--niterations", "2", "--mode", "time", "--threshold", "-7", "--sigma", "0.02",
+                         "--emitter", "433.92e6:0.3"], capture_output=True, text=True, timeout=300)
+    assert td.returncode == 0, td.stderr
+    lines = [l for l in td.stdout.splitlines() if "Max signal" in l]
+    # Reference quirk, reproduced on purpose (process.cpp:207): the running maximum starts at
+    # numeric_limits<float>::min(), a tiny POSITIVE number, so for normalised samples (every dB value
+    # negative) it never moves: all 10 tuned bands x 2 sweeps "exceed" a negative threshold and print 0.000000.
+    assert len(lines) == 20
+    m = [re.match(r"Sequence\[(\d+)\]: Max signal 0.000000 above threshold -7.000000 frequency (\d+), min (-?[\d.]+)", l)
+         for l in lines]
+    assert all(m) and [int(x.group(1)) for x in m] == list(range(20))
+    mins = {int(x.group(2)): float(x.group(3)) for x in m[:10]}
+    assert mins[433000000] > -10 and all(v < -30 for f, v in mins.items() if f != 433000000)   # the emitter's band
+    # ... and with the CLI's default positive threshold (scan.cpp:94) nothing can ever print
+    td2 = subprocess.run([demo, "--kind", "float", "--n", "8192", "--start", "400e6", "--stop", "460e6",
+                          "--niterations", "2", "--mode", "time", "--threshold", "10", "--emitter", "433.92e6:0.3"],
+                         capture_output=True, text=True, timeout=300)
+    assert td2.returncode == 0 and "Max signal" not in td2.stdout

@@ -507,7 +507,7 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
         hits[k].freq_hz = (uint64_t)frequency;  // process.cpp:57
       }
     }
-    if (overflow > p->d.max_hits || (hits && total > hit_cap)) result = SCN_E_TRUNCATED;
+    if (hits && (overflow > p->d.max_hits || total > hit_cap)) result = SCN_E_TRUNCATED;  // only when records were asked for
 
   } else if (trigger) {
     memset(trigger, 0, nb);

@@ -218,9 +218,11 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   cf tw1[16];
 #pragma unroll
   for (int p = 1; p < 16; p++) tw1[p] = from_v2f(args.twiddle[(t * p) & (N - 1)]);
+  // Window taps with the ENOB scale folded in: onebymax (utility.cpp:65) is +-2^-k, so
+  // float(s)*scale*w and float(s)*(scale*w) round identically -- one multiply per component saved.
   float win[16];
 #pragma unroll
-  for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t];
+  for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t] * args.scale;
   // pass-2 twiddles W_{16M}^(c*q) = W_N^(16 c q), table [q][c] shared by the workgroup
   lds_tw2[t] = args.twiddle[(16 * p2 * c2) & (N - 1)];
   if (t == 0) lds_hits[0] = lds_hits[1] = 0;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 
     cf v[16];
 #pragma unroll
-    for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, args.scale) * win[a];
+    for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, 1.0f) * win[a];
     if (PF) {
       // the raw registers are free again: start fetching the next buffer of this workgroup now,
       // its latency hides behind the FFT passes below

@@ -31,6 +31,28 @@ def test_host_classes_cpu(host_build, tmp_path):
     assert "host cpu tests ok" in out.stdout
 
 
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_host_classes_under_sanitizers(host_build, tmp_path, san):
+    """CPU-only sanitizer runs of the queue / buffer / source classes (the reference ships none and has a
+    known data race on its shared FFT plan).  The host sources are compiled INTO the test
+    binary so they are instrumented; libscanner_hip is only linked for scn_frequency_table."""
+    exe = tmp_path / "test_host_san"
+    srcs = [os.path.join(HOST, f) for f in ("frequencyTable.cpp", "messageQueue.cpp", "signalSource.cpp",
+                                            "syntheticSource.cpp", "processInterface.cpp", "sampleBuffer.cpp")]
+    cmd = ["g++", "-std=gnu++11", "-O1", "-g", "-fno-omit-frame-pointer", f"-fsanitize={san}", "-pthread", "-I", HOST,
+           os.path.join(ROOT, "tests", "cpp", "test_host_cpu.cpp")] + srcs + [
+           "-o", str(exe), "-L" + os.path.join(ROOT, "scanner_amd"), "-lscanner_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "scanner_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[:200])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0",
+               UBSAN_OPTIONS="halt_on_error=1")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "host cpu tests ok" in out.stdout, out.stderr[-3000:]
+
+
 def test_reference_call_sites_compile(host_build, tmp_path):
     """The wiring of scan.cpp:211-239 written against the reference's names compiles unchanged."""
     src = tmp_path / "wiring.cpp"

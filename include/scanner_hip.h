@@ -150,6 +150,13 @@ int scn_collect(scn_plan *plan, int slot, float *power_db, scn_hit *hits,
 int scn_collect_time_domain(scn_plan *plan, int slot, float *max_db, float *min_db,
                             uint8_t *above);
 
+/* K1 alone, synchronously: convert n_buffers raw buffers (host memory, the plan's wire format) to
+ * complex float exactly as the plan's kernels do (utility.cpp:9-84 with the plan's enob /
+ * correct_dc), writing n_buffers*N {re,im} float pairs to out (host).  This is what the
+ * triggered-capture writer needs (messageQueue.h:98-139 dumps fftwf_complex[N] records); it runs on
+ * its own stream and does not disturb pending slots. */
+int scn_convert_raw(scn_plan *plan, const void *raw, uint32_t n_buffers, float *out);
+
 /* Wait for the slot's submit without copying anything back. */
 int scn_wait(scn_plan *plan, int slot);
 

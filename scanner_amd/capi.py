@@ -79,6 +79,7 @@ SYMBOLS = {
     "scn_submit_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, _vp, _vp, _vp]),
     "scn_collect": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), _vp]),
     "scn_collect_time_domain": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "scn_convert_raw": (C.c_int, [_vp, _vp, C.c_uint32, _vp]),
     "scn_wait": (C.c_int, [_vp, C.c_int]),
     "scn_plan_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "scn_device_spectrum": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),

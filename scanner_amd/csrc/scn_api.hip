@@ -411,6 +411,26 @@ int scn_submit_device(scn_plan *p, int slot, const void *d_raw, uint32_t nb, con
   return submit_common(p, s, d_raw, nb, fc, seq, d_power_db);
 }
 
+int scn_convert_raw(scn_plan *p, const void *raw, uint32_t nb, float *out) {
+  if (!p || (nb && (!raw || !out))) return fail(SCN_E_INVALID, "null argument");
+  if (!nb) return SCN_OK;
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  const size_t in_bytes = p->buf_bytes * nb, out_bytes = sizeof(float) * 2 * (size_t)p->d.n * nb;
+  void *d_in = nullptr;
+  scn_v2f *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_in, in_bytes);
+  if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, raw, in_bytes, hipMemcpyHostToDevice, p->d2h_stream);
+  if (e == hipSuccess)
+    e = scn_launch_convert((int)p->d.sample_kind, p->d.correct_dc != 0, d_in, d_out, p->d.n, nb, p->scale, p->d2h_stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, p->d2h_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->d2h_stream);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? SCN_E_NOMEM : SCN_E_HIP, "scn_convert_raw: %s", hipGetErrorString(e));
+  return SCN_OK;
+}
+
 int scn_wait(scn_plan *p, int slot) {
   int st = check_slot(p, slot);
   if (st) return st;

@@ -65,6 +65,10 @@ struct ScnWelchArgs {
 };
 hipError_t scn_launch_welch(const ScnWelchArgs &args, int num_cus, hipStream_t stream);
 
+// K1 alone (capture path)
+hipError_t scn_launch_convert(int kind, bool correct_dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers,
+                              float scale, hipStream_t stream);
+
 hipError_t scn_launch_fft(uint32_t n, int kind, bool correct_dc, bool hits, const ScnFftArgs &args,
                           int num_cus, hipStream_t stream);
 bool scn_fft_size_supported(uint32_t n);

@@ -540,6 +540,58 @@ hipError_t scn_launch_time_domain(int kind, bool dc, const ScnTdArgs &a, int num
 }
 
 // ------------------------------------------------------------------------------------
+// K1 alone: raw wire format -> complex float (utility.cpp:9-84), for the triggered-capture path
+// (messageQueue.h:98-139 writes fftwf_complex[N] records).  One 256-thread workgroup per buffer.
+// ------------------------------------------------------------------------------------
+template <int KIND, bool DC>
+__global__ __launch_bounds__(256) void scn_convert_kernel(const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers,
+                                                          float scale) {
+  typedef RawLoader<KIND> L;
+  __shared__ int s_sum[8];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (uint32_t buf = blockIdx.x; buf < n_buffers; buf += gridDim.x) {
+    __amdgpu_buffer_rsrc_t rin = make_rsrc(reinterpret_cast<const char *>(raw) + (size_t)buf * L::kBufBytes(n), L::kBufBytes(n));
+    int dc_re = 0, dc_im = 0;
+    if (DC) {
+      int sr = 0, si = 0;
+      for (uint32_t i = t; i < n; i += 256) {
+        int re, im;
+        L::ints(L::template load<0>(rin, n, i, 0), re, im);
+        sr += re;
+        si += im;
+      }
+      sr = wave_sum(sr);
+      si = wave_sum(si);
+      if (lane == 0) {
+        s_sum[wave] = sr;
+        s_sum[4 + wave] = si;
+      }
+      __syncthreads();
+      dc_re = (int)((uint32_t)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) / n);  // utility.cpp:77-78 quirk
+      dc_im = (int)((uint32_t)(s_sum[4] + s_sum[5] + s_sum[6] + s_sum[7]) / n);
+    }
+    for (uint32_t i = t; i < n; i += 256)
+      out[(size_t)buf * n + i] = to_v2f(L::conv(L::template load<0>(rin, n, i, 0), dc_re, dc_im, scale));
+    __syncthreads();
+  }
+}
+
+hipError_t scn_launch_convert(int kind, bool dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers, float scale,
+                              hipStream_t s) {
+  if (n_buffers == 0) return hipSuccess;
+  void (*k)(const void *, scn_v2f *, uint32_t, uint32_t, float) = nullptr;
+  switch (kind) {
+    case SCN_K_FLOAT_COMPLEX: k = scn_convert_kernel<SCN_K_FLOAT_COMPLEX, false>; break;
+    case SCN_K_SHORT_COMPLEX: k = dc ? scn_convert_kernel<SCN_K_SHORT_COMPLEX, true> : scn_convert_kernel<SCN_K_SHORT_COMPLEX, false>; break;
+    case SCN_K_SHORT: k = dc ? scn_convert_kernel<SCN_K_SHORT, true> : scn_convert_kernel<SCN_K_SHORT, false>; break;
+    case SCN_K_BYTE_COMPLEX: k = dc ? scn_convert_kernel<SCN_K_BYTE_COMPLEX, true> : scn_convert_kernel<SCN_K_BYTE_COMPLEX, false>; break;
+    default: return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(k, dim3(n_buffers < 2048 ? n_buffers : 2048), dim3(256), 0, s, raw, out, n, n_buffers, scale);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // host-side launcher
 // ------------------------------------------------------------------------------------
 template <int M, int KIND>

@@ -19,15 +19,34 @@ SampleQueue::SampleQueue(SampleKind kind, uint32_t enob, uint32_t sampleCount, u
     : m_kind(kind), m_enob(enob), m_sampleCount(sampleCount), m_bufferCount(bufferCount),
       m_correctDCOffset(correctDCOffset), m_doWrite(doWrite), m_bufferBytes(bytesPerSample(kind) * sampleCount),
       m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_nextSequenceId(0),
-      m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0) {
+      m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0), m_writeFile(nullptr),
+      m_writeActive(false), m_writeNext(0) {
   assert(kind > Illegal && kind <= FloatComplex);  // messageQueue.h:163
   assert(bufferCount > 0);
   if (m_poolSize <= bufferCount) m_poolSize = bufferCount + 1;
+  if (m_doWrite && m_historyCapacity < 8) {  // capture needs some history to find the pre-trigger buffers in
+    m_historyCapacity = 8;
+    m_poolSize += 8;
+  }
   for (uint32_t i = 0; i < m_poolSize; i++) m_free.push_back(new MessageType(m_bufferBytes));
+  if (m_doWrite) {
+    printf("Starting write thread...\n");  // messageQueue.h:166
+    m_writeThread.reset(new std::thread(&SampleQueue::WriteThreadWorker, this));
+  }
 }
 
 SampleQueue::~SampleQueue() {
   assert(m_buffer.empty());  // messageQueue.h:173
+  if (m_doWrite && m_writeThread) {
+    printf("Stopping write thread...\n");  // messageQueue.h:176
+    {
+      std::unique_lock<std::mutex> lock(m_historyMutex);
+      m_done = true;  // (SetIsDone has normally run already)
+      m_writeWake.notify_all();
+    }
+    m_writeThread->join();
+  }
+  if (m_writeFile) fclose(m_writeFile);
   for (MessageType *m : m_history) delete m;
   for (MessageType *m : m_buffer) delete m;
   for (MessageType *m : m_free) delete m;
@@ -122,25 +141,95 @@ void SampleQueue::MessageProcessed(MessageType *message) {
     Free(old);
   }
   m_history.push_front(message);
+  if (m_writeActive) m_writeWake.notify_one();  // messageQueue.h:272
 }
 
 void SampleQueue::BeginWrite(uint64_t startSequenceId, std::string fileName) {
-  (void)fileName;
+  printf("BeginWrite %s: %lu\n", fileName.c_str(), (unsigned long)startSequenceId);  // messageQueue.h:276
   std::unique_lock<std::mutex> lock(m_historyMutex);
   m_writeStart = startSequenceId;
   m_writeEnd = std::numeric_limits<uint64_t>::max();
+  if (m_doWrite) {
+    if (m_writeFile) fclose(m_writeFile);
+    m_writeFile = fopen(fileName.c_str(), "w");
+    if (!m_writeFile) fprintf(stderr, "Failed to open file '%s'\n", fileName.c_str());
+    m_writeNext = startSequenceId;
+    m_writeActive = m_writeFile != nullptr;
+    m_writeWake.notify_one();
+  }
 }
 
 void SampleQueue::EndWrite(uint64_t sequenceId) {
+  printf("EndWrite %lu\n", (unsigned long)sequenceId);  // messageQueue.h:285
   std::unique_lock<std::mutex> lock(m_historyMutex);
   m_writeEnd = sequenceId;
+  m_writeWake.notify_one();
+}
+
+// messageQueue.h:98-139, restated without the iterator games: write, in sequence order, every
+// processed message with id in [m_writeStart, m_writeEnd) as it reaches the history ring; close the
+// file once a message at or past the end id (or the end of the stream) shows up.
+void SampleQueue::WriteThreadWorker() {
+  std::vector<unsigned char> raw(m_bufferBytes);
+  std::vector<float> converted(2 * (size_t)m_sampleCount);
+  std::unique_lock<std::mutex> lock(m_historyMutex);
+  while (true) {
+    while (!m_done && !m_writeActive) m_writeWake.wait(lock);
+    if (!m_writeActive) break;  // done, nothing being written
+    // oldest -> newest: find the first message the writer still wants
+    MessageType *next = nullptr;
+    bool pastEnd = false;
+    for (auto it = m_history.rbegin(); it != m_history.rend(); ++it) {
+      uint64_t seq = (*it)->GetHeader().m_sequenceId;
+      if (seq < m_writeNext) continue;
+      if (seq >= m_writeEnd) {
+        pastEnd = true;
+      } else {
+        next = *it;
+      }
+      break;
+    }
+    if (next) {
+      const uint64_t seq = next->GetHeader().m_sequenceId;
+      memcpy(raw.data(), next->GetRawData(), m_bufferBytes);
+      m_writeNext = seq + 1;
+      FILE *f = m_writeFile;
+      lock.unlock();
+      printf("Writing %lu\n", (unsigned long)seq);  // messageQueue.h:125
+      const float *data = reinterpret_cast<const float *>(raw.data());
+      if (m_kind != FloatComplex) {
+        if (m_converter) {
+          m_converter(raw.data(), 1, converted.data());
+          data = converted.data();
+        } else {
+          fprintf(stderr, "SampleQueue: no converter installed, writing raw samples\n");
+        }
+      }
+      fwrite(data, m_kind != FloatComplex && !m_converter ? 1 : sizeof(fftwf_complex),
+             m_kind != FloatComplex && !m_converter ? m_bufferBytes : m_sampleCount, f);
+      lock.lock();
+      continue;
+    }
+    if (pastEnd || m_done) {  // capture complete (or the stream ended): close the file
+      if (m_writeFile) fclose(m_writeFile);
+      m_writeFile = nullptr;
+      m_writeActive = false;
+      if (m_done) break;
+      continue;
+    }
+    m_writeWake.wait(lock);
+  }
 }
 
 void SampleQueue::SetIsDone() {
-  std::unique_lock<std::mutex> lock(m_mutex);
-  assert(!m_done);
-  m_done = true;
-  m_notEmpty.notify_all();
+  {
+    std::unique_lock<std::mutex> lock(m_mutex);
+    assert(!m_done);
+    m_done = true;
+    m_notEmpty.notify_all();
+  }
+  std::unique_lock<std::mutex> lock(m_historyMutex);  // messageQueue.h:299-303: wake the writer too
+  m_writeWake.notify_all();
 }
 
 bool SampleQueue::GetIsDone() {

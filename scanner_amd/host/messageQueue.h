@@ -9,6 +9,10 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
+#include <functional>
+#include <memory>
+#include <thread>
 #include <cstdint>
 #include <cstring>
 #include <ctime>
@@ -61,10 +65,15 @@ class SampleQueue {
   MessageType *TryGetNextSamples();  // non-blocking variant used to fill a batch; nullptr if empty
   void MessageProcessed(MessageType *message);  // messageQueue.h:259-273
 
-  // Triggered capture (messageQueue.h:275-288) is outside this build's scope: the calls are
-  // accepted and recorded so the trigger state machine of ProcessSamples runs unchanged.
+  // Triggered capture (messageQueue.h:98-139, 275-288): with doWrite a write thread dumps the
+  // processed messages with sequence ids in [start, end) from the history ring to `fileName`
+  // as raw little-endian fftwf_complex[sampleCount] records -- the reference's file format.
+  // Messages hold raw wire-format samples here, so integer kinds go through the converter
+  // (K1 on the GPU, scn_convert_raw) that the consumer installs with SetConverter.
   void BeginWrite(uint64_t startSequenceId, std::string fileName);
   void EndWrite(uint64_t sequenceId);
+  typedef std::function<void(const void *raw, uint32_t nBuffers, float *out)> Converter;
+  void SetConverter(Converter c) { m_converter = c; }
 
   void SetIsDone();
   bool GetIsDone();
@@ -99,7 +108,15 @@ class SampleQueue {
   std::condition_variable m_notEmpty, m_notFull, m_poolNotEmpty;
   uint64_t m_nextSequenceId;
   uint32_t m_iterationCount;
-  bool m_done;
+  std::atomic<bool> m_done;
   std::atomic<bool> m_acknowledged;
   uint64_t m_writeStart, m_writeEnd;
+  // write thread state (guarded by m_historyMutex)
+  void WriteThreadWorker();
+  std::unique_ptr<std::thread> m_writeThread;
+  std::condition_variable m_writeWake;
+  FILE *m_writeFile;
+  bool m_writeActive;
+  uint64_t m_writeNext;  // next sequence id the writer wants
+  Converter m_converter;
 };

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 
 #include "../../include/scanner_hip.h"
 
@@ -27,13 +28,15 @@ ProcessSamples::ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_
       m_preTrigger(preTrigger), m_postTrigger(postTrigger), m_endSequenceId(0), m_writing(false), m_mode(mode),
       m_fileNameBase(fileNameBase), m_threshold(threshold), m_useBandWidth(useBandWidth), m_windowType(windowType),
       m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_firstDevice(0), m_hitCount(0),
-      m_bufferCount(0) {
+      m_bufferCount(0), m_convertPlan(nullptr) {
   (void)dcIgnoreWidth;  // the reference ignores it too and hard-codes 4 bins (process.cpp:86-88)
   assert(mode > Illegal && mode <= FrequencyDomain);  // process.cpp:99
   assert(threadCount <= MAX_THREADS);                 // process.cpp:100
 }
 
-ProcessSamples::~ProcessSamples() {}
+ProcessSamples::~ProcessSamples() {
+  if (m_convertPlan) scn_plan_destroy(static_cast<scn_plan *>(m_convertPlan));
+}
 
 void ProcessSamples::TimeToString(time_t time, char *buffer, uint32_t length) {  // process.cpp:146-158
   struct tm *t = localtime(&time);
@@ -205,6 +208,29 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
 
 bool ProcessSamples::StartProcessing(SampleQueue &sampleQueue) {  // process.cpp:316-331
   m_sampleQueue = &sampleQueue;
+  // Triggered capture writes converted samples (fftwf_complex records); the queue holds raw ones,
+  // so give it K1 on the GPU through a small dedicated plan.
+  scn_plan *convertPlan = nullptr;
+  std::mutex convertMutex;
+  if (m_fileNameBase != "" && sampleQueue.m_kind != SampleQueue::FloatComplex) {
+    scn_plan_desc d;
+    memset(&d, 0, sizeof(d));
+    d.struct_size = sizeof(d);
+    d.n = m_sampleCount;
+    d.sample_rate = m_sampleRate;
+    d.sample_kind = planKind(sampleQueue.m_kind);
+    d.enob = m_enob;
+    d.correct_dc = sampleQueue.GetCorrectDCOffset();
+    d.mode = SCN_MODE_TIME_DOMAIN;  // no FFT-size restriction; only scn_convert_raw is used
+    d.threshold = m_threshold;
+    d.max_batch = 1;
+    d.device_id = m_firstDevice;
+    check(scn_plan_create(&d, &convertPlan), "scn_plan_create");
+    sampleQueue.SetConverter([convertPlan, &convertMutex](const void *raw, uint32_t n, float *out) {
+      std::lock_guard<std::mutex> g(convertMutex);
+      check(scn_convert_raw(convertPlan, raw, n, out), "scn_convert_raw");
+    });
+  }
   std::vector<std::thread> threads;
   for (uint32_t t = 0; t < m_threadCount; t++) {
     printf("Starting process thread %u\n", t);
@@ -213,6 +239,14 @@ bool ProcessSamples::StartProcessing(SampleQueue &sampleQueue) {  // process.cpp
   for (uint32_t t = 0; t < m_threadCount; t++) {
     threads[t].join();
     printf("Stopped process thread %u\n", t);
+  }
+  if (convertPlan) {
+    // the write thread may still be converting its last records: the queue's destructor joins it
+    // before the plan could be needed again, so hand the plan's lifetime to the converter
+    sampleQueue.SetConverter([convertPlan](const void *raw, uint32_t n, float *out) {
+      check(scn_convert_raw(convertPlan, raw, n, out), "scn_convert_raw");
+    });
+    m_convertPlan = convertPlan;
   }
   return true;
 }

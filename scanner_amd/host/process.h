@@ -66,4 +66,5 @@ class ProcessSamples {
   uint32_t m_maxBatch;
   int m_firstDevice;
   std::atomic<uint64_t> m_hitCount, m_bufferCount;
+  void *m_convertPlan;  // scn_plan used by the capture writer (K1 on the GPU); outlives StartProcessing
 };

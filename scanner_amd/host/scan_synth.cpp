@@ -18,7 +18,10 @@ int main(int argc, char **argv) {
   float threshold = 10.0f;
   uint64_t seed = 1;
   bool correctDC = false, timeDomain = false;
-  std::string kindName = "short_complex", dump;
+  std::string kindName = "short_complex", dump, outFile;
+  uint32_t pre = 0, post = 0;
+  unsigned long burstFirst = 1, burstLast = 0;
+  double burstGain = 1.0;
   std::vector<SyntheticSource::Emitter> emitters;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -45,7 +48,13 @@ int main(int argc, char **argv) {
     else if (a == "--correct-dc") correctDC = true;
     else if (a == "--mode") timeDomain = std::string(val()) == "time";
     else if (a == "--dump") dump = val();
-    else if (a == "--emitter") {
+    else if (a == "--outfile") outFile = val();
+    else if (a == "--pre") pre = (uint32_t)atol(val());
+    else if (a == "--post") post = (uint32_t)atol(val());
+    else if (a == "--burst") {  // first:last:gain
+      const char *v = val();
+      if (sscanf(v, "%lu:%lu:%lf", &burstFirst, &burstLast, &burstGain) != 3) { fprintf(stderr, "--burst wants first:last:gain\n"); return 2; }
+    } else if (a == "--emitter") {
       const char *v = val();
       const char *c = strchr(v, ':');
       if (!c) { fprintf(stderr, "--emitter wants freq:amplitude\n"); return 2; }
@@ -65,12 +74,13 @@ int main(int argc, char **argv) {
   SyntheticSource source(fs, n, start, stop, kind, seed, sigma);
   for (auto &e : emitters) source.AddEmitter(e.frequency, e.amplitude);
   if (!dump.empty()) source.SetDumpFile(dump);
+  source.SetBurst(burstFirst, burstLast, burstGain);
 
   // scan.cpp:211-223
   ProcessSamples process(n, fs, enob, threshold, gr::fft::window::WIN_BLACKMAN_HARRIS, timeDomain ? ProcessSamples::TimeDomain : ProcessSamples::FrequencyDomain,
-                         threads, "", 0.75, 0.0, 0, 0);
+                         threads, outFile, 0.75, 0.0, pre, post);
   process.SetMaxBatch(batch);
-  SampleQueue sampleQueue(kind, enob, n, depth, correctDC, false);
+  SampleQueue sampleQueue(kind, enob, n, depth, correctDC, outFile != "");  // scan.cpp:223
 
   // scan.cpp:234-238 (the source delivers numIterations+1 sweeps: the first one is the queue's warm-up discard)
   source.Start();

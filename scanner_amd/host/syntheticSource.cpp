@@ -40,8 +40,9 @@ void SyntheticSource::Generate(double fc, uint64_t bufferIndex, void *raw) {
   const double twoPi = 6.283185307179586476925286766559;
   std::vector<double> re(n), im(n);
   uint64_t s = m_seed * 0x100000001b3ull + bufferIndex * 0x9e3779b97f4a7c15ull + 0x1234567;
+  const double sigma = m_sigma * ((bufferIndex >= m_burstFirst && bufferIndex <= m_burstLast) ? m_burstGain : 1.0);
   for (uint32_t k = 0; k < n; k++) {  // Box-Muller
-    double r = std::sqrt(-2.0 * std::log(uniform01(s))) * m_sigma;
+    double r = std::sqrt(-2.0 * std::log(uniform01(s))) * sigma;
     double a = twoPi * uniform01(s);
     re[k] = r * std::cos(a);
     im[k] = r * std::sin(a);

@@ -23,6 +23,9 @@ class SyntheticSource : public SignalSource {
   ~SyntheticSource() override;
 
   void AddEmitter(double frequency, double amplitude) { m_emitters.push_back(Emitter{frequency, amplitude}); }
+  // Wideband burst: buffers with generation index in [first, last] get their noise scaled by `gain`
+  // (enough bins above threshold to make process_fft return true, process.cpp:62 -> triggered capture).
+  void SetBurst(uint64_t first, uint64_t last, double gain) { m_burstFirst = first; m_burstLast = last; m_burstGain = gain; }
   // Also append every generated raw buffer (queue order, including the discarded warm-up
   // sweep) to this file, so a test can replay the exact bytes through the CPU oracle.
   void SetDumpFile(const std::string &path);
@@ -46,4 +49,6 @@ class SyntheticSource : public SignalSource {
   uint64_t m_bufferIndex;
   double m_tuned;
   FILE *m_dump;
+  uint64_t m_burstFirst = 1, m_burstLast = 0;
+  double m_burstGain = 1.0;
 };

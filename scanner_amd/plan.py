@@ -150,6 +150,15 @@ class Plan:
         self._keep[slot] = None
         return mx, mn, ab
 
+    def convert_raw(self, raw):
+        """K1 alone on the GPU: raw buffers (numpy, the plan's wire format) -> complex64 [B, n]."""
+        raw = np.ascontiguousarray(raw)
+        nb = raw.nbytes // self.buffer_bytes
+        out = np.empty((nb, self.n), np.complex64)
+        capi.check(self._L.scn_convert_raw(self._h, raw.ctypes.data_as(C.c_void_p), nb, out.ctypes.data_as(C.c_void_p)),
+                   "scn_convert_raw")
+        return out
+
     # -- plumbing -----------------------------------------------------------
     @property
     def stream_handle(self):

@@ -159,3 +159,34 @@ def test_scan_synth_two_consumer_threads_and_time_domain(host_build, tmp_path):
                           "--niterations", "2", "--mode", "time", "--threshold", "10", "--emitter", "433.92e6:0.3"],
                          capture_output=True, text=True, timeout=300)
     assert td2.returncode == 0 and "Max signal" not in td2.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,enob", [("short_complex", 12), ("float", 12)])
+def test_triggered_capture_file(host_build, oracle_mod, tmp_path, kind, enob):
+    """Triggered capture (process.cpp:160-181,250-270; messageQueue.h:98-139,259-288): a wideband burst makes
+    process_fft return true for three buffers; with pre=2 / post=3 the writer must dump exactly the buffers
+    [first-2, last+3] as raw fftwf_complex[N] records (K1 for the integer formats runs on the GPU)."""
+    _, demo = host_build
+    n = 4096
+    dump = tmp_path / "raw.bin"
+    base = str(tmp_path / "cap_")
+    cmd = [demo, "--kind", kind, "--n", str(n), "--start", "100e6", "--stop", "0", "--niterations", "40", "--threshold", "2",
+           "--enob", str(enob), "--sigma", "0.01", "--batch", "4", "--depth", "32", "--burst", "20:22:10", "--dump", str(dump),
+           "--outfile", base, "--pre", "2", "--post", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    # generation index g -> sequence id g-1 (the first sweep is the queue's warm-up discard)
+    assert re.search(r"BeginWrite \S+: 17\n", out.stdout), out.stdout[-2000:]
+    assert "EndWrite 25" in out.stdout
+    assert [int(x) for x in re.findall(r"Writing (\d+)", out.stdout)] == list(range(17, 25))
+    files = [f for f in os.listdir(tmp_path) if f.startswith("cap_")]
+    assert len(files) == 1 and re.match(r"cap_\d{8}-\d\d:\d\d:\d\d-103000000-1$", files[0]), files   # process.cpp:160-171
+    got = np.fromfile(tmp_path / files[0], np.complex64).reshape(-1, n)
+    assert got.shape[0] == 8
+    per = {"short_complex": 4, "float": 8}[kind] * n
+    raw = np.fromfile(dump, np.uint8).reshape(-1, per)[18:26]          # generation indices 18..25
+    o = oracle_mod.Oracle(n, kind={"short_complex": 3, "float": 4}[kind], enob=enob)
+    dt = {"short_complex": np.int16, "float": np.complex64}[kind]
+    want = np.stack([o.convert(r.view(dt)) for r in raw])
+    assert np.array_equal(got, want)                                     # bit-exact K1 on the GPU

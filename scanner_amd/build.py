@@ -62,7 +62,7 @@ def build(force=False, verbose=False, defines=(), out=None):
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libscanner_host.so")
 HOST_DEMO = os.path.join(HOST, "scan_synth")
-HOST_SOURCES = ["frequencyTable.cpp", "messageQueue.cpp", "signalSource.cpp", "syntheticSource.cpp",
+HOST_SOURCES = ["frequencyTable.cpp", "messageQueue.cpp", "signalSource.cpp", "syntheticSource.cpp", "fileSource.cpp",
                 "processInterface.cpp", "sampleBuffer.cpp", "process.cpp"]
 
 

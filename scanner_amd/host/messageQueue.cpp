@@ -20,7 +20,7 @@ SampleQueue::SampleQueue(SampleKind kind, uint32_t enob, uint32_t sampleCount, u
       m_correctDCOffset(correctDCOffset), m_doWrite(doWrite), m_bufferBytes(bytesPerSample(kind) * sampleCount),
       m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_nextSequenceId(0),
       m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0), m_writeFile(nullptr),
-      m_writeActive(false), m_writeNext(0) {
+      m_writeActive(false), m_writeShutdown(false), m_writeNext(0) {
   assert(kind > Illegal && kind <= FloatComplex);  // messageQueue.h:163
   assert(bufferCount > 0);
   if (m_poolSize <= bufferCount) m_poolSize = bufferCount + 1;
@@ -41,7 +41,7 @@ SampleQueue::~SampleQueue() {
     printf("Stopping write thread...\n");  // messageQueue.h:176
     {
       std::unique_lock<std::mutex> lock(m_historyMutex);
-      m_done = true;  // (SetIsDone has normally run already)
+      m_writeShutdown = true;
       m_writeWake.notify_all();
     }
     m_writeThread->join();
@@ -136,6 +136,14 @@ void SampleQueue::MessageProcessed(MessageType *message) {
     return;
   }
   if (m_history.size() >= m_historyCapacity) {
+    // Back-pressure the reference lacks: the oldest message is not recycled while the capture
+    // writer still has to dump it (the reference silently loses records when its ring laps the writer).
+    while (m_writeActive && !m_history.empty()) {
+      const uint64_t oldest = m_history.back()->GetHeader().m_sequenceId;
+      if (oldest < m_writeNext || oldest >= m_writeEnd) break;
+      m_writeWake.notify_one();
+      m_writeDrained.wait(lock);
+    }
     MessageType *old = m_history.back();
     m_history.pop_back();
     Free(old);
@@ -174,8 +182,10 @@ void SampleQueue::WriteThreadWorker() {
   std::vector<float> converted(2 * (size_t)m_sampleCount);
   std::unique_lock<std::mutex> lock(m_historyMutex);
   while (true) {
-    while (!m_done && !m_writeActive) m_writeWake.wait(lock);
-    if (!m_writeActive) break;  // done, nothing being written
+    // (the reference's writer gives up as soon as the PRODUCER is done, messageQueue.h:100-121, losing
+    // whatever the consumers had not processed yet; this one runs until the queue is torn down)
+    while (!m_writeShutdown && !m_writeActive) m_writeWake.wait(lock);
+    if (!m_writeActive) break;  // shutting down, nothing being written
     // oldest -> newest: find the first message the writer still wants
     MessageType *next = nullptr;
     bool pastEnd = false;
@@ -208,13 +218,15 @@ void SampleQueue::WriteThreadWorker() {
       fwrite(data, m_kind != FloatComplex && !m_converter ? 1 : sizeof(fftwf_complex),
              m_kind != FloatComplex && !m_converter ? m_bufferBytes : m_sampleCount, f);
       lock.lock();
+      m_writeDrained.notify_all();
       continue;
     }
-    if (pastEnd || m_done) {  // capture complete (or the stream ended): close the file
+    if (pastEnd || m_writeShutdown) {  // capture complete (or the queue is going away): close the file
       if (m_writeFile) fclose(m_writeFile);
       m_writeFile = nullptr;
       m_writeActive = false;
-      if (m_done) break;
+      m_writeDrained.notify_all();
+      if (m_writeShutdown) break;
       continue;
     }
     m_writeWake.wait(lock);

@@ -114,9 +114,10 @@ class SampleQueue {
   // write thread state (guarded by m_historyMutex)
   void WriteThreadWorker();
   std::unique_ptr<std::thread> m_writeThread;
-  std::condition_variable m_writeWake;
+  std::condition_variable m_writeWake, m_writeDrained;
   FILE *m_writeFile;
   bool m_writeActive;
+  bool m_writeShutdown;  // set by the destructor: the consumers are gone, drain what is there and stop
   uint64_t m_writeNext;  // next sequence id the writer wants
   Converter m_converter;
 };

@@ -14,6 +14,7 @@
 #include "frequencyTable.h"
 #include "messageQueue.h"
 #include "sampleBuffer.h"
+#include "fileSource.h"
 #include "syntheticSource.h"
 
 static int g_fail = 0;
@@ -155,6 +156,41 @@ static void test_synthetic_source() {
   CHECK(got == 2 * src.GetFrequencyCount() && starts == 2);
 }
 
+static void test_file_source() {
+  // a SyntheticSource dump replayed through FileSource delivers the same bytes in the same order
+  const uint32_t n = 256, fs = 8000000;
+  const char *path = "/tmp/scn_filesource_test.bin";
+  std::vector<std::vector<int16_t>> sent;
+  {
+    SyntheticSource src(fs, n, 88e6, 100e6, SampleQueue::ShortComplex, 9, 0.05);
+    src.SetDumpFile(path);
+    SampleQueue q(SampleQueue::ShortComplex, 12, n, 64, false, false);
+    src.StartStreaming(3, q);
+    while (SampleQueue::MessageType *m = q.GetNextSamples()) {
+      const int16_t *r = (const int16_t *)m->GetRawData();
+      sent.push_back(std::vector<int16_t>(r, r + 2 * n));
+      q.MessageProcessed(m);
+    }
+    src.StopStreaming();
+  }
+  FileSource fsrc(path, fs, n, 88e6, 100e6, SampleQueue::ShortComplex);
+  SampleQueue q(SampleQueue::ShortComplex, 12, n, 64, false, false);
+  fsrc.StartStreaming(100, q);  // more sweeps than the file holds: end of file ends the stream
+  size_t k = 0;
+  double lastFc = 0;
+  while (SampleQueue::MessageType *m = q.GetNextSamples()) {
+    const int16_t *r = (const int16_t *)m->GetRawData();
+    CHECK(k < sent.size() && std::vector<int16_t>(r, r + 2 * n) == sent[k]);
+    lastFc = m->GetHeader().m_frequency;
+    k++;
+    q.MessageProcessed(m);
+  }
+  fsrc.StopStreaming();
+  // the dump holds 3 sweeps (incl. the warm-up one the first queue discarded); replay discards its own first sweep
+  CHECK(k == sent.size() && fsrc.GetBuffersRead() == 3 * fsrc.GetFrequencyCount() && lastFc > 88e6);
+  remove(path);
+}
+
 int main() {
   test_queue_basic();
   test_queue_blocking_and_recycle();
@@ -162,6 +198,7 @@ int main() {
   test_sample_buffer();
   test_frequency_table();
   test_synthetic_source();
+  test_file_source();
   if (g_fail) {
     fprintf(stderr, "%d check(s) failed\n", g_fail);
     return 1;

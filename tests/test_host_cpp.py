@@ -38,7 +38,7 @@ def test_host_classes_under_sanitizers(host_build, tmp_path, san):
     binary so they are instrumented; libscanner_hip is only linked for scn_frequency_table."""
     exe = tmp_path / "test_host_san"
     srcs = [os.path.join(HOST, f) for f in ("frequencyTable.cpp", "messageQueue.cpp", "signalSource.cpp",
-                                            "syntheticSource.cpp", "processInterface.cpp", "sampleBuffer.cpp")]
+                                            "syntheticSource.cpp", "fileSource.cpp", "processInterface.cpp", "sampleBuffer.cpp")]
     cmd = ["g++", "-std=gnu++11", "-O1", "-g", "-fno-omit-frame-pointer", f"-fsanitize={san}", "-pthread", "-I", HOST,
            os.path.join(ROOT, "tests", "cpp", "test_host_cpu.cpp")] + srcs + [
            "-o", str(exe), "-L" + os.path.join(ROOT, "scanner_amd"), "-lscanner_hip",

@@ -214,6 +214,16 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   // pass-3 identity for M == 32: parity e = lane half, butterfly kl
   const uint32_t e = (t >> 5) & 1u, kl32 = (t & 31u) + 32u * (t >> 6);
 
+  // the first buffer's samples go out before anything else: their latency then overlaps the
+  // ~31 table loads below instead of following them
+  typename L::raw_t raw[16];
+  if (PF && blockIdx.x < args.n_buffers) {
+    __amdgpu_buffer_rsrc_t r0 =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+#pragma unroll
+    for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(r0, N, t, T * a);
+  }
+
   // persistent per-thread constants: pass-1 twiddles W_N^(t*p) and window taps
   cf tw1[16];
 #pragma unroll
@@ -256,14 +266,6 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   auto flush_counts = [&](uint32_t first_k, uint32_t count) {
     if (t < count) args.per_buffer_hits[blockIdx.x + (first_k + t) * gridDim.x] = (uint32_t)lds_hist[t];
   };
-
-  typename L::raw_t raw[16];
-  if (PF && blockIdx.x < args.n_buffers) {
-    __amdgpu_buffer_rsrc_t r0 =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
-#pragma unroll
-    for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(r0, N, t, T * a);
-  }
 
   for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
     // ---- K1 + K2: load, convert, window ----

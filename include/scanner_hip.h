@@ -175,6 +175,23 @@ int scn_frequency_table(uint32_t sample_rate, double start, double stop,
                         uint32_t shard, uint32_t n_shards, double *out,
                         uint32_t cap, uint32_t *count, uint32_t *first);
 
+/* HackRFSource::interpolateSamples (hackRFSource.cpp:186-222), the in-band header of HackRF
+ * sweep-mode transfers: when the transfer starts with the bytes 0x7F 0x7F, bytes 2..9 hold the
+ * tuned frequency in Hz (little-endian u64) and the first five int8 IQ samples (bytes 0..9) are
+ * overwritten in place with the sixth (bytes 10,11).  *center_frequency receives
+ * double(frequency + scan_offset_hz) (:221), i.e. double(scan_offset_hz) when no header is found.
+ * Host-only (12 bytes of work per transfer; the frequency is needed on the host for scn_submit's
+ * center_freqs anyway), needs no device.  Reproduces the reference as written: its loop over
+ * 8192-sample blocks (:191-192) re-reads the START of the transfer every iteration, so only block
+ * 0's header is ever parsed and later blocks are passed through untouched; a later iteration
+ * matches again only when the patched sample is itself (0x7F,0x7F), in which case the frequency is
+ * re-read from the patched bytes and the patch value is averaged with the sample before the block
+ * (:210-213) -- also reproduced.  *n_mismatch (optional) counts the iterations at which the
+ * reference prints "interpolateSamples: frequencyHz[..] != thisFrequencyHz[..]" (:204-208); the
+ * library itself prints nothing. */
+int scn_hackrf_sweep_fixup(void *transfer, uint32_t valid_length, uint32_t scan_offset_hz,
+                           double *center_frequency, uint32_t *n_mismatch);
+
 /* ------------------------------------------------------------------------------------
  * Streaming Welch PSD (BASELINE config 5).  No counterpart in the reference -- it never
  * overlaps or averages -- so these entry points replace nothing; they

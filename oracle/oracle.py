@@ -86,6 +86,8 @@ def lib():
         L.scn_oracle_run_batch.argtypes = [
             C.POINTER(Params), C.c_int, u32, C.c_int, vp, u32, vp, vp, vp, vp, C.c_uint64, vp, u32]
         L.scn_oracle_welch.argtypes = [vp, u32, u32, u32, vp]
+        L.scn_oracle_hackrf_interpolate.restype = C.c_double
+        L.scn_oracle_hackrf_interpolate.argtypes = [vp, u32, u32, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -195,6 +197,14 @@ def frequency_table(sample_rate, start, stop, use_bandwidth=0.75, dc_ignore_widt
     out = np.empty(cnt, np.float64)
     L.scn_oracle_frequency_table(sample_rate, start, stop, use_bandwidth, dc_ignore_width, _p(out), cnt)
     return out
+
+
+def hackrf_interpolate(transfer_u8, scan_offset=0):
+    """hackRFSource.cpp:186-222.  Returns (patched copy of the transfer, centre frequency, mismatches)."""
+    buf = np.array(transfer_u8, dtype=np.uint8, copy=True)
+    mism = C.c_uint32()
+    fc = lib().scn_oracle_hackrf_interpolate(_p(buf), buf.size, int(scan_offset), C.byref(mism))
+    return buf, fc, mism.value
 
 
 # ---------------------------------------------------------------------------

@@ -305,6 +305,41 @@ uint32_t scn_oracle_frequency_table(uint32_t fs, double start, double stop,
   return count;
 }
 
+/* ---- HackRF sweep-mode in-band header ------------------------------------ */
+
+/* hackRFSource.cpp:186-222, statement by statement.  NOTE the block loop's pointer: the
+ * reference sets `ubuf = transfer->buffer` inside the loop without adding the block offset
+ * (:192), so every iteration examines the head of the transfer.  *n_mismatch counts the
+ * printf of :204-206. */
+double scn_oracle_hackrf_interpolate(uint8_t *buffer, uint32_t valid_length,
+                                     uint32_t scan_offset, uint32_t *n_mismatch) {
+  uint32_t count = valid_length / 2;
+  uint64_t frequency_hz = 0;
+  uint32_t mism = 0;
+  for (uint32_t i = 0; i < count; i += 8192) {
+    uint8_t *ubuf = buffer;
+    if (ubuf[0] == 0x7F && ubuf[1] == 0x7F) {
+      uint64_t this_hz = ((uint64_t)ubuf[9] << 56) | ((uint64_t)ubuf[8] << 48) |
+                         ((uint64_t)ubuf[7] << 40) | ((uint64_t)ubuf[6] << 32) |
+                         ((uint64_t)ubuf[5] << 24) | ((uint64_t)ubuf[4] << 16) |
+                         ((uint64_t)ubuf[3] << 8) | ubuf[2];
+      if (frequency_hz != 0 && frequency_hz != this_hz) mism++;
+      frequency_hz = this_hz;
+      int8_t post[2] = {(int8_t)ubuf[10], (int8_t)ubuf[11]};
+      if (i > 0) {
+        post[0] = (post[0] + (int8_t)buffer[2 * (i - 1)]) / 2;
+        post[1] = (post[1] + (int8_t)buffer[2 * (i - 1) + 1]) / 2;
+      }
+      for (uint32_t j = 0; j < 5; j++) {
+        ubuf[2 * j] = post[0];
+        ubuf[2 * j + 1] = post[1];
+      }
+    }
+  }
+  if (n_mismatch) *n_mismatch = mism;
+  return (double)(frequency_hz + scan_offset);
+}
+
 /* ---- whole consumer sequence over a batch ------------------------------- */
 
 typedef struct {

@@ -113,6 +113,12 @@ uint32_t scn_oracle_frequency_table(uint32_t sample_rate, double start,
                                     double dc_ignore_width, double *out,
                                     uint32_t cap);
 
+/* hackRFSource.cpp:186-222 (sweep-mode in-band header): parses the tuned frequency, patches the
+ * first five samples in place, returns double(frequency + scan_offset).  As written (only the head
+ * of the transfer is ever examined). */
+double scn_oracle_hackrf_interpolate(uint8_t *buffer, uint32_t valid_length,
+                                     uint32_t scan_offset, uint32_t *n_mismatch);
+
 /* The consumer sequence of process.cpp:293-299 preceded by the producer-side
  * convert of messageQueue.h:190-237, for a batch of buffers laid out back to
  * back in `raw` (kind decides the element size; planar = I block then Q block

@@ -93,6 +93,8 @@ SYMBOLS = {
     "scn_welch_collect": (C.c_int, [_vp, C.c_int, _vp]),
     "scn_frequency_table": (C.c_int, [C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32,
                                       C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "scn_hackrf_sweep_fixup": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_uint32)]),
 }
 
 
@@ -147,3 +149,13 @@ def frequency_table(sample_rate, start, stop, use_bandwidth=0.75, dc_ignore_widt
                                 out.ctypes.data_as(_vp), cnt.value, C.byref(cnt), C.byref(first)),
           "scn_frequency_table")
     return first.value, out
+
+
+def hackrf_sweep_fixup(transfer, scan_offset_hz=0):
+    """HackRFSource::interpolateSamples (hackRFSource.cpp:186-222) on a uint8/int8 numpy transfer,
+    IN PLACE.  Returns (centre frequency, mismatch count)."""
+    assert transfer.dtype.itemsize == 1 and transfer.flags.c_contiguous and transfer.flags.writeable
+    fc, mism = C.c_double(), C.c_uint32()
+    check(lib().scn_hackrf_sweep_fixup(transfer.ctypes.data_as(_vp), transfer.size, int(scan_offset_hz),
+                                       C.byref(fc), C.byref(mism)), "scn_hackrf_sweep_fixup")
+    return fc.value, mism.value

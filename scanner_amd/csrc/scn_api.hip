@@ -594,6 +594,37 @@ int scn_frequency_table(uint32_t sample_rate, double start, double stop, double 
   return SCN_OK;
 }
 
+int scn_hackrf_sweep_fixup(void *transfer, uint32_t valid_length, uint32_t scan_offset_hz,
+                           double *center_frequency, uint32_t *n_mismatch) {
+  if (!transfer || !center_frequency) return fail(SCN_E_INVALID, "null argument");
+  if (valid_length < 12) return fail(SCN_E_INVALID, "a sweep transfer holds at least 6 samples");
+  uint8_t *head = static_cast<uint8_t *>(transfer);
+  const int8_t *samples = static_cast<const int8_t *>(transfer);
+  const uint32_t n_samples = valid_length / 2;  // :188
+  uint64_t tuned = 0;
+  uint32_t mismatches = 0;
+  // one pass per 8192-sample block, every pass looking at the head of the transfer (:191-192)
+  for (uint32_t first = 0; first < n_samples; first += 8192) {
+    if (head[0] != 0x7F || head[1] != 0x7F) continue;
+    uint64_t f = 0;
+    for (int k = 7; k >= 0; k--) f = (f << 8) | head[2 + k];  // :194-201
+    if (tuned != 0 && tuned != f) mismatches++;               // :202-206
+    tuned = f;
+    int8_t fill_i = (int8_t)head[10], fill_q = (int8_t)head[11];
+    if (first > 0) {  // :209-212, int arithmetic, truncating division, narrowed back to int8
+      fill_i = (int8_t)((fill_i + samples[2 * (first - 1)]) / 2);
+      fill_q = (int8_t)((fill_q + samples[2 * (first - 1) + 1]) / 2);
+    }
+    for (int j = 0; j < 5; j++) {
+      head[2 * j] = (uint8_t)fill_i;
+      head[2 * j + 1] = (uint8_t)fill_q;
+    }
+  }
+  *center_frequency = (double)(tuned + scan_offset_hz);  // u64 + u32, then to double (:221)
+  if (n_mismatch) *n_mismatch = mismatches;
+  return SCN_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------

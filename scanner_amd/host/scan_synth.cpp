@@ -21,6 +21,7 @@ int main(int argc, char **argv) {
   std::string kindName = "short_complex", dump, outFile;
   uint32_t pre = 0, post = 0;
   unsigned long burstFirst = 1, burstLast = 0;
+  uint32_t sweepBlocks = 0, scanOffset = 0;
   double burstGain = 1.0;
   std::vector<SyntheticSource::Emitter> emitters;
   for (int i = 1; i < argc; i++) {
@@ -51,6 +52,8 @@ int main(int argc, char **argv) {
     else if (a == "--outfile") outFile = val();
     else if (a == "--pre") pre = (uint32_t)atol(val());
     else if (a == "--post") post = (uint32_t)atol(val());
+    else if (a == "--sweep-blocks") sweepBlocks = (uint32_t)atol(val());
+    else if (a == "--scan-offset") scanOffset = (uint32_t)atof(val());
     else if (a == "--burst") {  // first:last:gain
       const char *v = val();
       if (sscanf(v, "%lu:%lu:%lf", &burstFirst, &burstLast, &burstGain) != 3) { fprintf(stderr, "--burst wants first:last:gain\n"); return 2; }
@@ -75,6 +78,7 @@ int main(int argc, char **argv) {
   for (auto &e : emitters) source.AddEmitter(e.frequency, e.amplitude);
   if (!dump.empty()) source.SetDumpFile(dump);
   source.SetBurst(burstFirst, burstLast, burstGain);
+  if (sweepBlocks) source.SetSweepFraming(sweepBlocks, scanOffset);  // HackRF sweep-mode transfers
 
   // scan.cpp:211-223
   ProcessSamples process(n, fs, enob, threshold, gr::fft::window::WIN_BLACKMAN_HARRIS, timeDomain ? ProcessSamples::TimeDomain : ProcessSamples::FrequencyDomain,

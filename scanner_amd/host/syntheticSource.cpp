@@ -1,5 +1,7 @@
 #include "syntheticSource.h"
 
+#include "../../include/scanner_hip.h"
+
 #include <cassert>
 #include <cmath>
 #include <cstring>
@@ -35,8 +37,7 @@ void SyntheticSource::SetDumpFile(const std::string &path) {
   }
 }
 
-void SyntheticSource::Generate(double fc, uint64_t bufferIndex, void *raw) {
-  const uint32_t n = m_sampleCount;
+void SyntheticSource::GenerateN(double fc, uint64_t bufferIndex, void *raw, const uint32_t n) {
   const double twoPi = 6.283185307179586476925286766559;
   std::vector<double> re(n), im(n);
   uint64_t s = m_seed * 0x100000001b3ull + bufferIndex * 0x9e3779b97f4a7c15ull + 0x1234567;
@@ -131,6 +132,10 @@ bool SyntheticSource::StartStreaming(uint32_t numIterations, SampleQueue &sample
 // Same shape as the device workers (e.g. bladerfSource.cpp:244-302): tune, receive one
 // buffer, advance the table, append with a scan-start timestamp on the first entry.
 void SyntheticSource::ThreadWorker() {
+  if (m_sweepBlocks) {
+    SweepWorker();
+    return;
+  }
   std::vector<unsigned char> raw(m_bufferBytes);
   Retune(GetCurrentFrequency());
   while (!GetIsDone() && !m_finished) {
@@ -142,5 +147,40 @@ void SyntheticSource::ThreadWorker() {
     double next = GetNextFrequency();
     if (GetFrequencyCount() > 1) Retune(next);
     Push(m_sampleQueue, raw.data(), centerFrequency, isScanStart ? startTime : 0);
+  }
+}
+
+// The shape of HackRFSource::hackRF_rx_callback (hackRFSource.cpp:224-270): one transfer per tune,
+// in-band header -> centre frequency, then one AppendSamples per sampleCount samples of the transfer,
+// every one of them carrying the scan-start time when the transfer opened a sweep.
+void SyntheticSource::SweepWorker() {
+  const uint32_t count = m_sweepBlocks * 8192u;
+  if (m_kind != SampleQueue::ByteComplex || count < m_sampleCount || count % m_sampleCount) {  // :254
+    fprintf(stderr, "SyntheticSource: sweep framing needs byte IQ and a transfer that is a multiple of the buffer\n");
+    exit(1);
+  }
+  std::vector<uint8_t> transfer(2u * (size_t)count);
+  Retune(GetCurrentFrequency());
+  while (!GetIsDone() && !m_finished) {
+    const double tuned = GetCurrentFrequency();
+    const bool isScanStart = GetIsScanStart();
+    GenerateN(tuned, m_bufferIndex++, transfer.data(), count);
+    const uint64_t hz = (uint64_t)tuned - m_scanOffset;  // what the firmware writes: tune minus the offset
+    for (uint32_t b = 0; b < m_sweepBlocks; b++) {
+      uint8_t *h = transfer.data() + (size_t)b * 16384u;
+      h[0] = h[1] = 0x7F;
+      for (int k = 0; k < 8; k++) h[2 + k] = (uint8_t)(hz >> (8 * k));
+    }
+    double centerFrequency = 0;
+    int st = scn_hackrf_sweep_fixup(transfer.data(), 2u * count, m_scanOffset, &centerFrequency, nullptr);
+    if (st != SCN_OK) {
+      fprintf(stderr, "scn_hackrf_sweep_fixup: %s: %s\n", scn_error_name(st), scn_last_error());
+      exit(1);
+    }
+    time_t startTime = (time_t)(86400 + GetIterationCount());
+    double next = GetNextFrequency();
+    if (GetFrequencyCount() > 1) Retune(next);
+    for (uint32_t i = 0; i < count; i += m_sampleCount)
+      Push(m_sampleQueue, transfer.data() + 2u * (size_t)i, centerFrequency, isScanStart ? startTime : 0);
   }
 }

@@ -29,6 +29,15 @@ class SyntheticSource : public SignalSource {
   // Also append every generated raw buffer (queue order, including the discarded warm-up
   // sweep) to this file, so a test can replay the exact bytes through the CPU oracle.
   void SetDumpFile(const std::string &path);
+  // HackRF sweep-mode framing (hackRFSource.cpp:186-270), ByteComplex only: every tune delivers ONE
+  // transfer of blocksPerTransfer x 8192 samples whose blocks start with the firmware's in-band header
+  // (0x7F 0x7F + tuned frequency, little-endian u64); the worker runs scn_hackrf_sweep_fixup on it and
+  // appends transfer/sampleCount buffers at the frequency the header carried (+ scanOffset), exactly
+  // as hackRF_rx_callback does.
+  void SetSweepFraming(uint32_t blocksPerTransfer, uint32_t scanOffsetHz) {
+    m_sweepBlocks = blocksPerTransfer;
+    m_scanOffset = scanOffsetHz;
+  }
 
   bool GetNextSamples(SampleQueue *sampleQueue, double_t &centerFrequency) override;
   bool StartStreaming(uint32_t numIterations, SampleQueue &sampleQueue) override;
@@ -36,11 +45,15 @@ class SyntheticSource : public SignalSource {
   double Retune(double frequency) override;
 
   // Fill `raw` (sampleCount samples in the kind's wire format) for one tune.
-  void Generate(double centerFrequency, uint64_t bufferIndex, void *raw);
+  void Generate(double centerFrequency, uint64_t bufferIndex, void *raw) {
+    GenerateN(centerFrequency, bufferIndex, raw, m_sampleCount);
+  }
+  void GenerateN(double centerFrequency, uint64_t bufferIndex, void *raw, uint32_t n);
   size_t GetBufferBytes() const { return m_bufferBytes; }
 
  private:
   void Push(SampleQueue *q, void *raw, double fc, time_t t);
+  void SweepWorker();
   SampleQueue::SampleKind m_kind;
   uint64_t m_seed;
   double m_sigma;
@@ -51,4 +64,5 @@ class SyntheticSource : public SignalSource {
   FILE *m_dump;
   uint64_t m_burstFirst = 1, m_burstLast = 0;
   double m_burstGain = 1.0;
+  uint32_t m_sweepBlocks = 0, m_scanOffset = 0;
 };

@@ -125,6 +125,57 @@ def test_scan_synth_transcript_matches_oracle(host_build, oracle_mod, tmp_path, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,blocks", [(8192, 4), (4096, 2), (8192, 1)])
+def test_scan_synth_hackrf_sweep_framing(host_build, oracle_mod, tmp_path, n, blocks):
+    """SURVEY 8(f) row 4 end to end: HackRF sweep-mode transfers (in-band 0x7F7F header per 8192-sample
+    block) -> scn_hackrf_sweep_fixup -> several int8 buffers per transfer at the header's frequency
+    (hackRFSource.cpp:186-270) -> the HIP path; transcript against the oracle on the dumped bytes."""
+    from scanner_amd import capi
+
+    _, demo = host_build
+    fs, iters, offset = 8000000, 2, 3000000
+    dump = tmp_path / "raw.bin"
+    cmd = [demo, "--kind", "byte", "--n", str(n), "--fs", str(fs), "--start", "2400e6", "--stop", "2440e6",
+           "--niterations", str(iters), "--threshold", "12", "--enob", "8", "--sigma", "0.03", "--batch", "7",
+           "--depth", "32", "--dump", str(dump), "--sweep-blocks", str(blocks), "--scan-offset", str(offset),
+           "--emitter", "2412.3e6:0.3", "--emitter", "2437.1e6:0.2", "--emitter", "2426.6e6:0.1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = [l for l in out.stdout.splitlines() if l.startswith("freq ")]
+    starts = [l for l in out.stdout.splitlines() if l.startswith("Start scan at ")]
+
+    centres = capi.frequency_table(fs, 2400e6, 2440e6)[1]
+    k = blocks * 8192 // n                      # buffers per transfer
+    raw = np.fromfile(dump, np.int8).reshape(-1, 2 * n)
+    assert raw.shape[0] == k * len(centres) * (iters + 1)
+    fc_all = np.repeat(np.tile(centres, iters + 1), k)
+    timed = np.repeat(np.tile(np.arange(len(centres)) == 0, iters + 1), k)   # buffers carrying a scan-start time
+    # the fixup ran: the first five samples of every transfer equal the sixth, and the later blocks'
+    # headers stay in the sample stream (the reference only ever looks at block 0)
+    heads = raw[::k]
+    assert (heads[:, :10].reshape(-1, 5, 2) == heads[:, None, 10:12]).all()
+    if 8192 * (blocks - 1) >= n or blocks > 1 and n == 8192:
+        second = raw[8192 // n] if n < 8192 else raw[1]
+        assert second[0] == 0x7F and second[1] == 0x7F
+    # SynchronizedAppend (messageQueue.h:65-72): the iteration count steps on EVERY timed buffer and
+    # everything from its second step on is kept
+    first_kept = int(np.flatnonzero(np.cumsum(timed) >= 2)[0])
+    raw, fc, timed = raw[first_kept:], fc_all[first_kept:], timed[first_kept:]
+    o = oracle_mod.Oracle(n, fs, 12.0, kind=KINDS["byte"], enob=8)
+    p_ref, h_ref, _ = o.run(raw, fc, np.arange(len(fc), dtype=np.uint64))
+    from tests import tolerances as tol
+
+    near = np.abs(p_ref[:, tol.evaluated_mask(n)] - 12.0) < tol.GUARD_DB
+    assert not near.any(), "pick other emitters: a bin sits on the threshold"
+    want = ["freq %d power_db" % h["freq_hz"] for h in h_ref]
+    assert len(got) == len(want) > 20
+    assert [re.match(r"(freq \d+ power_db)", l).group(1) for l in got] == want
+    vals = np.array([float(l.split()[-1]) for l in got])
+    assert np.abs(vals - h_ref["power_db"]).max() < 2e-3
+    assert len(starts) == int(timed.sum())
+
+
+@pytest.mark.gpu
 def test_scan_synth_two_consumer_threads_and_time_domain(host_build, tmp_path):
     """scan.cpp:217 runs 2 consumer threads: two plans on their own streams share the queue.  Line
     order across threads is nondeterministic (as in the reference), the multiset of lines is not."""

@@ -154,9 +154,9 @@ def test_scan_synth_hackrf_sweep_framing(host_build, oracle_mod, tmp_path, n, bl
     # headers stay in the sample stream (the reference only ever looks at block 0)
     heads = raw[::k]
     assert (heads[:, :10].reshape(-1, 5, 2) == heads[:, None, 10:12]).all()
-    if 8192 * (blocks - 1) >= n or blocks > 1 and n == 8192:
-        second = raw[8192 // n] if n < 8192 else raw[1]
-        assert second[0] == 0x7F and second[1] == 0x7F
+    if blocks > 1:
+        block1 = raw[8192 // n]                 # the buffer that starts at sample 8192 of the first transfer
+        assert block1[0] == 0x7F and block1[1] == 0x7F
     # SynchronizedAppend (messageQueue.h:65-72): the iteration count steps on EVERY timed buffer and
     # everything from its second step on is kept
     first_kept = int(np.flatnonzero(np.cumsum(timed) >= 2)[0])

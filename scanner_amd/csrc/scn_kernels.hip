@@ -171,6 +171,32 @@ struct RawLoader<SCN_K_SHORT> {
 //       read  (pass 3): fixed c, lanes kl consecutive
 //   then the pass-2 twiddle table [q][c] (16*M entries), DC-sum scratch, the hit counter.
 // ------------------------------------------------------------------------------------
+// Experiment build (-DSCN_STAMPS=1, scripts/stamp_profile.py): every wave reads the shader clock at the
+// phase boundaries of the buffer loop; wave 0 of each workgroup leaves the per-phase cycle totals in the
+// first 12 floats of its first buffer's spectrum.  Never defined in the product build.
+#ifndef SCN_STAMPS
+#define SCN_STAMPS 0
+#endif
+// Where the next buffer's 16 loads are issued: 0 all before pass 1; 1 all after barrier 1; 2 8/8 over those
+// two points; 3 4/4/4/4 over the four barrier-separated phases; 4 (product) 6/5/5 over the first three; 5 8/4/4.
+// Measured (profiles/r01_floors.md): 0 -> 4 is -3..-5 us per launch; 3, 4, 5 are within noise of each other.
+#ifndef SCN_PF_SPLIT
+#define SCN_PF_SPLIT 4
+#endif
+
+#if SCN_STAMPS
+#define SCN_STAMP(i)                                             \
+  do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); \
+    stamp_acc[i] += now_ - stamp_prev;                           \
+    stamp_prev = now_;                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+#else
+#define SCN_STAMP(i)
+#endif
+
 template <int M>
 struct Geo {
   static constexpr uint32_t N = 256u * M;
@@ -267,7 +293,14 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     if (t < count) args.per_buffer_hits[blockIdx.x + (first_k + t) * gridDim.x] = (uint32_t)lds_hist[t];
   };
 
+  // output o of this thread is bin j = jbase + joff(o):  M <= 16: o = u*M + r, j = t + T*u + 256*r;  M == 32: o = r', j = kl + 4096*e + 256*r'
+  auto joff_of = [](int o) -> uint32_t { return (M == 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M); };
+#if SCN_STAMPS
+  uint32_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t stamp_prev = (uint32_t)__builtin_readcyclecounter();
+#endif
   for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
+    SCN_STAMP(0);  // previous buffer's hit recording + loop back
     // ---- K1 + K2: load, convert, window ----
     if (!PF) {
       __amdgpu_buffer_rsrc_t rin =
@@ -307,18 +340,31 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     cf v[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, 1.0f) * win[a];
-    if (PF) {
-      // the raw registers are free again: start fetching the next buffer of this workgroup now,
-      // its latency hides behind the FFT passes below
-      const uint32_t nxt = buf + gridDim.x;
-      if (nxt < args.n_buffers) {
-        __amdgpu_buffer_rsrc_t rn =
-            make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)nxt * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+    SCN_STAMP(1);  // wait for this buffer's samples (+ convert, window)
+    // The raw registers are free again: fetch the next buffer of this workgroup while this one is
+    // transformed.  Branch-free (past the last buffer the descriptor has zero records: the loads return
+    // zeros without touching memory), so every load sits in the same basic block as the butterflies and
+    // can be issued between them: a burst of 16 loads stalls the wave at issue for ~1600 cycles when the
+    // memory pipeline is backed up (profiles/r01_floors.md, stamp profile), spread out they do not.
+    const uint32_t nxt = buf + gridDim.x;
+    const __amdgpu_buffer_rsrc_t rn =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(nxt < args.n_buffers ? nxt : buf) * L::kBufBytes(N),
+                  (nxt < args.n_buffers && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
+    auto prefetch = [&](int a_lo, int a_hi) {
 #pragma unroll
-        for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(rn, N, t, T * a);
-      }
-    }
+      for (int a = 0; a < 16; a++)
+        if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(rn, N, t, T * a);
+    };
+    // issue points: 0 before pass 1, 1 after barrier 1, 2 after barrier 2, 3 after barrier 3;
+    // pf_cut[k] .. pf_cut[k+1] = the loads issued at point k
+    constexpr int pf_cut[5] = {0,
+                               SCN_PF_SPLIT == 0 ? 16 : SCN_PF_SPLIT == 1 ? 0 : SCN_PF_SPLIT == 2 ? 8 : SCN_PF_SPLIT == 3 ? 4 : SCN_PF_SPLIT == 4 ? 6 : 8,
+                               SCN_PF_SPLIT <= 2 ? 16 : SCN_PF_SPLIT == 3 ? 8 : SCN_PF_SPLIT == 4 ? 11 : 12,
+                               SCN_PF_SPLIT <= 2 ? 16 : SCN_PF_SPLIT == 3 ? 12 : 16,
+                               16};
+    if (PF) prefetch(pf_cut[0], pf_cut[1]);
 
+    SCN_STAMP(2);  // issue of the next buffer's loads
     // ---- pass 1: DFT over a, twiddle W_N^(t p), scatter to row p ----
     fft16(v);
 #pragma unroll
@@ -327,7 +373,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       if (p) y = cmul(y, tw1[p]);
       w1[p * P1] = to_v2f(y);
     }
+    SCN_STAMP(3);  // pass 1 + exchange-1 writes
     __syncthreads();
+    SCN_STAMP(4);  // barrier 1
     if (HITS) {
       // every wave has passed the barrier above, so the previous buffer's recorders are done
       if (wave == 0 && n_done) {
@@ -343,13 +391,20 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     // ---- pass 2: thread (p, c): DFT over b, twiddle W_{16M}^(c q) ----
 #pragma unroll
     for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * M]);
+    if (PF) prefetch(pf_cut[1], pf_cut[2]);
     fft16(v);
 #pragma unroll
     for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * M]));
+    SCN_STAMP(5);  // exchange-1 reads + pass 2 + twiddles
     __syncthreads();  // every exchange-1 read done before the area is re-used
+    SCN_STAMP(6);  // barrier 2
+    if (PF) prefetch(pf_cut[2], pf_cut[3]);
 #pragma unroll
     for (int q = 0; q < 16; q++) w2[q * 16] = to_v2f(v[OUT16(q)]);
+    SCN_STAMP(7);  // exchange-2 writes
     __syncthreads();
+    SCN_STAMP(8);  // barrier 3
+    if (PF) prefetch(pf_cut[3], pf_cut[4]);
 
     // ---- pass 3: M-point DFT over c ----
     if constexpr (M == 32) {
@@ -392,21 +447,24 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       }
     }
 
-    // ---- K4 + K5: output o of this thread is bin j = jbase + joff(o) ----
-    //   M <= 16: o = u*M + r, j = t + T*u + 256*r        M == 32: o = r', j = kl + 4096*e + 256*r'
+    // ---- K4 + K5 ----
     v16f db;  // a true vector: the recording path below indexes it with a wave-uniform o (s_set_gpr_idx)
     float dmax = -3.40282347e+38f;  // cheap pre-filter: max over this thread's 16 bins (NaN-free: max ignores NaN)
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
 #pragma unroll
     for (int o = 0; o < 16; o++) {
-      const uint32_t joff = (M == 32) ? 256u * o : T * (o / M) + 256u * (o % M);
-      // NB: never __builtin_bit_cast a vector ELEMENT (db[o]): clang reads element 0 for every o
       const float d = power_db(v[out_reg<M>(o)]);
       db[o] = d;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 4u * joff, AUX_ST);
+      // NB: never __builtin_bit_cast a vector ELEMENT (db[o]): clang reads element 0 for every o
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 4u * joff_of(o), AUX_ST);
       if (HITS) dmax = fmaxf(dmax, d);
     }
+    SCN_STAMP(9);  // exchange-2 reads + pass 3 + dB + stores issued
     __syncthreads();  // exchange area free again
+    SCN_STAMP(10);  // barrier 4
+#if SCN_STAMPS
+    stamp_acc[11] += 1;
+#endif
     if (HITS) {
       // Recording runs AFTER the barrier: a wave that holds detections does not stall the other
       // waves of its workgroup, they go on to the next buffer and meet it at that buffer's first
@@ -447,6 +505,12 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       par ^= 1;
     }
   }
+#if SCN_STAMPS
+  if (t == 0 && blockIdx.x < args.n_buffers && args.power_db) {
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int i = 0; i < 12; i++) args.power_db[(size_t)blockIdx.x * N + i] = (float)stamp_acc[i];
+  }
+#endif
   if (HITS) {
     __syncthreads();  // last buffer's recorders done
     if (wave == 0 && n_done) {

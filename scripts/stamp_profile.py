@@ -1,0 +1,41 @@
+"""Per-phase shader-clock profile of the fused kernel (experiment build -DSCN_STAMPS=1).
+   python scripts/build_variants.py stamps=SCN_STAMPS=1
+   SCN_LIB=scanner_amd/variants/lib_stamps.so python scripts/stamp_profile.py [n] [flags]
+Every workgroup's wave 0 accumulates cycles between phase boundaries over all its buffers; printed:
+mean cycles per buffer per phase over the workgroups, and the share of the loop."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, '.')
+from scanner_amd import Plan, capi, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+flags = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+nb = 8192 * 4096 // n
+dev = torch.device('cuda', 0)
+R = 4
+xs = [synth.cfloat_batch_torch(n, nb, seed=2 + r, device=dev) for r in range(R)]
+outs = [torch.empty((nb, n), dtype=torch.float32, device=dev) for r in range(R)]
+fc = 3e6 + 6e6 * np.arange(nb)
+p = Plan(n, 8000000, 10.0, max_batch=nb, max_hits=nb * 64, flags=flags)
+for k in range(12):   # pipelined like the bench; the last launch's stamps are read
+    p.submit_device(k & 1, xs[k % R], nb, fc, sync_producer=False, d_power_db=outs[k % R])
+    p.collect(k & 1, False, False)
+torch.cuda.synchronize()
+o = outs[(12 - 1) % R].cpu().numpy()
+names = ["hit recording + loop", "wait for samples + convert/window", "issue next loads", "pass 1 + exch-1 writes",
+         "barrier 1", "exch-1 reads + pass 2 + twiddle", "barrier 2", "exch-2 writes", "barrier 3",
+         "exch-2 reads + pass 3 + dB + stores", "barrier 4"]
+# workgroups = those whose first 12 floats look like stamps: count field == buffers per workgroup
+cnt = o[:, 11]
+grid = int((cnt > 0).sum()) if False else None
+rows = []
+for g in range(nb):
+    c = o[g, 11]
+    if c >= 1 and c == np.floor(c) and c <= nb and abs(o[g, :11].sum()) > 1000 and (o[g, :11] >= 0).all():
+        rows.append(o[g, :12])
+    else:
+        break
+rows = np.array(rows)
+per = rows[:, :11] / rows[:, 11:12]
+tot = per.sum(1).mean()
+print(f"n={n} flags={flags}: {len(rows)} workgroups, {rows[:,11].mean():.1f} buffers each, {tot:.0f} cycles per buffer per workgroup")
+for i, nm in enumerate(names):
+    print(f"  {nm:42s} {per[:, i].mean():8.0f} cyc  {100 * per[:, i].mean() / tot:5.1f} %   (p10 {np.percentile(per[:, i], 10):6.0f}  p90 {np.percentile(per[:, i], 90):6.0f})")

@@ -298,6 +298,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #if SCN_STAMPS
   uint32_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t stamp_prev = (uint32_t)__builtin_readcyclecounter();
+  const uint32_t stamp_t0 = (uint32_t)wall_clock64();  // 100 MHz
+  uint32_t stamp_hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(stamp_hw));
 #endif
   for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
     SCN_STAMP(0);  // previous buffer's hit recording + loop back
@@ -509,6 +512,12 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   if (t == 0 && blockIdx.x < args.n_buffers && args.power_db) {
     __builtin_amdgcn_s_waitcnt(0);
     for (int i = 0; i < 12; i++) args.power_db[(size_t)blockIdx.x * N + i] = (float)stamp_acc[i];
+    // start / end of this workgroup on the 100 MHz wall clock (low 24 bits: exact in a float) and where it ran
+    args.power_db[(size_t)blockIdx.x * N + 12] = (float)(stamp_t0 & 0xffffffu);
+    args.power_db[(size_t)blockIdx.x * N + 13] = (float)((uint32_t)wall_clock64() & 0xffffffu);
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    args.power_db[(size_t)blockIdx.x * N + 14] = (float)(((xcc & 0xfu) << 8) | ((stamp_hw >> 8) & 0xffu));  // xcc, se/sh/cu
   }
 #endif
   if (HITS) {

@@ -39,3 +39,14 @@ tot = per.sum(1).mean()
 print(f"n={n} flags={flags}: {len(rows)} workgroups, {rows[:,11].mean():.1f} buffers each, {tot:.0f} cycles per buffer per workgroup")
 for i, nm in enumerate(names):
     print(f"  {nm:42s} {per[:, i].mean():8.0f} cyc  {100 * per[:, i].mean() / tot:5.1f} %   (p10 {np.percentile(per[:, i], 10):6.0f}  p90 {np.percentile(per[:, i], 90):6.0f})")
+
+t0 = o[:len(rows), 12]; t1 = o[:len(rows), 13]; where = o[:len(rows), 14].astype(int)
+base = t0.min()
+st = (t0 - base) * 0.01; en = (t1 - base) * 0.01   # us
+print(f"workgroup start times (us after the first): p50 {np.percentile(st,50):.2f} p90 {np.percentile(st,90):.2f} max {st.max():.2f};  "
+      f"end: min {en.min():.2f} p50 {np.percentile(en,50):.2f} max {en.max():.2f};  duration p50 {np.percentile(en-st,50):.2f}")
+late = st > 5.0
+print(f"workgroups starting more than 5 us late: {int(late.sum())} of {len(rows)}")
+import collections
+percu = collections.Counter(where.tolist())
+print("workgroups per CU histogram:", sorted(collections.Counter(percu.values()).items()))

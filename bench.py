@@ -38,14 +38,19 @@ USE_BW = 0.75          # scan.cpp:65
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle", type=float, default=0.4,
+                    help="seconds of untimed launches BEFORE the warmup steps, so that the GPU has left its idle power "
+                         "state whatever --warmup is (from idle the first ~100 launches run at half speed and a ~35 ms "
+                         "power-management stall follows around launch 700-800, scripts/drift.py); 0 disables")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--kind", default="cfloat", choices=["cfloat", "int16", "int8"])
     ap.add_argument("--threshold", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate wall budget of the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0,
+                    help="approximate wall budget of the CPU baseline (three legs: 1, 2 and 8 threads, ~20 CPU-seconds)")
     ap.add_argument("--rotate", type=int, default=0, help="distinct input/output batches (0: enough for 1.5 GiB)")
     ap.add_argument("--welch", action="store_true", help="BASELINE config C5: streaming 65536-pt 50%%-overlap Welch PSD")
     ap.add_argument("--welch-psd", type=int, default=8, help="PSDs per submit (K=16 segments each)")
@@ -69,17 +74,22 @@ def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s):
     t0 = time.perf_counter()
     o.run(raw_host[:32], want_power=True, want_hits=True, threads=1)
     per_buf = (time.perf_counter() - t0) / 32
+    cpu_s = 0.0
     for t in sorted({1, 2, tmax}):
         nb = int(min(len(raw_host), max(64, (budget_s / 3) / per_buf * t)))
+        reps = max(1, int(round((budget_s / 3) / (per_buf * nb / t))))  # passes over the sample: ~budget/3 of wall per leg
         t0 = time.perf_counter()
-        o.run(raw_host[:nb], want_power=True, want_hits=True, threads=t)
+        for _ in range(reps):
+            o.run(raw_host[:nb], want_power=True, want_hits=True, threads=t)
         dt = time.perf_counter() - t0
-        res[t] = (nb * n / dt / 1e6, nb)
-    v, nb = res[tmax]
+        cpu_s += dt * t
+        res[t] = (reps * nb * n / dt / 1e6, nb, reps)
+    v, nb, reps = res[tmax]
     return {
         "value": round(v, 3), "unit": "Msamples/s", "cores": tmax, "kind": "port",
-        "sample": f"first {nb} of the {args.batch} buffers of rank 0's batch, {n}-pt, oracle/scn_oracle.c "
-                  f"(own radix-2 FFT, not FFTW), spectra+hits, stdout suppressed",
+        "sample": f"{reps} passes over the first {nb} of the {args.batch} buffers of rank 0's batch, {n}-pt, "
+                  f"oracle/scn_oracle.c (own radix-2 FFT, not FFTW), spectra+hits, stdout suppressed; "
+                  f"~{cpu_s:.0f} CPU-seconds over the 1/2/{tmax}-thread legs",
         "host_cores_available": ncores,
         "threads_1": round(res[1][0], 3), "threads_2": round(res[min(2, tmax)][0], 3),
     }
@@ -251,6 +261,15 @@ def main():
                 plan.collect(s, want_power=False, want_hits=False)
                 pending[s] = False
 
+    # settle: the same steps, untimed and reported, until the GPU is out of its idle power state
+    settle_steps = 0
+    if args.settle > 0:
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < args.settle or (settle_steps & 1):
+            step(settle_steps)
+            settle_steps += 1
+        drain(settle_steps)
+        torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
     drain(args.warmup)
@@ -286,6 +305,11 @@ def main():
     all_hits = sweep.gather_hits(hits, dev) if (world > 1 or force_dist) else hits
     gather_ms = (time.perf_counter() - tg0) * 1e3
 
+    # BASELINE.json config this run corresponds to (shape, format); anything else is labelled as what it is
+    config_tag = ("C2" if (n, args.kind, nb) == (4096, "cfloat", 8192) else
+                  "C4 per-GPU share" if (n, args.kind, nb) == (4096, "cfloat", 2048) else
+                  "C3 shape, batched" if (n, args.kind) == (8192, "int16") else
+                  "C1 shape, batched" if (n, args.kind) == (1024, "cfloat") else "other")
     samples_per_step = world * nb * n
     value = samples_per_step * args.steps / elapsed / 1e6
     buffers_per_s = world * nb * args.steps / elapsed
@@ -307,6 +331,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
@@ -314,7 +339,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {n}-pt FFT+power+threshold, batch {nb} {args.kind} buffers per GPU resident in HBM, "
+                "workload": f"{config_tag}: {n}-pt FFT+power+threshold, batch {nb} {args.kind} buffers per GPU resident in HBM, "
                             f"Blackman-Harris, fs={FS} Hz, threshold {args.threshold} dB; frequency table "
                             f"range-sharded over {world} GPU(s)",
                 "n": n, "batch_per_gpu": nb, "sample_kind": args.kind, "parallelism": f"table-shard x{world}",

@@ -21,17 +21,30 @@ for f in find("trace/**/*kernel_stats.csv"):
         d["Name"] = d.get("Name", "")[:90]
         if float(d.get("Percentage", 0) or 0) >= 0.5:
             print(d)
-durs = []
+recs = []
 for f in find("trace/**/*kernel_trace.csv"):
     for row in csv.DictReader(open(f)):
         if KER in row.get("Kernel_Name", ""):
-            durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            recs.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
             meta = {k: row.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
                                             "Workgroup_Size_X", "Grid_Size_X")}
-if durs:
-    durs.sort()
-    print(f"{KER}: n={len(durs)} avg={sum(durs)/len(durs)/1e3:.2f}us median={durs[len(durs)//2]/1e3:.2f}us "
-          f"min={durs[0]/1e3:.2f}us max={durs[-1]/1e3:.2f}us", meta)
+
+
+def stats(label, d):
+    d = sorted(d)
+    print(f"{label}: n={len(d)} avg={sum(d)/len(d)/1e3:.2f}us median={d[len(d)//2]/1e3:.2f}us "
+          f"min={d[0]/1e3:.2f}us max={d[-1]/1e3:.2f}us")
+
+
+if recs:
+    recs.sort()
+    print(f"{KER} launches in the trace (settle + warmup + timed steps + the final hit-list sweep):", meta)
+    stats("  all launches", [r[1] for r in recs])
+    try:  # the timed region of bench.py = the `steps` launches before the final sweep's one
+        steps = json.loads(open(os.path.join(out, "bench_trace.json")).read().strip().splitlines()[-1])["steps"]
+        stats(f"  the {steps} launches of bench.py's timed region", [r[1] for r in recs[-(steps + 1):-1]])
+    except Exception as e:  # pragma: no cover
+        print("  (timed region not separable:", e, ")")
 print("== PMC (average per launch of the FFT kernel) ==")
 summary = {}
 for f in find("pmc_*/**/*counter_collection.csv"):

@@ -82,6 +82,7 @@ struct scn_plan {
   std::vector<float> h_window;
   float *d_window = nullptr;
   scn_v2f *d_twiddle = nullptr;
+  scn_v2f *d_tw1_table = nullptr;  // [15][n/16], ScnFftArgs::tw1_table
   Slot slot[SCN_NUM_SLOTS];
 };
 
@@ -187,6 +188,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.raw = d_raw;
   a.window = p->d_window;
   a.twiddle = p->d_twiddle;
+  a.tw1_table = p->d_tw1_table;
   a.power_db = d_power;
   a.n_buffers = nb;
   a.scale = p->scale;
@@ -332,6 +334,17 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     }
     SCN_TRY(hipMemcpyAsync(p->d_window, p->h_window.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, p->stream));
     SCN_TRY(hipMemcpyAsync(p->d_twiddle, tw.data(), sizeof(float) * 2 * d.n, hipMemcpyHostToDevice, p->stream));
+    // the same values, regrouped per thread of the fused kernel: entry (p-1, t) = W_n^(t p), t < n/16
+    const uint32_t nthreads = d.n / 16;
+    std::vector<float> tw1(2 * (size_t)15 * nthreads);
+    for (uint32_t pp = 1; pp < 16; pp++)
+      for (uint32_t t = 0; t < nthreads; t++) {
+        const uint32_t m = (t * pp) & (d.n - 1);
+        tw1[2 * ((size_t)(pp - 1) * nthreads + t)] = tw[2 * m];
+        tw1[2 * ((size_t)(pp - 1) * nthreads + t) + 1] = tw[2 * m + 1];
+      }
+    SCN_TRY(hipMalloc(&p->d_tw1_table, sizeof(float) * tw1.size()));
+    SCN_TRY(hipMemcpyAsync(p->d_tw1_table, tw1.data(), sizeof(float) * tw1.size(), hipMemcpyHostToDevice, p->stream));
     SCN_TRY(hipStreamSynchronize(p->stream));
 #undef SCN_TRY
   } while (0);
@@ -352,6 +365,7 @@ int scn_plan_destroy(scn_plan *p) {
   for (int i = 0; i < SCN_NUM_SLOTS; i++) free_slot(p->slot[i]);
   if (p->d_window) (void)hipFree(p->d_window);
   if (p->d_twiddle) (void)hipFree(p->d_twiddle);
+  if (p->d_tw1_table) (void)hipFree(p->d_tw1_table);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   if (p->h2d_stream) (void)hipStreamDestroy(p->h2d_stream);
   if (p->d2h_stream) (void)hipStreamDestroy(p->d2h_stream);

@@ -24,6 +24,9 @@ struct ScnFftArgs {
   const void *raw;          // n_buffers raw buffers back to back
   const float *window;      // [N]
   const scn_v2f *twiddle;   // W_N^m = exp(-2 pi i m / N), m in [0, N)
+  const scn_v2f *tw1_table; // [15][N/16]: entry (p-1, t) = W_N^(t p): the pass-1 constants of thread t, p-major so that a
+                            // wave loads each p with one coalesced 512-byte access (gathered from `twiddle` with lane
+                            // stride 8p bytes the same 15 loads made the kernel prologue 6 us, up to 13 us, per launch)
   float *power_db;          // [n_buffers][N] or nullptr
   uint32_t n_buffers;
   float scale;              // onebymax of utility.cpp:65 (1.0 for float input)

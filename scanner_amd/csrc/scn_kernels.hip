@@ -234,6 +234,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
   int *lds_hist = lds_hits + 2;                             // [64] finished per-buffer counts awaiting the flush
 
+#if SCN_STAMPS
+  const uint32_t stamp_entry = (uint32_t)wall_clock64();  // first instruction of the workgroup
+#endif
   const uint32_t t = threadIdx.x;
   const uint32_t p2 = t / M, c2 = t % M;  // pass-2 identity (p, c); also the (q, c) of the table entry below
   const uint32_t lane = t & 63, wave = t >> 6;
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   // persistent per-thread constants: pass-1 twiddles W_N^(t*p) and window taps
   cf tw1[16];
 #pragma unroll
-  for (int p = 1; p < 16; p++) tw1[p] = from_v2f(args.twiddle[(t * p) & (N - 1)]);
+  for (int p = 1; p < 16; p++) tw1[p] = from_v2f(args.tw1_table[(p - 1) * T + t]);
   // Window taps with the ENOB scale folded in: onebymax (utility.cpp:65) is +-2^-k, so
   // float(s)*scale*w and float(s)*(scale*w) round identically -- one multiply per component saved.
   float win[16];
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     args.power_db[(size_t)blockIdx.x * N + 14] = (float)(((xcc & 0xfu) << 8) | ((stamp_hw >> 8) & 0xffu));  // xcc, se/sh/cu
+    args.power_db[(size_t)blockIdx.x * N + 15] = (float)(stamp_entry & 0xffffffu);
   }
 #endif
   if (HITS) {

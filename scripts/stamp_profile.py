@@ -40,9 +40,11 @@ print(f"n={n} flags={flags}: {len(rows)} workgroups, {rows[:,11].mean():.1f} buf
 for i, nm in enumerate(names):
     print(f"  {nm:42s} {per[:, i].mean():8.0f} cyc  {100 * per[:, i].mean() / tot:5.1f} %   (p10 {np.percentile(per[:, i], 10):6.0f}  p90 {np.percentile(per[:, i], 90):6.0f})")
 
-t0 = o[:len(rows), 12]; t1 = o[:len(rows), 13]; where = o[:len(rows), 14].astype(int)
-base = t0.min()
-st = (t0 - base) * 0.01; en = (t1 - base) * 0.01   # us
+t0 = o[:len(rows), 12]; t1 = o[:len(rows), 13]; where = o[:len(rows), 14].astype(int); te = o[:len(rows), 15]
+base = te.min()
+st = (t0 - base) * 0.01; en = (t1 - base) * 0.01; ent = (te - base) * 0.01   # us
+print(f"workgroup ENTRY times (us after the first): p50 {np.percentile(ent,50):.2f} p90 {np.percentile(ent,90):.2f} max {ent.max():.2f};  "
+      f"prologue (entry -> first buffer): p10 {np.percentile(st-ent,10):.2f} p50 {np.percentile(st-ent,50):.2f} p90 {np.percentile(st-ent,90):.2f} max {(st-ent).max():.2f} us")
 print(f"workgroup start times (us after the first): p50 {np.percentile(st,50):.2f} p90 {np.percentile(st,90):.2f} max {st.max():.2f};  "
       f"end: min {en.min():.2f} p50 {np.percentile(en,50):.2f} max {en.max():.2f};  duration p50 {np.percentile(en-st,50):.2f}")
 late = st > 5.0

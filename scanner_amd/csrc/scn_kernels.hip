@@ -535,6 +535,254 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 }
 
 // ------------------------------------------------------------------------------------
+// 8192 points, wide form: ONE workgroup of 256 threads per buffer, 32 points per thread.
+//
+// Same decomposition as above (n = 512a + 32b + c, k = p + 16q + 256r, passes 16 x 16 x 32), but every
+// thread plays two of the 512 "virtual threads" of passes 1 and 2 (tau and tau + 256) and owns one whole
+// 32-point DFT in pass 3 (in registers: two 16-point DFTs + one radix-2 step, no cross-lane exchange).
+// Why: with 512 threads a workgroup is 8 waves, two workgroups per CU are 4 waves per SIMD = 128 VGPRs,
+// which leaves no registers to prefetch the next buffer -- the stamp profile of that form shows the load
+// latency fully exposed (19 % waiting for samples, 20 % at barrier 1, 13 % at barrier 4).  256 threads x
+// 2 workgroups per CU (LDS: 2 x 70 KiB) are 2 waves per SIMD = 256 VGPRs: room for the next buffer's
+// 32 samples per thread, fetched in three groups spread over the passes like the smaller sizes.
+// LDS layouts and bank behaviour are those of Geo<32> (P1 = 512, P2 = 257): each wave touches the same
+// slots per instruction as a wave of the 512-thread form does.
+// ------------------------------------------------------------------------------------
+#ifndef SCN_WIDE_8192
+#define SCN_WIDE_8192 1
+#endif
+namespace {
+struct Geo8k {
+  static constexpr uint32_t N = 8192, T = 256, P1 = 512, P2 = 257;
+  static constexpr uint32_t EXCH = (16u * P1 > 32u * P2) ? 16u * P1 : 32u * P2;  // slots
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + 512u * 8u + 16u * 4u + 2u * 4u + 8u;
+  static constexpr uint32_t WG_PER_CU = 2;
+};
+typedef float v32f __attribute__((ext_vector_type(32)));
+}  // namespace
+
+template <int KIND, bool DC, bool HITS>
+__global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
+  typedef Geo8k G;
+  constexpr int AUX_LD = SCN_AUX_LD;
+  constexpr int AUX_ST = SCN_AUX_ST;
+  constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
+  typedef RawLoader<KIND> L;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+  v2f *lds_tw2 = lds + G::EXCH;                              // [16][32]: W_512^(c q) at q*32 + c
+  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + 512);    // [16] DC-sum scratch (re[8], im[8])
+  int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
+
+  const uint32_t t = threadIdx.x;
+  const uint32_t lane = t & 63, wave = t >> 6;
+  const uint32_t c2 = t & 31u, p2 = t >> 5;  // pass-2 identity of virtual thread t: (p2, c2); of t + 256: (p2 + 8, c2)
+
+  // first buffer's samples first: x[256 a' + t], a' = 2a + h  <->  virtual thread t + 256 h, input a
+  typename L::raw_t raw[32];
+  if (blockIdx.x < args.n_buffers) {
+    __amdgpu_buffer_rsrc_t r0 =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+#pragma unroll
+    for (int a = 0; a < 32; a++) raw[a] = L::template load<AUX_LD>(r0, N, t, T * a);
+  }
+  // persistent constants: pass-1 twiddles of both virtual threads (coalesced table rows of 512), window taps
+  cf tw1a[16], tw1b[16];
+#pragma unroll
+  for (int p = 1; p < 16; p++) {
+    tw1a[p] = from_v2f(args.tw1_table[(p - 1) * 512 + t]);
+    tw1b[p] = from_v2f(args.tw1_table[(p - 1) * 512 + 256 + t]);
+  }
+  float win[32];
+#pragma unroll
+  for (int a = 0; a < 32; a++) win[a] = args.window[T * a + t] * args.scale;
+  // pass-2 twiddles W_512^(c q) = W_N^(16 c q), entry q*32 + c: this thread fills entries t and t + 256
+  lds_tw2[t] = args.twiddle[(16u * p2 * c2) & (N - 1)];
+  lds_tw2[t + 256] = args.twiddle[(16u * (p2 + 8u) * c2) & (N - 1)];
+  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
+  __syncthreads();
+
+  v2f *w1 = lds + t;                       // + p*P1 (+256 for the second virtual thread)
+  v2f *r1 = lds + p2 * P1 + c2;            // + b*32 (+ 8*P1 for the second)
+  v2f *w2 = lds + c2 * P2 + p2;            // + 16*q (+ 8 for the second)
+  v2f *r3 = lds + t;                       // + c*P2
+  const v2f *tw2 = lds_tw2 + c2;           // + q*32
+  const uint32_t st_voff = t * 4u;         // output r of this thread is bin j = t + 256 r
+
+  uint32_t keepmask = 0;  // K5 mask of this thread's 32 bins (process.cpp:46-52)
+  if (HITS) {
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+      const uint32_t j = t + 256u * r;
+      const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
+      const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
+      keepmask |= keep ? (1u << r) : 0u;
+    }
+  }
+  uint32_t par = 0;
+  uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running
+
+  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
+    // ---- K1 + K2 ----
+    int dc_re = 0, dc_im = 0;
+    if (DC) {
+      int sr = 0, si = 0;
+#pragma unroll
+      for (int a = 0; a < 32; a++) {
+        int re, im;
+        L::ints(raw[a], re, im);
+        sr += re;
+        si += im;
+      }
+      sr = wave_sum(sr);
+      si = wave_sum(si);
+      if (lane == 0) {
+        lds_cnt[wave] = sr;
+        lds_cnt[8 + wave] = si;
+      }
+      __syncthreads();
+      sr = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
+      si = lds_cnt[8] + lds_cnt[9] + lds_cnt[10] + lds_cnt[11];
+      dc_re = (int)((uint32_t)sr / N);  // int32 /= uint32, utility.cpp:77-78
+      dc_im = (int)((uint32_t)si / N);
+    }
+    cf va[16], vb[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+      va[a] = L::conv(raw[2 * a], dc_re, dc_im, 1.0f) * win[2 * a];
+      vb[a] = L::conv(raw[2 * a + 1], dc_re, dc_im, 1.0f) * win[2 * a + 1];
+    }
+    // next buffer of this workgroup, branch-free (zero records past the end), in three groups
+    const uint32_t nxt = buf + gridDim.x;
+    const __amdgpu_buffer_rsrc_t rn =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(nxt < args.n_buffers ? nxt : buf) * L::kBufBytes(N),
+                  (nxt < args.n_buffers && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
+    auto prefetch = [&](int a_lo, int a_hi) {
+#pragma unroll
+      for (int a = 0; a < 32; a++)
+        if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(rn, N, t, T * a);
+    };
+    prefetch(0, 11);
+
+    // ---- pass 1: virtual threads t and t + 256 ----
+    fft16(va);
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      cf y = va[OUT16(p)];
+      if (p) y = cmul(y, tw1a[p]);
+      w1[p * P1] = to_v2f(y);
+    }
+    fft16(vb);
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      cf y = vb[OUT16(p)];
+      if (p) y = cmul(y, tw1b[p]);
+      w1[p * P1 + 256] = to_v2f(y);
+    }
+    __syncthreads();
+    if (HITS) {
+      if (t == 0 && prev != 0xffffffffu) {  // every wave is past the barrier: the previous buffer's recorders are done
+        args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        lds_hits[par ^ 1] = 0;
+      }
+    }
+    prefetch(11, 22);
+
+    // ---- pass 2: virtual threads (p2, c2) and (p2 + 8, c2) ----
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+      va[b] = from_v2f(r1[b * 32]);
+      vb[b] = from_v2f(r1[b * 32 + 8 * P1]);
+    }
+    fft16(va);
+    fft16(vb);
+#pragma unroll
+    for (int q = 1; q < 16; q++) {
+      const cf w = from_v2f(tw2[q * 32]);
+      va[OUT16(q)] = cmul(va[OUT16(q)], w);
+      vb[OUT16(q)] = cmul(vb[OUT16(q)], w);
+    }
+    __syncthreads();  // every exchange-1 read done before the area is re-used
+    prefetch(22, 32);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      w2[q * 16] = to_v2f(va[OUT16(q)]);
+      w2[q * 16 + 8] = to_v2f(vb[OUT16(q)]);
+    }
+    __syncthreads();
+
+    // ---- pass 3: one 32-point DFT over c per thread (kl = t): even c -> va, odd c -> vb ----
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      va[c] = from_v2f(r3[(2 * c) * P2]);
+      vb[c] = from_v2f(r3[(2 * c + 1) * P2]);
+    }
+    fft16(va);
+    fft16(vb);
+
+    // ---- K4 + K5: X[r'] = E[r'] + W_32^r' O[r'], X[r' + 16] = E[r'] - W_32^r' O[r'] ----
+    v32f db;
+    float dmax = -3.40282347e+38f;
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const cf ev = va[OUT16(r)];
+      cf od = vb[OUT16(r)];
+      if (r) {
+        const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
+        const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
+        od = cmul(od, cf{cr, -sr});
+      }
+      const float d0 = power_db(ev + od), d1 = power_db(ev - od);
+      db[r] = d0;
+      db[r + 16] = d1;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d0), rout, st_voff, 1024u * r, AUX_ST);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), rout, st_voff, 1024u * (r + 16), AUX_ST);
+      if (HITS) dmax = fmaxf(dmax, fmaxf(d0, d1));
+    }
+    __syncthreads();  // exchange area free again
+    if (HITS) {
+      if (__ballot(dmax > args.threshold)) {
+        uint32_t hitmask = 0;
+#pragma unroll
+        for (int r = 0; r < 32; r++) hitmask |= (db[r] > args.threshold) ? (1u << r) : 0u;  // strict >, process.cpp:54
+        hitmask &= keepmask;
+        const uint32_t total = wave_add_u32((uint32_t)__popc(hitmask));
+        if (total) {
+          uint32_t wm = wave_or_u32(hitmask);
+          uint32_t base = 0;
+          if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
+          base = __builtin_amdgcn_readfirstlane(base);
+          while (wm) {
+            const int r = __builtin_ctz(wm);  // wave-uniform
+            wm &= wm - 1u;
+            const bool hit = (hitmask >> r) & 1u;
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+              const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+              const ScnDevHit rec = ScnDevHit{buf, (t + 256u * (uint32_t)r) ^ (N / 2), db[r], 0u};
+              if (pos < args.hit_region) {
+                args.hits[(size_t)buf * args.hit_region + pos] = rec;
+              } else {
+                uint32_t opos = atomicAdd(args.ov_counter, 1u) - args.ov_base;
+                if (opos < args.ov_cap) args.ov_hits[opos] = rec;
+              }
+            }
+            base += (uint32_t)__popcll(m);
+          }
+        }
+      }
+      prev = buf;
+      par ^= 1;
+    }
+  }
+  if (HITS) {
+    __syncthreads();  // last buffer's recorders done
+    if (t == 0 && prev != 0xffffffffu) args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Time-domain mode (process.cpp:203-237): per buffer, max and min over the samples of
 // 10*log2(|x|)/log2(10).  The dB map is monotone, so the kernel reduces max/min of |x|^2
 // (computed exactly as the reference does: re*re + im*im in float, no fused multiply-add) and
@@ -705,6 +953,32 @@ static hipError_t launch_size(int kind, bool dc, bool hits, const ScnFftArgs &ar
   }
 }
 
+template <int KIND>
+static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
+  typedef Geo8k G;
+  void (*k)(ScnFftArgs) = nullptr;
+  if (dc && hits) k = scn_fft8k_kernel<KIND, true, true>;
+  else if (dc) k = scn_fft8k_kernel<KIND, true, false>;
+  else if (hits) k = scn_fft8k_kernel<KIND, false, true>;
+  else k = scn_fft8k_kernel<KIND, false, false>;
+  // > 64 KiB of dynamic LDS: opt-in per function and per device, set on every launch (see launch_kind)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  int grid = num_cus * (int)G::WG_PER_CU;
+  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), G::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+static hipError_t launch_8k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream) {
+  switch (kind) {
+    case SCN_K_FLOAT_COMPLEX: return launch_8k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream);
+    case SCN_K_SHORT_COMPLEX: return launch_8k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream);
+    case SCN_K_SHORT: return launch_8k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream);
+    case SCN_K_BYTE_COMPLEX: return launch_8k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus,
                           hipStream_t stream) {
   if (args.n_buffers == 0) return hipSuccess;
@@ -712,7 +986,7 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFft
     case 1024: return launch_size<4>(kind, dc, hits, args, num_cus, stream);
     case 2048: return launch_size<8>(kind, dc, hits, args, num_cus, stream);
     case 4096: return launch_size<16>(kind, dc, hits, args, num_cus, stream);
-    case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream);
+    case 8192: return SCN_WIDE_8192 ? launch_8k(kind, dc, hits, args, num_cus, stream) : launch_size<32>(kind, dc, hits, args, num_cus, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -9,7 +9,7 @@ CPU fallback: importing ``capi`` without the built library raises.
 """
 from . import capi  # noqa: F401
 from .capi import (  # noqa: F401
-    KIND_BYTE_COMPLEX, KIND_SHORT, KIND_SHORT_COMPLEX, KIND_FLOAT_COMPLEX, OUT_HITS, OUT_SPECTRUM,
+    KIND_BYTE_COMPLEX, KIND_SHORT, KIND_SHORT_COMPLEX, KIND_FLOAT_COMPLEX, OUT_HITS, OUT_SPECTRUM, PLAN_OVERLAP_SLOTS,
     HIT_DTYPE, ScannerError)
 from .plan import Plan, WelchPlan  # noqa: F401
 from . import synth, sweep  # noqa: F401,E402

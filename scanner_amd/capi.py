@@ -17,6 +17,7 @@ KIND_BYTE_COMPLEX, KIND_SHORT, KIND_SHORT_COMPLEX, KIND_FLOAT_COMPLEX = 1, 2, 3,
 MODE_TIME_DOMAIN, MODE_FREQUENCY_DOMAIN = 1, 2
 WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 3, 5
 OUT_SPECTRUM, OUT_HITS = 1, 2
+PLAN_OVERLAP_SLOTS = 4  # each slot on its own compute stream (scanner_hip.h)
 DC_IGNORE_NONE = 0xFFFFFFFF
 NUM_SLOTS = 2
 ABI_VERSION = 1
@@ -82,6 +83,7 @@ SYMBOLS = {
     "scn_convert_raw": (C.c_int, [_vp, _vp, C.c_uint32, _vp]),
     "scn_wait": (C.c_int, [_vp, C.c_int]),
     "scn_plan_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "scn_slot_stream": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "scn_device_spectrum": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "scn_plan_window": (C.c_int, [_vp, _vp, C.c_uint32]),
     "scn_welch_create": (C.c_int, [C.POINTER(WelchDesc), C.POINTER(_vp)]),

@@ -55,6 +55,8 @@ struct Slot {
   uint32_t *d_buf_hits = nullptr;
   uint32_t *h_buf_hits = nullptr;
   hipEvent_t kernel_done = nullptr, staged = nullptr;
+  hipStream_t stream = nullptr;     // where this slot's kernels run: the plan's compute stream, or its own (SCN_PLAN_OVERLAP_SLOTS)
+  bool own_stream = false;
   ScnDevHit *d_hits = nullptr;      // [max_batch][hit_region] per-buffer hit regions
   ScnDevHit *d_ov_hits = nullptr;   // [max_hits] overflow list (buffers with > hit_region hits)
   uint32_t *d_ov_counter = nullptr; // device-side overflow slot allocator, never reset
@@ -143,7 +145,7 @@ int ensure_slot_outputs(scn_plan *p, Slot &s) {
     SCN_HIP(hipMalloc(&s.d_ov_counter, sizeof(uint32_t)));
     SCN_HIP(hipMalloc(&s.d_buf_hits, sizeof(uint32_t) * p->d.max_batch));
     SCN_HIP(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
-    SCN_HIP(hipMemsetAsync(s.d_ov_counter, 0, sizeof(uint32_t), p->stream));
+    SCN_HIP(hipMemsetAsync(s.d_ov_counter, 0, sizeof(uint32_t), s.stream));
     SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * p->d.max_batch, hipHostMallocDefault));
     s.ov_base = 0;
   }
@@ -168,8 +170,8 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     a.scale = p->scale;
     a.max_db = s.h_td;
     a.min_db = s.h_td + p->d.max_batch;
-    SCN_HIP(scn_launch_time_domain((int)p->d.sample_kind, p->d.correct_dc != 0, a, p->num_cus, p->stream));
-    SCN_HIP(hipEventRecord(s.done, p->stream));
+    SCN_HIP(scn_launch_time_domain((int)p->d.sample_kind, p->d.correct_dc != 0, a, p->num_cus, s.stream));
+    SCN_HIP(hipEventRecord(s.done, s.stream));
     s.pending = true;
     return SCN_OK;
   }
@@ -204,14 +206,20 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.ov_cap = p->d.max_hits;
   a.per_buffer_hits = s.d_buf_hits;
   const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
-  SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, p->stream));
-  if (hits && nb) {
-    SCN_HIP(hipEventRecord(s.kernel_done, p->stream));
+  SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, s.stream));
+  if (hits && nb && s.own_stream) {
+    // overlapped slots: the counts follow the kernel on the slot's own stream -- the next kernel there is two
+    // submits away, and one stream less keeps both compute streams on hardware queues of their own (HIP maps
+    // streams onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one)
+    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, s.stream));
+    SCN_HIP(hipEventRecord(s.done, s.stream));
+  } else if (hits && nb) {
+    SCN_HIP(hipEventRecord(s.kernel_done, s.stream));
     SCN_HIP(hipStreamWaitEvent(p->d2h_stream, s.kernel_done, 0));
     SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, p->d2h_stream));
     SCN_HIP(hipEventRecord(s.done, p->d2h_stream));
   } else {
-    SCN_HIP(hipEventRecord(s.done, p->stream));
+    SCN_HIP(hipEventRecord(s.done, s.stream));
   }
   s.pending = true;
   return SCN_OK;
@@ -223,6 +231,10 @@ void free_slot(Slot &s) {
   if (s.d_power) (void)hipFree(s.d_power);
   if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
   if (s.d_buf_hits) (void)hipFree(s.d_buf_hits);
+  if (s.own_stream && s.stream) {
+    (void)hipStreamSynchronize(s.stream);
+    (void)hipStreamDestroy(s.stream);
+  }
   if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
   if (s.staged) (void)hipEventDestroy(s.staged);
   if (s.h_td) (void)hipHostFree(s.h_td);
@@ -278,7 +290,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   if (d.dc_ignore_bins == SCN_DC_IGNORE_NONE) d.dc_ignore_bins = 0;
   if (d.use_bandwidth == 0.0) d.use_bandwidth = 0.75;  // scan.cpp:65
   if (!d.trigger_count) d.trigger_count = 1047;        // process.cpp:62
-  if (!d.flags) d.flags = SCN_OUT_SPECTRUM | SCN_OUT_HITS;
+  if (!(d.flags & (SCN_OUT_SPECTRUM | SCN_OUT_HITS))) d.flags |= SCN_OUT_SPECTRUM | SCN_OUT_HITS;
   if (!d.max_batch) return fail(SCN_E_INVALID, "max_batch must be >= 1");
   if (!d.max_hits) d.max_hits = (uint32_t)std::min<uint64_t>((uint64_t)d.max_batch * 64u, 1u << 28);
   if (bytes_per_sample(d.sample_kind) == 0) return fail(SCN_E_INVALID, "unknown sample_kind %u", d.sample_kind);
@@ -323,6 +335,14 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->h2d_stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->d2h_stream, hipStreamNonBlocking));
+    for (int k = 0; k < SCN_NUM_SLOTS; k++) {
+      Slot &sl = p->slot[k];
+      sl.stream = p->stream;
+      if ((d.flags & SCN_PLAN_OVERLAP_SLOTS) && k > 0) {  // slot 0 keeps the plan's stream (scn_plan_stream)
+        SCN_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        sl.own_stream = true;
+      }
+    }
     SCN_TRY(hipMalloc(&p->d_window, sizeof(float) * d.n));
     SCN_TRY(hipMalloc(&p->d_twiddle, sizeof(scn_v2f) * d.n));
     std::vector<float> tw(2 * (size_t)d.n);
@@ -408,7 +428,7 @@ int scn_submit(scn_plan *p, int slot, uint32_t nb, const double *fc, const uint6
     if (!s.staged) SCN_HIP(hipEventCreateWithFlags(&s.staged, hipEventDisableTiming));
     SCN_HIP(hipMemcpyAsync(s.d_raw, s.h_raw, p->buf_bytes * nb, hipMemcpyHostToDevice, p->h2d_stream));
     SCN_HIP(hipEventRecord(s.staged, p->h2d_stream));
-    SCN_HIP(hipStreamWaitEvent(p->stream, s.staged, 0));
+    SCN_HIP(hipStreamWaitEvent(s.stream, s.staged, 0));
   }
   return submit_common(p, s, s.d_raw, nb, fc, seq, nullptr);
 }
@@ -505,12 +525,12 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
       std::vector<ScnDevHit> &hh = s.host_hits;
       std::vector<ScnDevHit> regions((size_t)nb * p->hit_region);
       SCN_HIP(hipMemcpyAsync(regions.data(), s.d_hits, sizeof(ScnDevHit) * regions.size(), hipMemcpyDeviceToHost,
-                             p->stream));
+                             s.stream));
       hh.resize((size_t)in_regions + ov_kept);
       if (ov_kept)
         SCN_HIP(hipMemcpyAsync(hh.data() + in_regions, s.d_ov_hits, sizeof(ScnDevHit) * ov_kept,
-                               hipMemcpyDeviceToHost, p->stream));
-      SCN_HIP(hipStreamSynchronize(p->stream));
+                               hipMemcpyDeviceToHost, s.stream));
+      SCN_HIP(hipStreamSynchronize(s.stream));
       // Region b already holds buffer b's hits (in arbitrary order), so buffer-major order needs
       // no global sort: sort each small region by i; only the overflow list (rare) is sorted
       // globally and merged in.
@@ -548,12 +568,19 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   }
   if (n_hits) *n_hits = total;
   if (power_db && nb) {
-    SCN_HIP(hipMemcpyAsync(power_db, s.cur_power, sizeof(float) * (size_t)n * nb, hipMemcpyDeviceToHost, p->stream));
-    SCN_HIP(hipStreamSynchronize(p->stream));
+    SCN_HIP(hipMemcpyAsync(power_db, s.cur_power, sizeof(float) * (size_t)n * nb, hipMemcpyDeviceToHost, s.stream));
+    SCN_HIP(hipStreamSynchronize(s.stream));
   }
   if (result == SCN_E_TRUNCATED)
     return fail(result, "%u hits: more than the caller's capacity %u or the device overflow capacity %u", total,
                 hit_cap, p->d.max_hits);
+  return SCN_OK;
+}
+
+int scn_slot_stream(scn_plan *p, int slot, void **hip_stream) {
+  if (int st = check_slot(p, slot)) return st;
+  if (!hip_stream) return fail(SCN_E_INVALID, "null argument");
+  *hip_stream = (void *)p->slot[slot].stream;
   return SCN_OK;
 }
 

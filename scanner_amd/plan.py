@@ -166,6 +166,12 @@ class Plan:
         capi.check(self._L.scn_plan_stream(self._h, C.byref(s)), "scn_plan_stream")
         return s.value or 0
 
+    def slot_stream_handle(self, slot):
+        """The stream slot's kernels run on (differs per slot only with capi.PLAN_OVERLAP_SLOTS)."""
+        s = C.c_void_p()
+        capi.check(self._L.scn_slot_stream(self._h, slot, C.byref(s)), "scn_slot_stream")
+        return s.value or 0
+
     def window(self):
         w = np.empty(self.n, np.float32)
         capi.check(self._L.scn_plan_window(self._h, w.ctypes.data_as(C.c_void_p), self.n), "scn_plan_window")

@@ -121,6 +121,56 @@ def test_pinned_double_buffered_submit(torch_cuda, oracle_mod):
         assert np.array_equal(t, t_ref)
 
 
+@pytest.mark.parametrize("n,kind,enob,path", [(4096, capi.KIND_FLOAT_COMPLEX, 12, "device"),
+                                              (8192, capi.KIND_SHORT_COMPLEX, 12, "device"),
+                                              (4096, capi.KIND_FLOAT_COMPLEX, 12, "pinned")])
+def test_overlapped_slots_give_identical_results(torch_cuda, n, kind, enob, path):
+    """SCN_PLAN_OVERLAP_SLOTS puts the two slots on streams of their own so that consecutive launches
+    overlap; the slots share nothing but read-only tables, so every spectrum bit and every hit must equal
+    what the single-stream plan produces, in a pipeline that keeps both slots in flight."""
+    torch = torch_cuda
+    nb, rounds = 700, 6     # > one resident wave of workgroups for 8192-pt, several launches in flight
+    raws = []
+    for k in range(rounds):
+        x = synth.cfloat_batch(n, nb, seed=300 + k)
+        raws.append(synth.quantize(x, kind))
+    fcs = [100e6 + 6e6 * np.arange(nb) + 7 * k for k in range(rounds)]
+    seqs = [np.arange(k * nb, (k + 1) * nb, dtype=np.uint64) for k in range(rounds)]
+
+    def run(flags):
+        out = []
+        with Plan(n, FS, 9.5, kind=kind, enob=enob, max_batch=nb, max_hits=1 << 18, flags=flags) as plan:
+            if flags & capi.PLAN_OVERLAP_SLOTS:
+                assert plan.slot_stream_handle(0) == plan.stream_handle != plan.slot_stream_handle(1)
+            else:
+                assert plan.slot_stream_handle(0) == plan.slot_stream_handle(1) == plan.stream_handle
+            dev = [_to_dev(torch, r) for r in raws] if path == "device" else None
+            views = [plan.host_buffer(s) for s in range(2)] if path == "pinned" else None
+            for k in range(rounds):
+                s = k & 1
+                if k >= 2:
+                    out.append(plan.collect(s, hit_cap=1 << 18))
+                if path == "device":
+                    plan.submit_device(s, dev[k], nb, fcs[k], seqs[k])
+                else:
+                    views[s][:] = np.ascontiguousarray(raws[k]).view(np.uint8).reshape(-1)
+                    plan.submit(s, nb, fcs[k], seqs[k])
+            out.append(plan.collect(rounds & 1, hit_cap=1 << 18))
+            out.append(plan.collect((rounds + 1) & 1, hit_cap=1 << 18))
+        return out
+
+    base = capi.OUT_SPECTRUM | capi.OUT_HITS
+    ref = run(base)
+    got = run(base | capi.PLAN_OVERLAP_SLOTS)
+    assert len(ref) == len(got) == rounds
+    total = 0
+    for (p0, h0, t0), (p1, h1, t1) in zip(ref, got):
+        assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))       # bit-identical spectra
+        assert h0.tobytes() == h1.tobytes() and np.array_equal(t0, t1)      # identical hit records, order, trigger flags
+        total += len(h0)
+    assert total > 100
+
+
 # ---------------------------------------------------------------------------------------
 # the other FFT sizes: BASELINE C1 (1024-pt, one cfloat buffer), C3 (8192-pt int16), 2048
 # ---------------------------------------------------------------------------------------

@@ -65,6 +65,6 @@ if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 correction)"},
               open(os.path.join(out, "pmc_traffic.json"), "w"))
 try:
-    print("bench line under trace:", open(os.path.join(out, "bench_trace.json")).read().strip()[-900:])
+    print("bench line under trace:", open(os.path.join(out, "bench_trace.json")).read().strip()[-1400:])
 except Exception:
     pass

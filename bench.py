@@ -171,7 +171,7 @@ def welch_main(args):
         algo = new_samples * 8 + npsd * N * 4  # 8 B per NEW sample + 4N/K per segment
         ms = elapsed / args.steps * 1e3
         achieved = algo / (ms * 1e-3) / 1e9
-        print(json.dumps({
+        emit({
             "metric": "Msamples/s (new complex samples through 65536-pt 50%-overlap Welch PSD)",
             "value": round(world * new_samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5),
@@ -185,15 +185,39 @@ def welch_main(args):
                          "kernel": "scn_welch_cols_kernel + scn_welch_rows_kernel (two-pass four-step FFT: the work "
                                    "buffer round trip and the 50% overlap re-read are NOT algorithmic bytes)",
                          "algorithmic_bytes_per_launch": algo},
-        }), flush=True)
+        })
     plan.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The driver reads ONE JSON line from stdout.  Libraries write there too (RCCL prints a version banner to
+    stdout when the process group is created), so file descriptor 1 is pointed at stderr for the whole run and
+    the result line alone goes to the original stdout (emit)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def main():
     args = parse()
+    claim_stdout()
     if args.welch:
         return welch_main(args)
     import torch
@@ -417,7 +441,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, host, okind, enob, args.cpu_seconds)
         elif world == 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(out)
     plan.close()
     if world > 1 or force_dist:
         dist.barrier()

@@ -680,6 +680,8 @@ struct WelchSlot {
   float *cur_psd = nullptr; // device location of the pending results
   bool via_graph = false;
   hipGraphExec_t graph = nullptr;  // captured H2D -> kernel A -> kernel B -> D2H for graph_npsd PSDs
+  hipStream_t stream = nullptr;    // the pinned path's own stream: this slot's H2D overlaps the other slot's kernels
+  void *d_work = nullptr;          // ... which needs a work buffer of its own ([max_psd*K][n] complex)
   uint32_t graph_npsd = 0;
   hipEvent_t done = nullptr;
   bool pending = false;
@@ -703,19 +705,19 @@ size_t welch_samples(const scn_welch *w, uint32_t n_psd) {
   return ((size_t)n_psd * w->d.segments_per_psd + 1u) * w->hop;
 }
 
-int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd) {
+int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd, hipStream_t stream, void *d_work) {
   ScnWelchArgs a;
   a.in = d_in;
   a.window = w->d_window;
   a.twiddle = w->d_twiddle;
-  a.work = w->d_work;
+  a.work = d_work;
   a.psd_db = d_psd;
   a.n_segments = n_psd * w->d.segments_per_psd;
   a.hop = w->hop;
   a.k = w->d.segments_per_psd;
   a.n_psd = n_psd;
   a.inv_k = 1.0f / (float)w->d.segments_per_psd;
-  SCN_HIP(scn_launch_welch(a, w->num_cus, w->stream));
+  SCN_HIP(scn_launch_welch(a, w->num_cus, stream));
   return SCN_OK;
 }
 
@@ -783,12 +785,15 @@ int scn_welch_destroy(scn_welch *w) {
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   for (int i = 0; i < SCN_NUM_SLOTS; i++) {
     WelchSlot &s = w->slot[i];
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
     if (s.graph) (void)hipGraphExecDestroy(s.graph);
     if (s.h_in) (void)hipHostFree(s.h_in);
     if (s.h_psd) (void)hipHostFree(s.h_psd);
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_psd) (void)hipFree(s.d_psd);
     if (s.done) (void)hipEventDestroy(s.done);
+    if (s.d_work) (void)hipFree(s.d_work);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   if (w->d_window) (void)hipFree(w->d_window);
   if (w->d_twiddle) (void)hipFree(w->d_twiddle);
@@ -830,6 +835,8 @@ int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
   if (!s.d_psd) SCN_HIP(hipMalloc(&s.d_psd, psd_bytes));
   if (!s.h_psd) SCN_HIP(hipHostMalloc(&s.h_psd, psd_bytes, hipHostMallocDefault));
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if (!s.stream) SCN_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  if (!s.d_work) SCN_HIP(hipMalloc(&s.d_work, sizeof(float) * 2 * (size_t)w->d.n * w->d.max_psd * w->d.segments_per_psd));
   if (!s.graph || s.graph_npsd != n_psd) {
     // capture the slot's inner loop once per batch size: H2D -> columns -> rows -> D2H
     if (s.graph) {
@@ -837,13 +844,13 @@ int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
       s.graph = nullptr;
     }
     hipGraph_t graph = nullptr;
-    SCN_HIP(hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, welch_samples(w, n_psd) * 8u, hipMemcpyHostToDevice, w->stream);
+    SCN_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, welch_samples(w, n_psd) * 8u, hipMemcpyHostToDevice, s.stream);
     int inner = SCN_OK;
-    if (e == hipSuccess) inner = welch_enqueue(w, s.d_in, n_psd, s.d_psd);
+    if (e == hipSuccess) inner = welch_enqueue(w, s.d_in, n_psd, s.d_psd, s.stream, s.d_work);
     if (e == hipSuccess && inner == SCN_OK)
-      e = hipMemcpyAsync(s.h_psd, s.d_psd, sizeof(float) * (size_t)w->d.n * n_psd, hipMemcpyDeviceToHost, w->stream);
-    hipError_t e2 = hipStreamEndCapture(w->stream, &graph);
+      e = hipMemcpyAsync(s.h_psd, s.d_psd, sizeof(float) * (size_t)w->d.n * n_psd, hipMemcpyDeviceToHost, s.stream);
+    hipError_t e2 = hipStreamEndCapture(s.stream, &graph);
     if (e != hipSuccess || e2 != hipSuccess || inner != SCN_OK) {
       if (graph) (void)hipGraphDestroy(graph);
       if (inner != SCN_OK) return inner;
@@ -854,8 +861,8 @@ int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
     if (e != hipSuccess) return fail(SCN_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
     s.graph_npsd = n_psd;
   }
-  SCN_HIP(hipGraphLaunch(s.graph, w->stream));
-  SCN_HIP(hipEventRecord(s.done, w->stream));
+  SCN_HIP(hipGraphLaunch(s.graph, s.stream));
+  SCN_HIP(hipEventRecord(s.done, s.stream));
   s.pending = true;
   s.via_graph = true;
   s.n_psd = n_psd;
@@ -876,7 +883,7 @@ int scn_welch_submit_device(scn_welch *w, int slot, const void *d_samples, uint3
     d_psd_db = s.d_psd;
   }
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-  st = welch_enqueue(w, d_samples, n_psd, d_psd_db);
+  st = welch_enqueue(w, d_samples, n_psd, d_psd_db, w->stream, w->d_work);
   if (st) return st;
   SCN_HIP(hipEventRecord(s.done, w->stream));
   s.pending = true;

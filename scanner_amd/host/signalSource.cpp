@@ -5,12 +5,10 @@
 
 SignalSource::SignalSource(uint32_t sampleRate, uint32_t sampleCount, double startFrequency, double stopFrequency,
                            double useBandWidth, double dcIgnoreWidth, bool doTiming)
-    : m_doTiming(doTiming), m_elapsedTime(0), m_retuneTimeIndex(0), m_getSamplesTimeIndex(0), m_isDone(false),
-      m_finished(false), m_synchronousMode(false), m_thread(nullptr), m_retuneTime(s_maxIndex),
-      m_getSamplesTime(s_maxIndex), m_sampleRate(sampleRate), m_sampleCount(sampleCount),
-      m_startFrequency(startFrequency), m_stopFrequency(stopFrequency),
-      m_frequencyTable(sampleRate, startFrequency, stopFrequency, useBandWidth, dcIgnoreWidth),
-      m_iterationLimit(0), m_sampleQueue(nullptr) {}
+    : m_sampleRate(sampleRate), m_sampleCount(sampleCount), m_sampleQueue(nullptr), m_finished(false),
+      m_frequencyTable(sampleRate, startFrequency, stopFrequency, useBandWidth, dcIgnoreWidth), m_iterationLimit(0),
+      m_isDone(false), m_synchronousMode(false), m_thread(nullptr), m_doTiming(doTiming), m_elapsedTime(0),
+      m_retuneTimeIndex(0), m_getSamplesTimeIndex(0), m_retuneTime(s_maxIndex), m_getSamplesTime(s_maxIndex) {}
 
 SignalSource::~SignalSource() {
   if (m_thread && m_thread->joinable()) m_thread->join();

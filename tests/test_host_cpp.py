@@ -50,6 +50,15 @@ def test_host_classes_under_sanitizers(host_build, tmp_path, san):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0",
                UBSAN_OPTIONS="halt_on_error=1")
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
+    if out.returncode != 0 and "unexpected memory mapping" in out.stderr:
+        # ThreadSanitizer cannot lay out its shadow under this kernel's ASLR entropy: retry with ASLR off
+        import shutil
+        if not shutil.which("setarch"):
+            pytest.skip("ThreadSanitizer cannot run under this kernel's ASLR settings")
+        out = subprocess.run(["setarch", os.uname().machine, "-R", str(exe)], capture_output=True, text=True,
+                             timeout=300, env=env)
+        if out.returncode != 0 and ("unexpected memory mapping" in out.stderr or "setarch" in out.stderr):
+            pytest.skip("ThreadSanitizer cannot run under this kernel's ASLR settings")
     assert out.returncode == 0 and "host cpu tests ok" in out.stdout, out.stderr[-3000:]
 
 

@@ -1,7 +1,8 @@
 """ctypes binding for the CPU oracle (oracle/libscn_oracle.so) + float64 goldens.
 
-TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED: the reference has no golden
-vectors and cannot be built here (see oracle/scn_oracle.h).  Only tests/,
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED for the DSP functions: the reference has no golden
+vectors and its DSP sources cannot be built here (see oracle/scn_oracle.h); the frequency table IS
+pinned against the reference's own frequencyTable.cpp (ref_lib below, oracle/_ref).  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
 the product package scanner_amd never does.
 
@@ -53,6 +54,49 @@ def build(force=False):
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB
+
+
+_REF_LIB = os.path.join(_HERE, "_ref", "libref_frequency_table.so")
+_ref = None
+
+
+def ref_lib():
+    """The reference's own frequencyTable.cpp, compiled from /root/reference by `make -C oracle ref` (the only
+    reference source that builds in this image -- see ref_binding.cpp).  None where it has not been built."""
+    global _ref
+    if _ref is None and os.path.exists(_REF_LIB):
+        L = C.CDLL(_REF_LIB)
+        u32, dbl, vp = C.c_uint32, C.c_double, C.c_void_p
+        L.ref_frequency_table.restype = u32
+        L.ref_frequency_table.argtypes = [u32, dbl, dbl, dbl, dbl, vp, u32]
+        L.ref_frequency_walk.argtypes = [u32, dbl, dbl, dbl, dbl, u32, vp, vp, vp]
+        L.ref_frequency_start.restype = dbl
+        L.ref_frequency_start.argtypes = [u32, dbl, dbl, dbl, dbl]
+        L.ref_frequency_stop.restype = dbl
+        L.ref_frequency_stop.argtypes = [u32, dbl, dbl, dbl, dbl]
+        _ref = L
+    return _ref
+
+
+def ref_frequency_table(sample_rate, start, stop, use_bandwidth=0.75, dc_ignore_width=0.0):
+    """frequencyTable.cpp:9-37 as the reference itself computes it (prints its "Frequency i: f" lines to stdout)."""
+    L = ref_lib()
+    assert L is not None, "oracle/_ref has not been built (needs /root/reference)"
+    n = L.ref_frequency_table(int(sample_rate), start, stop, use_bandwidth, dc_ignore_width, None, 0)
+    out = np.empty(n, np.float64)
+    L.ref_frequency_table(int(sample_rate), start, stop, use_bandwidth, dc_ignore_width, _p(out), n)
+    return out
+
+
+def ref_frequency_walk(sample_rate, start, stop, use_bandwidth, dc_ignore_width, steps):
+    """(frequency, iteration count, scan-start flag) of `steps` consecutive tunes, reference code."""
+    L = ref_lib()
+    assert L is not None
+    f = np.empty(steps, np.float64)
+    it = np.empty(steps, np.uint32)
+    ss = np.empty(steps, np.uint8)
+    L.ref_frequency_walk(int(sample_rate), start, stop, use_bandwidth, dc_ignore_width, steps, _p(f), _p(it), _p(ss))
+    return f, it, ss
 
 
 _lib = None

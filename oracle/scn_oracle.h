@@ -14,6 +14,12 @@
  * which exist here, and stand-in headers are not allowed.  The oracle is
  * therefore pinned by mathematics instead: float64 DFT / window goldens
  * (numpy/scipy) and hand-derivable known answers under tests/golden/.
+ * One function IS pinned against the reference itself: frequencyTable.cpp
+ * needs only the standard library, so `make -C oracle ref` compiles it from
+ * /root/reference into oracle/_ref/ (ref_binding.cpp) and
+ * tests/test_oracle_ref.py holds scn_oracle_frequency_table, the product's
+ * scn_frequency_table and the fixture tests/golden/frequency_table_ref.npz
+ * (generated from that build) to it.
  *
  * Third-party arithmetic restated here (absent from /root/reference, no
  * version pinned by the reference -- its Makefile:10-11 links -lfftw3f -lvolk

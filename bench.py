@@ -395,8 +395,12 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
+            # counters come from their own rocprofv3 passes (scripts/prof.sh); only valid for the launch shape they
+            # were collected on
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                if (j.get("n"), j.get("sample_kind"), j.get("batch_per_gpu")) == (n, args.kind, nb):
+                    traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

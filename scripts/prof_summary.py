@@ -61,8 +61,15 @@ if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
     fetch = summary.get("FETCH_SIZE", 0) * 1024 * 2
     write = summary.get("WRITE_SIZE", 0) * 1024
     print(f"hbm_bytes_per_launch (FETCH_SIZE*1024*2 + WRITE_SIZE*1024) = {fetch + write:.4g}  (read {fetch:.4g}, write {write:.4g})")
-    json.dump({"hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write,
-               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 correction)"},
+    shape = {}
+    try:  # the launch shape the counters belong to (bench.py only reports them for the same shape)
+        cfg = json.loads(open(os.path.join(out, "bench_trace.json")).read().strip().splitlines()[-1])["config"]
+        shape = {k: cfg[k] for k in ("n", "sample_kind", "batch_per_gpu")}
+    except Exception:
+        pass
+    json.dump(dict({"hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write,
+                    "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 correction)"},
+                   **shape),
               open(os.path.join(out, "pmc_traffic.json"), "w"))
 try:
     print("bench line under trace:", open(os.path.join(out, "bench_trace.json")).read().strip()[-1400:])

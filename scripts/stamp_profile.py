@@ -8,13 +8,17 @@ sys.path.insert(0, '.')
 from scanner_amd import Plan, capi, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 flags = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+kindname = sys.argv[3] if len(sys.argv) > 3 else "cfloat"
+kind = {"cfloat": capi.KIND_FLOAT_COMPLEX, "int16": capi.KIND_SHORT_COMPLEX}[kindname]
 nb = 8192 * 4096 // n
 dev = torch.device('cuda', 0)
 R = 4
 xs = [synth.cfloat_batch_torch(n, nb, seed=2 + r, device=dev) for r in range(R)]
+if kindname == "int16":
+    xs = [torch.clamp(torch.round(x * 2047.0), -2048, 2047).to(torch.int16).contiguous() for x in xs]
 outs = [torch.empty((nb, n), dtype=torch.float32, device=dev) for r in range(R)]
 fc = 3e6 + 6e6 * np.arange(nb)
-p = Plan(n, 8000000, 10.0, max_batch=nb, max_hits=nb * 64, flags=flags)
+p = Plan(n, 8000000, 10.0, kind=kind, enob=12, max_batch=nb, max_hits=nb * 64, flags=flags)
 for k in range(12):   # pipelined like the bench; the last launch's stamps are read
     p.submit_device(k & 1, xs[k % R], nb, fc, sync_producer=False, d_power_db=outs[k % R])
     p.collect(k & 1, False, False)
@@ -36,7 +40,7 @@ for g in range(nb):
 rows = np.array(rows)
 per = rows[:, :11] / rows[:, 11:12]
 tot = per.sum(1).mean()
-print(f"n={n} flags={flags}: {len(rows)} workgroups, {rows[:,11].mean():.1f} buffers each, {tot:.0f} cycles per buffer per workgroup")
+print(f"n={n} {kindname} flags={flags}: {len(rows)} workgroups, {rows[:,11].mean():.1f} buffers each, {tot:.0f} cycles per buffer per workgroup")
 for i, nm in enumerate(names):
     print(f"  {nm:42s} {per[:, i].mean():8.0f} cyc  {100 * per[:, i].mean() / tot:5.1f} %   (p10 {np.percentile(per[:, i], 10):6.0f}  p90 {np.percentile(per[:, i], 90):6.0f})")
 

@@ -56,6 +56,10 @@ struct Slot {
   uint32_t *h_buf_hits = nullptr;
   hipEvent_t kernel_done = nullptr, staged = nullptr;
   hipStream_t stream = nullptr;     // where this slot's kernels run: the plan's compute stream, or its own (SCN_PLAN_OVERLAP_SLOTS)
+  // buffer-queue heads of the persistent workgroups (ScnFftArgs::work_counter; 8 heads, never reset) and their values
+  // before the next launch (host-tracked).  Per slot: with overlapped slots two launches pull concurrently.
+  uint32_t *d_work_counter = nullptr;
+  uint32_t work_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool own_stream = false;
   ScnDevHit *d_hits = nullptr;      // [max_batch][hit_region] per-buffer hit regions
   ScnDevHit *d_ov_hits = nullptr;   // [max_hits] overflow list (buffers with > hit_region hits)
@@ -205,8 +209,12 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.ov_base = s.ov_base;
   a.ov_cap = p->d.max_hits;
   a.per_buffer_hits = s.d_buf_hits;
+  a.work_counter = s.d_work_counter;
+  for (uint32_t x = 0; x < 8; x++) a.work_base[x] = s.work_base[x];
   const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
   SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, s.stream));
+  if (scn_kind_uses_queue((int)p->d.sample_kind))
+    for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
   if (hits && nb && s.own_stream) {
     // overlapped slots: the counts follow the kernel on the slot's own stream -- the next kernel there is two
     // submits away, and one stream less keeps both compute streams on hardware queues of their own (HIP maps
@@ -235,6 +243,7 @@ void free_slot(Slot &s) {
     (void)hipStreamSynchronize(s.stream);
     (void)hipStreamDestroy(s.stream);
   }
+  if (s.d_work_counter) (void)hipFree(s.d_work_counter);
   if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
   if (s.staged) (void)hipEventDestroy(s.staged);
   if (s.h_td) (void)hipHostFree(s.h_td);
@@ -363,6 +372,10 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
         tw1[2 * ((size_t)(pp - 1) * nthreads + t)] = tw[2 * m];
         tw1[2 * ((size_t)(pp - 1) * nthreads + t) + 1] = tw[2 * m + 1];
       }
+    for (int k = 0; k < SCN_NUM_SLOTS; k++) {
+      SCN_TRY(hipMalloc(&p->slot[k].d_work_counter, sizeof(uint32_t) * 8 * 32));
+      SCN_TRY(hipMemsetAsync(p->slot[k].d_work_counter, 0, sizeof(uint32_t) * 8 * 32, p->stream));
+    }
     SCN_TRY(hipMalloc(&p->d_tw1_table, sizeof(float) * tw1.size()));
     SCN_TRY(hipMemcpyAsync(p->d_tw1_table, tw1.data(), sizeof(float) * tw1.size(), hipMemcpyHostToDevice, p->stream));
     SCN_TRY(hipStreamSynchronize(p->stream));

@@ -44,7 +44,22 @@ struct ScnFftArgs {
   uint32_t ov_base;           // its value before this submit (host-tracked)
   uint32_t ov_cap;
   uint32_t *per_buffer_hits;  // [n_buffers] total hits of each buffer (device memory)
+  // buffer queue of the persistent workgroups: 8 heads, 32 words (one 128-byte line) apart, never reset; head x
+  // serves the buffers b = 8 j + x; work_base[x] is its value before this launch and a launch adds exactly the
+  // number of such buffers (scn_work_shard_count) to it
+  uint32_t *work_counter;
+  uint32_t work_base[8];
 };
+// which wire formats pull their buffers from the queue (the compute-bound integer ones; the float path is
+// memory-bound and measurably better off with the static assignment)
+#ifndef SCN_DYNAMIC_WORK
+#define SCN_DYNAMIC_WORK 1
+#endif
+static constexpr bool scn_kind_uses_queue(int kind) { return SCN_DYNAMIC_WORK != 0 && kind != SCN_K_FLOAT_COMPLEX; }
+// number of buffers b < n_buffers with b % 8 == shard
+static inline uint32_t scn_work_shard_count(uint32_t n_buffers, uint32_t shard) {
+  return n_buffers > shard ? (n_buffers - shard + 7u) / 8u : 0u;
+}
 
 // time-domain mode (process.cpp:203-237)
 struct ScnTdArgs {

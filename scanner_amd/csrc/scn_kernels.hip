@@ -183,6 +183,40 @@ struct RawLoader<SCN_K_SHORT> {
 #ifndef SCN_PF_SPLIT
 #define SCN_PF_SPLIT 4
 #endif
+// Work distribution over the persistent workgroups.  1 (product): every workgroup starts on buffer blockIdx.x and
+// then takes buffers from a device-scope queue, one iteration ahead so that the prefetch knows its target.
+// 0: static grid-stride assignment (buf = blockIdx.x + k*gridDim.x).  With the static form the workgroups of one
+// launch finish far apart (dispatch order, 10 or 11 buffers each, uneven speeds: 36..55 us in a 55 us int16
+// launch).  For the memory-bound float path that tail is not idle capacity (the remaining workgroups run faster:
+// measured neutral); for the compute-bound integer formats and the 8192-point kernel (8 buffers per workgroup) it is.
+// The queue is sharded 8 ways: one returning device-scope atomic saturates at ~88 per us on one word, so 8192
+// dequeues on one head would take longer than the launch (measured: 74 -> 115 us).  Workgroups land on XCD
+// blockIdx.x % 8, so a shard is pulled by one XCD; shard x owns the buffers b = 8 j + x.  The launcher never
+// starts more workgroups than buffers, so workgroup g takes buffer g statically (shard g % 8, j = g / 8) and
+// head x hands out j = j0, j0 + 1, ... with j0 = the number of workgroups in shard x.  Heads are never reset:
+// work_base[x] is head x's value before the launch (host-tracked; a launch adds exactly the number of buffers of
+// shard x, because every workgroup stops at its first index past the end).
+// Measured per wire format (one box, single stream, us per launch static -> queue): int16 4096-pt 64.1 -> 61.2,
+// int8 63.9 -> 59.4, 8192-pt int16 98.5 -> 89.9, float 4096-pt 76.1 -> 77.0, 8192-pt float 83.8 -> 85.8: the
+// queue is compiled in for the integer formats only (scn_kind_uses_queue, scn_kernels.h).
+#ifndef SCN_DYNAMIC_WORK
+#define SCN_DYNAMIC_WORK 1
+#endif
+// The dequeue must stay ONE plain global_atomic_add whose result is collected an iteration later.  LLVM's AMDGPU
+// atomic optimizer rewrites any atomic with a provably uniform address into a wave reduction followed at once
+// by s_waitcnt vmcnt(0) + readfirstlane (wave 0 then sits out the atomic's ~3 us round trip on every buffer:
+// 74 -> 116 us), so the address gets an opaque per-lane zero offset.  (Switching the pass off globally,
+// -amdgpu-atomic-optimizer-strategy=None, is not an option: it is what aggregates the hit path's overflow
+// atomics per wave -- without it the int16 C3-shaped launch went from 64 to 97 us.)
+#define SCN_WORK_QUEUE_SETUP()                                                                         \
+  const uint32_t wq_shard = blockIdx.x & 7u;                                                           \
+  uint32_t *const wq_head = args.work_counter + 32u * wq_shard; /* one 128-byte line per head */       \
+  const uint32_t wq_base = args.work_base[wq_shard];                                                   \
+  const uint32_t wq_j0 = (gridDim.x - wq_shard + 7u) >> 3;                                             \
+  uint32_t wq_zero;                                                                                    \
+  asm("v_mov_b32 %0, 0" : "=v"(wq_zero));                                                              \
+  auto wq_take = [&]() -> uint32_t { return atomicAdd(wq_head + wq_zero, 1u); };                       \
+  auto wq_buffer = [&](uint32_t taken) -> uint32_t { return 8u * (wq_j0 + (taken - wq_base)) + wq_shard; }
 
 #if SCN_STAMPS
 #define SCN_STAMP(i)                                             \
@@ -225,6 +259,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
   constexpr bool PF = G::PREFETCH;
+  constexpr bool DYN = scn_kind_uses_queue(KIND);
   constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -232,7 +267,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   v2f *lds_tw2 = lds + G::EXCH;                              // [16][M]
   int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T);      // [16] DC-sum scratch (re[8], im[8])
   int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
-  int *lds_hist = lds_hits + 2;                             // [64] finished per-buffer counts awaiting the flush
+  uint32_t *lds_next = reinterpret_cast<uint32_t *>(lds_hits + 2);  // [1] the buffer this workgroup takes after the next one
 
 #if SCN_STAMPS
   const uint32_t stamp_entry = (uint32_t)wall_clock64();  // first instruction of the workgroup
@@ -264,7 +299,11 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t] * args.scale;
   // pass-2 twiddles W_{16M}^(c*q) = W_N^(16 c q), table [q][c] shared by the workgroup
   lds_tw2[t] = args.twiddle[(16 * p2 * c2) & (N - 1)];
-  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
+  SCN_WORK_QUEUE_SETUP();
+  if (t == 0) {
+    lds_hits[0] = lds_hits[1] = 0;
+    lds_next[0] = DYN ? wq_buffer(wq_take()) : blockIdx.x + gridDim.x;
+  }
   __syncthreads();
 
   v2f *w1 = lds + t;                      // + p*P1
@@ -288,13 +327,8 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       keepmask |= keep ? (1u << o) : 0u;
     }
   }
-  uint32_t par = 0;        // which of the two LDS hit counters the buffer in flight uses
-  uint32_t n_done = 0;     // buffers of this workgroup whose recorders have been started
-  // Per-buffer hit counts (device memory; the host copies them back on its own stream) are parked
-  // in LDS and flushed by wave 0, up to 64 per store instruction.
-  auto flush_counts = [&](uint32_t first_k, uint32_t count) {
-    if (t < count) args.per_buffer_hits[blockIdx.x + (first_k + t) * gridDim.x] = (uint32_t)lds_hist[t];
-  };
+  uint32_t par = 0;             // which of the two LDS hit counters the buffer in flight uses
+  uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running (none yet)
 
   // output o of this thread is bin j = jbase + joff(o):  M <= 16: o = u*M + r, j = t + T*u + 256*r;  M == 32: o = r', j = kl + 4096*e + 256*r'
   auto joff_of = [](int o) -> uint32_t { return (M == 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M); };
@@ -305,8 +339,11 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   uint32_t stamp_hw;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(stamp_hw));
 #endif
-  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
+  uint32_t buf = blockIdx.x;
+  uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
+  while (buf < args.n_buffers) {
     SCN_STAMP(0);  // previous buffer's hit recording + loop back
+    const bool more = nxt < args.n_buffers;
     // ---- K1 + K2: load, convert, window ----
     if (!PF) {
       __amdgpu_buffer_rsrc_t rin =
@@ -347,15 +384,19 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #pragma unroll
     for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, 1.0f) * win[a];
     SCN_STAMP(1);  // wait for this buffer's samples (+ convert, window)
+    // Take the buffer after the next one; the answer is only needed at the end of this iteration.  Issued here,
+    // behind the convert: a grab ahead of it sits in a divergent branch and the merged wait count then makes
+    // wave 0 sit out the atomic's round trip where it waits for the samples.
+    uint32_t taken = 0;
+    if (DYN && t == 0 && more) taken = wq_take();
     // The raw registers are free again: fetch the next buffer of this workgroup while this one is
     // transformed.  Branch-free (past the last buffer the descriptor has zero records: the loads return
     // zeros without touching memory), so every load sits in the same basic block as the butterflies and
     // can be issued between them: a burst of 16 loads stalls the wave at issue for ~1600 cycles when the
     // memory pipeline is backed up (profiles/r01_floors.md, stamp profile), spread out they do not.
-    const uint32_t nxt = buf + gridDim.x;
     const __amdgpu_buffer_rsrc_t rn =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(nxt < args.n_buffers ? nxt : buf) * L::kBufBytes(N),
-                  (nxt < args.n_buffers && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N),
+                  (more && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
     auto prefetch = [&](int a_lo, int a_hi) {
 #pragma unroll
       for (int a = 0; a < 16; a++)
@@ -384,13 +425,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     SCN_STAMP(4);  // barrier 1
     if (HITS) {
       // every wave has passed the barrier above, so the previous buffer's recorders are done
-      if (wave == 0 && n_done) {
-        const uint32_t k = n_done - 1;  // index (within this workgroup) of the buffer just completed
-        if (t == 0) {
-          lds_hist[k & 63u] = lds_hits[par ^ 1];
-          lds_hits[par ^ 1] = 0;
-        }
-        if ((k & 63u) == 63u) flush_counts(k - 63u, 64u);  // same wave: LDS program order suffices
+      if (t == 0 && prev != 0xffffffffu) {
+        args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        lds_hits[par ^ 1] = 0;
       }
     }
 
@@ -466,8 +503,10 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       if (HITS) dmax = fmaxf(dmax, d);
     }
     SCN_STAMP(9);  // exchange-2 reads + pass 3 + dB + stores issued
-    __syncthreads();  // exchange area free again
+    if (t == 0) lds_next[0] = !more ? 0xffffffffu : DYN ? wq_buffer(taken) : nxt + gridDim.x;
+    __syncthreads();  // exchange area free again; lds_next visible (it is rewritten three barriers from now)
     SCN_STAMP(10);  // barrier 4
+    const uint32_t after = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
 #if SCN_STAMPS
     stamp_acc[11] += 1;
 #endif
@@ -507,9 +546,11 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
           }
         }
       }
-      n_done++;
+      prev = buf;
       par ^= 1;
     }
+    buf = nxt;
+    nxt = after;
   }
 #if SCN_STAMPS
   if (t == 0 && blockIdx.x < args.n_buffers && args.power_db) {
@@ -526,11 +567,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #endif
   if (HITS) {
     __syncthreads();  // last buffer's recorders done
-    if (wave == 0 && n_done) {
-      const uint32_t k = n_done - 1;
-      if (t == 0) lds_hist[k & 63u] = lds_hits[par ^ 1];
-      flush_counts(k & ~63u, (k & 63u) + 1u);
-    }
+    if (t == 0 && prev != 0xffffffffu) args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
   }
 }
 
@@ -567,12 +604,14 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
   constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
+  constexpr bool DYN = scn_kind_uses_queue(KIND);
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
   v2f *lds_tw2 = lds + G::EXCH;                              // [16][32]: W_512^(c q) at q*32 + c
   int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + 512);    // [16] DC-sum scratch (re[8], im[8])
   int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
+  uint32_t *lds_next = reinterpret_cast<uint32_t *>(lds_hits + 2);  // [1] the buffer this workgroup takes after the next one
 
   const uint32_t t = threadIdx.x;
   const uint32_t lane = t & 63, wave = t >> 6;
@@ -599,7 +638,11 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   // pass-2 twiddles W_512^(c q) = W_N^(16 c q), entry q*32 + c: this thread fills entries t and t + 256
   lds_tw2[t] = args.twiddle[(16u * p2 * c2) & (N - 1)];
   lds_tw2[t + 256] = args.twiddle[(16u * (p2 + 8u) * c2) & (N - 1)];
-  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
+  SCN_WORK_QUEUE_SETUP();
+  if (t == 0) {
+    lds_hits[0] = lds_hits[1] = 0;
+    lds_next[0] = DYN ? wq_buffer(wq_take()) : blockIdx.x + gridDim.x;
+  }
   __syncthreads();
 
   v2f *w1 = lds + t;                       // + p*P1 (+256 for the second virtual thread)
@@ -622,7 +665,10 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   uint32_t par = 0;
   uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running
 
-  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
+  uint32_t buf = blockIdx.x;
+  uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
+  while (buf < args.n_buffers) {
+    const bool more = nxt < args.n_buffers;
     // ---- K1 + K2 ----
     int dc_re = 0, dc_im = 0;
     if (DC) {
@@ -652,11 +698,13 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       va[a] = L::conv(raw[2 * a], dc_re, dc_im, 1.0f) * win[2 * a];
       vb[a] = L::conv(raw[2 * a + 1], dc_re, dc_im, 1.0f) * win[2 * a + 1];
     }
+    // take the buffer after the next one (behind the convert, see scn_fft_kernel); needed at the end of the iteration
+    uint32_t taken = 0;
+    if (DYN && t == 0 && more) taken = wq_take();
     // next buffer of this workgroup, branch-free (zero records past the end), in three groups
-    const uint32_t nxt = buf + gridDim.x;
     const __amdgpu_buffer_rsrc_t rn =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(nxt < args.n_buffers ? nxt : buf) * L::kBufBytes(N),
-                  (nxt < args.n_buffers && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N),
+                  (more && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
     auto prefetch = [&](int a_lo, int a_hi) {
 #pragma unroll
       for (int a = 0; a < 32; a++)
@@ -740,7 +788,9 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), rout, st_voff, 1024u * (r + 16), AUX_ST);
       if (HITS) dmax = fmaxf(dmax, fmaxf(d0, d1));
     }
-    __syncthreads();  // exchange area free again
+    if (t == 0) lds_next[0] = !more ? 0xffffffffu : DYN ? wq_buffer(taken) : nxt + gridDim.x;
+    __syncthreads();  // exchange area free again; lds_next visible
+    const uint32_t after = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
     if (HITS) {
       if (__ballot(dmax > args.threshold)) {
         uint32_t hitmask = 0;
@@ -775,6 +825,8 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       prev = buf;
       par ^= 1;
     }
+    buf = nxt;
+    nxt = after;
   }
   if (HITS) {
     __syncthreads();  // last buffer's recorders done

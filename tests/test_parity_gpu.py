@@ -123,13 +123,14 @@ def test_pinned_double_buffered_submit(torch_cuda, oracle_mod):
 
 @pytest.mark.parametrize("n,kind,enob,path", [(4096, capi.KIND_FLOAT_COMPLEX, 12, "device"),
                                               (8192, capi.KIND_SHORT_COMPLEX, 12, "device"),
+                                              (4096, capi.KIND_SHORT_COMPLEX, 12, "device"),
                                               (4096, capi.KIND_FLOAT_COMPLEX, 12, "pinned")])
 def test_overlapped_slots_give_identical_results(torch_cuda, n, kind, enob, path):
     """SCN_PLAN_OVERLAP_SLOTS puts the two slots on streams of their own so that consecutive launches
     overlap; the slots share nothing but read-only tables, so every spectrum bit and every hit must equal
     what the single-stream plan produces, in a pipeline that keeps both slots in flight."""
     torch = torch_cuda
-    nb, rounds = 700, 6     # > one resident wave of workgroups for 8192-pt, several launches in flight
+    nb, rounds = 900, 6     # > one resident wave of workgroups (768 / 512): the integer kinds pull from the buffer queue
     raws = []
     for k in range(rounds):
         x = synth.cfloat_batch(n, nb, seed=300 + k)
@@ -169,6 +170,46 @@ def test_overlapped_slots_give_identical_results(torch_cuda, n, kind, enob, path
         assert h0.tobytes() == h1.tobytes() and np.array_equal(t0, t1)      # identical hit records, order, trigger flags
         total += len(h0)
     assert total > 100
+
+
+@pytest.mark.parametrize("n,kind,enob,dc", [(4096, capi.KIND_SHORT_COMPLEX, 12, False), (4096, capi.KIND_BYTE_COMPLEX, 8, False),
+                                            (1024, capi.KIND_SHORT, 12, True), (8192, capi.KIND_BYTE_COMPLEX, 8, False)])
+def test_buffer_queue_over_many_launches(torch_cuda, oracle_mod, n, kind, enob, dc):
+    """The integer formats' workgroups take their buffers from a device-side queue whose heads are never reset
+    (the host tracks their base per slot).  Batches larger than one resident wave of workgroups, of changing
+    size, on both slots, many launches in a row: every buffer of every launch must be processed exactly once --
+    spectra and hit lists against the oracle."""
+    torch = torch_cuda
+    sizes = [1800, 2047, 769, 5, 1500, 3000, 1, 2500]
+    rng_seed = 900
+    with Plan(n, FS, 9.5, kind=kind, enob=enob, correct_dc=dc, max_batch=max(sizes), max_hits=1 << 19) as plan:
+        o = oracle_mod.Oracle(n, FS, 9.5, kind=kind, enob=enob, correct_dc=dc)
+        pending = {}
+        for k, nb in enumerate(sizes):
+            s = k & 1
+            if s in pending:
+                _check_launch(plan, o, n, s, *pending.pop(s))
+            raw = synth.quantize(synth.cfloat_batch(n, nb, seed=rng_seed + k), kind)
+            if dc:  # a positive offset: the integer mean is then an ordinary small number (the negative-sum quirk of
+                raw = (raw + 37).astype(raw.dtype)   # utility.cpp:77-78 has its own test, test_dc_quirk_negative_mean)
+            fc = 100e6 + 6e6 * np.arange(nb) + k
+            seq = np.arange(1000 * k, 1000 * k + nb, dtype=np.uint64)
+            plan.submit_device(s, _to_dev(torch, raw), nb, fc, seq)
+            pending[s] = (raw, fc, seq)
+        for s in sorted(pending):
+            _check_launch(plan, o, n, s, *pending[s])
+
+
+def _check_launch(plan, o, n, slot, raw, fc, seq):
+    p, h, t = plan.collect(slot, hit_cap=1 << 19)
+    p_ref, h_ref, t_ref = o.run(raw, fc, seq, threads=8)
+    tol.compare_spectra(p, p_ref)
+    near = np.abs(p_ref[:, tol.evaluated_mask(n)] - 9.5) < tol.GUARD_DB
+    if not near.any():
+        _assert_hits_equal(h, h_ref)
+        assert np.array_equal(t, t_ref)
+    else:   # a bin on the threshold somewhere: counts must still agree away from it
+        assert abs(len(h) - len(h_ref)) <= int(near.sum())
 
 
 # ---------------------------------------------------------------------------------------

@@ -68,6 +68,7 @@ def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s):
     from oracle import oracle as O
 
     O.build()
+    O.set_fft_mode(False)  # the float radix-2 FFT: FFTW computes in float too; the double-internal mode is for parity
     n = args.n
     o = O.Oracle(n, FS, args.threshold, kind=kind_oracle, enob=enob)
     ncores = os.cpu_count() or 1

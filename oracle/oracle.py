@@ -130,6 +130,8 @@ def lib():
         L.scn_oracle_run_batch.argtypes = [
             C.POINTER(Params), C.c_int, u32, C.c_int, vp, u32, vp, vp, vp, vp, C.c_uint64, vp, u32]
         L.scn_oracle_welch.argtypes = [vp, u32, u32, u32, vp]
+        L.scn_oracle_set_fft_mode.argtypes = [C.c_int]
+        L.scn_oracle_get_fft_mode.restype = C.c_int
         L.scn_oracle_hackrf_interpolate.restype = C.c_double
         L.scn_oracle_hackrf_interpolate.argtypes = [vp, u32, u32, C.POINTER(u32)]
         _lib = L
@@ -241,6 +243,12 @@ def frequency_table(sample_rate, start, stop, use_bandwidth=0.75, dc_ignore_widt
     out = np.empty(cnt, np.float64)
     L.scn_oracle_frequency_table(sample_rate, start, stop, use_bandwidth, dc_ignore_width, _p(out), cnt)
     return out
+
+
+def set_fft_mode(accurate):
+    """True (default): double-internal FFT rounded to float (FFTW's accuracy class, the parity reference);
+    False: textbook float radix-2 (the timed cpu_baseline, a second opinion)."""
+    lib().scn_oracle_set_fft_mode(1 if accurate else 0)
 
 
 def hackrf_interpolate(transfer_u8, scan_offset=0):

@@ -83,6 +83,11 @@ void scn_oracle_window_apply(float *samples /*[n][2]*/, const float *w,
 typedef struct scn_oracle_fft scn_oracle_fft;
 scn_oracle_fft *scn_oracle_fft_create(uint32_t n);
 void scn_oracle_fft_destroy(scn_oracle_fft *f);
+/* Arithmetic of the transform: 1 (default) double twiddles + double accumulation, rounded to float once --
+ * the stand-in for FFTW's accuracy class that parity is judged against; 0 a textbook radix-2 FFT in float
+ * (what bench.py's cpu_baseline times, and a second opinion in the tests).  See scn_oracle.c. */
+void scn_oracle_set_fft_mode(int accurate);
+int scn_oracle_get_fft_mode(void);
 /* memcpy in -> execute -> memcpy out, as fft.cpp:22-24 */
 void scn_oracle_fft_process(scn_oracle_fft *f, float *dest, const float *src);
 

@@ -191,3 +191,28 @@ def test_frequency_table(oracle_mod):
     t2 = oracle_mod.frequency_table(8000000, 88e6, 108e6)
     assert np.all(t2 < 108e6) and t2[-1] + 6e6 >= 108e6
     assert len(t2) == int(np.ceil((108e6 - t2[0]) / 6e6))              # the assert of frequencyTable.cpp:29
+
+
+def test_fft_modes_bracket_the_float64_transform(oracle_mod):
+    """The oracle's default FFT arithmetic (double-internal, rounded once: the FFTW-accuracy stand-in) and its
+    textbook float radix-2 mode (what bench.py times) are two evaluations of the same DFT: both within the parity
+    bar of the float64 transform, the default one essentially exact."""
+    import numpy as np
+    from scanner_amd import synth
+    from tests import tolerances as tol
+
+    n, nb = 8192, 24
+    x = synth.cfloat_batch(n, nb, seed=77)
+    o = oracle_mod.Oracle(n, 8000000, 10.0)
+    _, P64, _ = oracle_mod.ref64_spectrum(x, o.window())
+    mean = P64.mean(axis=-1, keepdims=True)
+    errs = {}
+    try:
+        for accurate in (True, False):
+            oracle_mod.set_fft_mode(accurate)
+            p, _, _ = o.run(x, want_hits=False)
+            errs[accurate] = float((np.abs(tol.db_to_power(p) - P64) / np.maximum(P64, mean)).max())
+    finally:
+        oracle_mod.set_fft_mode(True)
+    assert errs[True] < 1e-6 and errs[False] < tol.REL_POWER, errs
+    assert errs[True] < errs[False]

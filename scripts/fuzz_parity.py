@@ -11,12 +11,7 @@ from scanner_amd import Plan, capi, synth
 from oracle import oracle as O
 from tests import tolerances as tol
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
 FS = 8000000
-t_end = time.time() + budget
-cases = launches = 0
 kinds = [capi.KIND_FLOAT_COMPLEX, capi.KIND_SHORT_COMPLEX, capi.KIND_SHORT, capi.KIND_BYTE_COMPLEX]
 
 
@@ -24,77 +19,89 @@ def dev(raw):
     return torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).cuda()
 
 
-while time.time() < t_end:
-    n = int(rng.choice([1024, 2048, 4096, 8192]))
-    kind = int(rng.choice(kinds))
-    enob = 8 if kind == capi.KIND_BYTE_COMPLEX else int(rng.choice([12, 12, 14, 16, 10]))
-    dc = bool(rng.integers(0, 2)) and kind != capi.KIND_FLOAT_COMPLEX
-    thr = float(rng.choice([6.0, 9.5, 12.0, 20.0, -5.0]))
-    out_flags = int(rng.choice([3, 3, 1, 2]))
-    flags = out_flags | (capi.PLAN_OVERLAP_SLOTS if rng.integers(0, 2) else 0)
-    max_nb = int(rng.choice([3, 64, 700, 1300, 2600])) if n <= 4096 else int(rng.choice([3, 64, 600, 1100]))
-    region_scale = int(rng.choice([1, 64, 64, 400]))   # small max_hits -> small hit regions -> overflow path
-    max_hits = max(64, max_nb * region_scale)
-    nl = int(rng.integers(1, 6))
-    o = O.Oracle(n, FS, thr, kind=kind, enob=enob, correct_dc=dc)
-    desc = f"n={n} kind={kind} enob={enob} dc={dc} thr={thr} flags={flags} max_nb={max_nb} max_hits={max_hits}"
-    try:
-        with Plan(n, FS, thr, kind=kind, enob=enob, correct_dc=dc, max_batch=max_nb, max_hits=max_hits, flags=flags) as plan:
-            pend = {}
+def run(budget, seed):
+    """Returns (plans, launches); raises on the first discrepancy (the failing case is printed to stderr)."""
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    cases = launches = 0
+    while time.time() < t_end:
+        n = int(rng.choice([1024, 2048, 4096, 8192]))
+        kind = int(rng.choice(kinds))
+        enob = 8 if kind == capi.KIND_BYTE_COMPLEX else int(rng.choice([12, 12, 14, 16, 10]))
+        dc = bool(rng.integers(0, 2)) and kind != capi.KIND_FLOAT_COMPLEX
+        thr = float(rng.choice([6.0, 9.5, 12.0, 20.0, -5.0]))
+        out_flags = int(rng.choice([3, 3, 1, 2]))
+        flags = out_flags | (capi.PLAN_OVERLAP_SLOTS if rng.integers(0, 2) else 0)
+        max_nb = int(rng.choice([3, 64, 700, 1300, 2600])) if n <= 4096 else int(rng.choice([3, 64, 600, 1100]))
+        region_scale = int(rng.choice([1, 64, 64, 400]))   # small max_hits -> small hit regions -> overflow path
+        max_hits = max(64, max_nb * region_scale)
+        nl = int(rng.integers(1, 6))
+        o = O.Oracle(n, FS, thr, kind=kind, enob=enob, correct_dc=dc)
+        desc = f"n={n} kind={kind} enob={enob} dc={dc} thr={thr} flags={flags} max_nb={max_nb} max_hits={max_hits}"
+        try:
+            with Plan(n, FS, thr, kind=kind, enob=enob, correct_dc=dc, max_batch=max_nb, max_hits=max_hits, flags=flags) as plan:
+                pend = {}
 
-            def check(slot, raw, fc, seq, nb):
-                want_p, want_h = bool(out_flags & 1), bool(out_flags & 2)
-                try:
-                    p, h, t = plan.collect(slot, want_power=want_p, want_hits=want_h, hit_cap=nb * n + 1)
-                    truncated = False
-                except capi.ScannerError as e:
-                    if e.status != capi.E_TRUNCATED:
-                        raise
-                    truncated = True
-                    p = h = t = None
-                p_ref, h_ref, t_ref = o.run(raw, fc, seq, threads=8)
-                if truncated:       # device overflow capacity (max_hits) exceeded: must really be that many hits
-                    assert len(h_ref) > max_hits, (len(h_ref), max_hits)
-                    return
-                if want_p and nb:
-                    tol.compare_spectra(p, p_ref)
-                if want_h and nb:
-                    # bit-exact wherever the spectrum tolerance itself cannot move a bin across the threshold
-                    unsafe = tol.flip_unsafe(p_ref, thr) & tol.evaluated_mask(n)[None, :]
-                    if not unsafe.any():
-                        assert len(h) == len(h_ref), (len(h), len(h_ref))
-                        for f in ("seq_id", "i", "freq_hz"):
-                            assert np.array_equal(h[f], h_ref[f]), f
-                        assert np.array_equal(t, t_ref)
-                    else:
-                        seq0 = int(seq[0])
-                        a = set(zip((h["seq_id"] - seq0).tolist(), h["i"].tolist()))
-                        b = set(zip((h_ref["seq_id"] - seq0).tolist(), h_ref["i"].tolist()))
-                        for bufi, i in a ^ b:
-                            assert unsafe[bufi, (i + n // 2) % n], ("hit mismatch on a safe bin", bufi, i, float(p_ref[bufi, (i + n // 2) % n]), thr)
-                        same = np.array([k for k in range(len(h)) if (int(h["seq_id"][k]) - seq0, int(h["i"][k])) in b], dtype=int)
-                        if len(same):   # the common records carry the right frequency
-                            ref_map = {(int(r["seq_id"]) - seq0, int(r["i"])): int(r["freq_hz"]) for r in h_ref}
-                            assert all(ref_map[(int(h["seq_id"][k]) - seq0, int(h["i"][k]))] == int(h["freq_hz"][k]) for k in same[:2000])
+                def check(slot, raw, fc, seq, nb):
+                    want_p, want_h = bool(out_flags & 1), bool(out_flags & 2)
+                    try:
+                        p, h, t = plan.collect(slot, want_power=want_p, want_hits=want_h, hit_cap=nb * n + 1)
+                        truncated = False
+                    except capi.ScannerError as e:
+                        if e.status != capi.E_TRUNCATED:
+                            raise
+                        truncated = True
+                        p = h = t = None
+                    p_ref, h_ref, t_ref = o.run(raw, fc, seq, threads=8)
+                    if truncated:       # device overflow capacity (max_hits) exceeded: must really be that many hits
+                        assert len(h_ref) > max_hits, (len(h_ref), max_hits)
+                        return
+                    if want_p and nb:
+                        tol.compare_spectra(p, p_ref)
+                    if want_h and nb:
+                        # bit-exact wherever the spectrum tolerance itself cannot move a bin across the threshold
+                        unsafe = tol.flip_unsafe(p_ref, thr) & tol.evaluated_mask(n)[None, :]
+                        if not unsafe.any():
+                            assert len(h) == len(h_ref), (len(h), len(h_ref))
+                            for f in ("seq_id", "i", "freq_hz"):
+                                assert np.array_equal(h[f], h_ref[f]), f
+                            assert np.array_equal(t, t_ref)
+                        else:
+                            seq0 = int(seq[0])
+                            a = set(zip((h["seq_id"] - seq0).tolist(), h["i"].tolist()))
+                            b = set(zip((h_ref["seq_id"] - seq0).tolist(), h_ref["i"].tolist()))
+                            for bufi, i in a ^ b:
+                                assert unsafe[bufi, (i + n // 2) % n], ("hit mismatch on a safe bin", bufi, i, float(p_ref[bufi, (i + n // 2) % n]), thr)
+                            same = np.array([k for k in range(len(h)) if (int(h["seq_id"][k]) - seq0, int(h["i"][k])) in b], dtype=int)
+                            if len(same):   # the common records carry the right frequency
+                                ref_map = {(int(r["seq_id"]) - seq0, int(r["i"])): int(r["freq_hz"]) for r in h_ref}
+                                assert all(ref_map[(int(h["seq_id"][k]) - seq0, int(h["i"][k]))] == int(h["freq_hz"][k]) for k in same[:2000])
 
-            for k in range(nl):
-                s = int(rng.integers(0, 2))
-                if s in pend:
-                    check(s, *pend.pop(s))
-                nb = int(rng.integers(0, max_nb + 1))
-                x = synth.cfloat_batch(n, max(nb, 1), seed=int(rng.integers(1 << 30)))[:nb]
-                raw = synth.quantize(x, kind)
-                if dc:
-                    raw = (raw + int(rng.integers(1, 60))).astype(raw.dtype)   # positive mean (the negative-sum quirk has its own test)
-                fc = 50e6 + 6e6 * np.arange(nb) + float(rng.integers(0, 1000))
-                seq = (np.arange(nb) + int(rng.integers(0, 1 << 40))).astype(np.uint64)
-                plan.submit_device(s, dev(raw) if nb else torch.zeros(8, dtype=torch.uint8, device="cuda"), nb, fc, seq)
-                pend[s] = (raw, fc, seq, nb)
-                launches += 1
-            for s in sorted(pend):
-                check(s, *pend[s])
-    except Exception:
-        print("FAILED CASE:", desc, file=sys.stderr)
-        raise
-    cases += 1
-print(f"fuzz ok: {cases} plans, {launches} launches in {budget:.0f} s (seed {seed})")
+                for k in range(nl):
+                    s = int(rng.integers(0, 2))
+                    if s in pend:
+                        check(s, *pend.pop(s))
+                    nb = int(rng.integers(0, max_nb + 1))
+                    x = synth.cfloat_batch(n, max(nb, 1), seed=int(rng.integers(1 << 30)))[:nb]
+                    raw = synth.quantize(x, kind)
+                    if dc:
+                        raw = (raw + int(rng.integers(1, 60))).astype(raw.dtype)   # positive mean (the negative-sum quirk has its own test)
+                    fc = 50e6 + 6e6 * np.arange(nb) + float(rng.integers(0, 1000))
+                    seq = (np.arange(nb) + int(rng.integers(0, 1 << 40))).astype(np.uint64)
+                    plan.submit_device(s, dev(raw) if nb else torch.zeros(8, dtype=torch.uint8, device="cuda"), nb, fc, seq)
+                    pend[s] = (raw, fc, seq, nb)
+                    launches += 1
+                for s in sorted(pend):
+                    check(s, *pend[s])
+        except Exception:
+            print("FAILED CASE:", desc, file=sys.stderr)
+            raise
+        cases += 1
+    return cases, launches
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    cases, launches = run(budget, seed)
+    print(f"fuzz ok: {cases} plans, {launches} launches in {budget:.0f} s (seed {seed})")

@@ -1,0 +1,19 @@
+"""A short, seeded slice of scripts/fuzz_parity.py in the regular GPU suite: random sizes, wire formats, ENOB, DC,
+thresholds, output flags, overlapped slots and batch sizes over both slots, every launch checked against the oracle
+(spectra to the parity bar, hit lists exact wherever the bar itself cannot flip a bin).  Longer runs: the script."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+def test_seeded_fuzz_slice(built_lib, oracle_mod, seed):
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "scripts", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    plans, launches = fuzz.run(12.0, seed)
+    assert plans >= 5 and launches >= plans

@@ -526,6 +526,16 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
           uint32_t base = 0;
           if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
           base = __builtin_amdgcn_readfirstlane(base);
+          // This wave's records take the buffer's slots [base, base + total); those at or past hit_region go to
+          // the overflow list, reserved with ONE device-scope atomic per wave (one per overflowing output index
+          // made a hit-dense int16 launch -- 17 k overflow records -- 15-20 us slower: a single counter takes ~88
+          // returning atomics per us).
+          const uint32_t ov_from = base > args.hit_region ? base : args.hit_region;  // first overflowing slot of this wave
+          uint32_t ov_first = 0;
+          if (base + total > ov_from) {
+            if (lane == 0) ov_first = atomicAdd(args.ov_counter, base + total - ov_from);
+            ov_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ov_first) - args.ov_base;
+          }
           while (wm) {
             const int o = __builtin_ctz(wm);  // wave-uniform
             wm &= wm - 1u;
@@ -537,8 +547,8 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
               const ScnDevHit rec = ScnDevHit{buf, (jbase + joff) ^ (N / 2), db[o], 0u};
               if (pos < args.hit_region) {
                 args.hits[(size_t)buf * args.hit_region + pos] = rec;
-              } else {  // region full: spill through the device-scope counter
-                uint32_t opos = atomicAdd(args.ov_counter, 1u) - args.ov_base;
+              } else {  // region full: this wave's reserved part of the overflow list
+                const uint32_t opos = ov_first + (pos - ov_from);
                 if (opos < args.ov_cap) args.ov_hits[opos] = rec;
               }
             }
@@ -803,6 +813,14 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
           uint32_t base = 0;
           if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
           base = __builtin_amdgcn_readfirstlane(base);
+          // slots [base, base + total) of the buffer; the part past hit_region is reserved in the overflow list with
+          // one device-scope atomic per wave (see scn_fft_kernel)
+          const uint32_t ov_from = base > args.hit_region ? base : args.hit_region;
+          uint32_t ov_first = 0;
+          if (base + total > ov_from) {
+            if (lane == 0) ov_first = atomicAdd(args.ov_counter, base + total - ov_from);
+            ov_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ov_first) - args.ov_base;
+          }
           while (wm) {
             const int r = __builtin_ctz(wm);  // wave-uniform
             wm &= wm - 1u;
@@ -814,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
               if (pos < args.hit_region) {
                 args.hits[(size_t)buf * args.hit_region + pos] = rec;
               } else {
-                uint32_t opos = atomicAdd(args.ov_counter, 1u) - args.ov_base;
+                const uint32_t opos = ov_first + (pos - ov_from);
                 if (opos < args.ov_cap) args.ov_hits[opos] = rec;
               }
             }

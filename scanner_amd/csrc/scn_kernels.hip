@@ -1056,7 +1056,11 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFft
     case 1024: return launch_size<4>(kind, dc, hits, args, num_cus, stream);
     case 2048: return launch_size<8>(kind, dc, hits, args, num_cus, stream);
     case 4096: return launch_size<16>(kind, dc, hits, args, num_cus, stream);
-    case 8192: return SCN_WIDE_8192 ? launch_8k(kind, dc, hits, args, num_cus, stream) : launch_size<32>(kind, dc, hits, args, num_cus, stream);
+#if SCN_WIDE_8192
+    case 8192: return launch_8k(kind, dc, hits, args, num_cus, stream);
+#else
+    case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream);  // the 512-thread form (variant build)
+#endif
     default: return hipErrorInvalidValue;
   }
 }

@@ -213,7 +213,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   for (uint32_t x = 0; x < 8; x++) a.work_base[x] = s.work_base[x];
   const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
   SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, s.stream));
-  if (scn_kind_uses_queue((int)p->d.sample_kind))
+  if (scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
   if (hits && nb && s.own_stream) {
     // overlapped slots: the counts follow the kernel on the slot's own stream -- the next kernel there is two

@@ -198,7 +198,7 @@ struct RawLoader<SCN_K_SHORT> {
 // shard x, because every workgroup stops at its first index past the end).
 // Measured per wire format (one box, single stream, us per launch static -> queue): int16 4096-pt 64.1 -> 61.2,
 // int8 63.9 -> 59.4, 8192-pt int16 98.5 -> 89.9, float 4096-pt 76.1 -> 77.0, 8192-pt float 83.8 -> 85.8: the
-// queue is compiled in for the integer formats only (scn_kind_uses_queue, scn_kernels.h).
+// queue is compiled in for the integer formats from 4096 points up (scn_uses_queue, scn_kernels.h).
 #ifndef SCN_DYNAMIC_WORK
 #define SCN_DYNAMIC_WORK 1
 #endif
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
   constexpr bool PF = G::PREFETCH;
-  constexpr bool DYN = scn_kind_uses_queue(KIND);
+  constexpr bool DYN = scn_uses_queue(KIND, G::N);
   constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
   constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
-  constexpr bool DYN = scn_kind_uses_queue(KIND);
+  constexpr bool DYN = scn_uses_queue(KIND, N);
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);

@@ -34,11 +34,11 @@ for n in (1024, 2048, 4096, 8192):
                 res = []
                 for rnd in range(3):
                     pend = [False, False]
-                    for k in range(6):
+                    for k in range(40):
                         p.submit_device(k & 1, xs[k % 3], nb, fc, sync_producer=False); coll(k & 1)
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    K = 30
+                    K = 60
                     e0.record(ext)
                     for k in range(K):
                         s = k & 1

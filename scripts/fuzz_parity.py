@@ -19,6 +19,41 @@ def dev(raw):
     return torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).cuda()
 
 
+def time_domain_case(rng, n, kind, enob, dc):
+    thr = float(rng.choice([-1.5, -20.0, 3.0]))
+    o = O.Oracle(n, FS, thr, kind=kind, enob=enob, correct_dc=dc)
+    flags = capi.PLAN_OVERLAP_SLOTS if rng.integers(0, 2) else 0
+    desc = f"time-domain n={n} kind={kind} enob={enob} dc={dc} thr={thr} flags={flags}"
+    try:
+        with Plan(n, FS, thr, kind=kind, enob=enob, correct_dc=dc, max_batch=96, mode=capi.MODE_TIME_DOMAIN,
+                  flags=flags | capi.OUT_SPECTRUM | capi.OUT_HITS) as plan:
+            sub = []
+            for s in (0, 1):
+                nb = int(rng.integers(1, 97))
+                x = synth.cfloat_batch(n, nb, seed=int(rng.integers(1 << 30)))
+                raw = synth.quantize(x, kind)
+                if dc:
+                    raw = (raw + int(rng.integers(1, 60))).astype(raw.dtype)
+                plan.submit_device(s, dev(raw), nb, np.zeros(nb))
+                sub.append((raw, nb))
+            for s, (raw, nb) in enumerate(sub):
+                mx, mn, ab = plan.collect_time_domain(s)
+                flat = raw.reshape(nb, -1)
+                ref = [o.time_domain(o.convert(flat[b]), threshold=thr) for b in range(nb)]
+                rmax = np.array([r[1] for r in ref], np.float32)
+                rmin = np.array([r[2] for r in ref], np.float32)
+                rhit = np.array([r[0] for r in ref], np.uint8)
+                assert np.array_equal(np.isneginf(mn), np.isneginf(rmin)) and np.array_equal(np.isfinite(mx), np.isfinite(rmax))
+                fmx, fmn = np.isfinite(rmax), np.isfinite(rmin)
+                assert np.abs(mx[fmx] - rmax[fmx]).max(initial=0) < 1e-4, "max dB"
+                assert np.abs(mn[fmn] - rmin[fmn]).max(initial=0) < 5e-3, "min dB"
+                clear = np.abs(rmax - thr) > 1e-3
+                assert np.array_equal(ab[clear], rhit[clear]), "above-threshold flags"
+    except Exception:
+        print("FAILED CASE:", desc, file=sys.stderr)
+        raise
+
+
 near_misses = []   # (max_rel_power, case description, what the worst buffer looks like) of the last run()
 
 
@@ -37,6 +72,11 @@ def run(budget, seed):
         out_flags = int(rng.choice([3, 3, 1, 2]))
         flags = out_flags | (capi.PLAN_OVERLAP_SLOTS if rng.integers(0, 2) else 0)
         max_nb = int(rng.choice([3, 64, 700, 1300, 2600])) if n <= 4096 else int(rng.choice([3, 64, 600, 1100]))
+        if rng.random() < 0.15:   # time-domain mode (process.cpp:203-237): a few small launches against the oracle
+            time_domain_case(rng, n, kind, enob, dc)
+            cases += 1
+            launches += 2
+            continue
         region_scale = int(rng.choice([1, 64, 64, 400]))   # small max_hits -> small hit regions -> overflow path
         max_hits = max(64, max_nb * region_scale)
         nl = int(rng.integers(1, 6))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 1
+#define SCN_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -35,9 +35,11 @@ enum {
   SCN_E_HIP = 2,          /* a HIP runtime call failed (see scn_last_error) */
   SCN_E_NOMEM = 3,
   SCN_E_STATE = 4,        /* call out of order (collect before submit, ...) */
-  SCN_E_TRUNCATED = 5,    /* more hits than the caller's / the plan's capacity:
-                             n_hits holds the true total, the list the first ones */
-  SCN_E_NO_DEVICE = 6
+  SCN_E_TRUNCATED = 5,    /* more hits than the caller's buffer (or the plan's max_hits) holds: n_hits is the true
+                             total, the buffer holds the FIRST min(n_hits, hit_cap, max_hits) records of the ordered
+                             list and nothing is lost on the GPU: scn_collect_more fetches the rest */
+  SCN_E_NO_DEVICE = 6,
+  SCN_E_COMM = 7          /* RCCL could not be loaded or a collective failed */
 };
 
 /* Wire format of one IQ sample; values are messageQueue.h:31-37 SampleKind. */
@@ -82,7 +84,7 @@ typedef struct scn_hit {
  * constant where one exists. */
 typedef struct scn_plan_desc {
   uint32_t struct_size;
-  uint32_t n;              /* sampleCount = FFT size (scan.cpp:85); 1024/2048/4096/8192 */
+  uint32_t n;              /* sampleCount = FFT size (scan.cpp:85); a power of two, 1024 ... 16384 */
   uint32_t sample_rate;    /* Hz (scan.cpp:92) */
   uint32_t sample_kind;    /* SCN_KIND_* */
   uint32_t enob;           /* effective bits (scan.cpp:138,183) */
@@ -94,7 +96,8 @@ typedef struct scn_plan_desc {
   double use_bandwidth;    /* 0 -> 0.75 (scan.cpp:65) */
   uint32_t trigger_count;  /* 0 -> 1047 (process.cpp:62) */
   uint32_t max_batch;      /* buffers per submit (>= 1) */
-  uint32_t max_hits;       /* device hit-list capacity per slot; 0 -> 64 per buffer */
+  uint32_t max_hits;       /* records of the ordered hit list each slot keeps in pinned host memory (what one
+                              scn_collect can return; the rest stays on the GPU for scn_collect_more); 0 -> 64 per buffer */
   uint32_t flags;          /* SCN_OUT_* (neither -> SPECTRUM|HITS), SCN_PLAN_OVERLAP_SLOTS */
   int32_t device_id;       /* HIP device ordinal */
   uint32_t reserved[5];
@@ -143,10 +146,24 @@ int scn_submit_device(scn_plan *plan, int slot, const void *d_raw,
  * floats in natural FFT bin order (bin 0 = DC), or NULL.  hits: host array of
  * hit_cap entries or NULL; on return *n_hits is the total number of hits,
  * the list is ordered by (buffer order, i) as a single-threaded reference run
- * prints them.  trigger: n_buffers bytes, process_fft's return value
- * (hits > trigger_count) per buffer, or NULL. */
+ * prints them (process.cpp:46-61) -- the ordering and the completion of the
+ * records (seq_id, freq_hz) happen on the GPU, the call copies min(*n_hits,
+ * hit_cap, max_hits) 24-byte records out of pinned memory and returns
+ * SCN_E_TRUNCATED when that is not all of them.  trigger: n_buffers bytes,
+ * process_fft's return value (hits > trigger_count) per buffer, or NULL.
+ * With hits == NULL the call waits for the kernel and the per-buffer counts only. */
 int scn_collect(scn_plan *plan, int slot, float *power_db, scn_hit *hits,
                 uint32_t hit_cap, uint32_t *n_hits, uint8_t *trigger);
+
+/* Records [first, first + hit_cap) of the ordered hit list of the slot's last COLLECTED submit (valid until the
+ * slot's next submit): how a caller with a bounded buffer walks a list of any length -- a wideband burst makes every
+ * buffer of a batch report > 1047 hits (process.cpp:62) and the reference prints each of them.  *n_written receives
+ * the number of records stored (0 once first >= n_hits). */
+int scn_collect_more(scn_plan *plan, int slot, uint32_t first, scn_hit *hits, uint32_t hit_cap, uint32_t *n_written);
+
+/* Zero-copy alternative to the hits argument of scn_collect: the plan's own pinned copy of the ordered list
+ * (min(n_hits, max_hits) records), valid from scn_collect until the slot's next submit. */
+int scn_hits_view(scn_plan *plan, int slot, const scn_hit **hits, uint32_t *n);
 
 /* Time-domain plans (mode = SCN_MODE_TIME_DOMAIN; ProcessSamples::DoTimeDomainThresholding,
  * process.cpp:203-237): wait for the slot's submit and fetch, per buffer, the maximum and
@@ -184,6 +201,31 @@ int scn_frequency_table(uint32_t sample_rate, double start, double stop,
                         double use_bandwidth, double dc_ignore_width,
                         uint32_t shard, uint32_t n_shards, double *out,
                         uint32_t cap, uint32_t *count, uint32_t *first);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU sweep (scan.cpp:211-239 run once per GPU over a shard of the frequency table): one
+ * process -- or one thread -- per GPU, each with its own plan on the index range scn_frequency_table gives it; no
+ * data-path collective.  The only exchange is the sweep's final hit list to the root over RCCL / xGMI:
+ * ncclAllGather of the per-rank counts, then one group of ncclSend / ncclRecv straight into the rank-major
+ * (= globally ordered, the shards being contiguous) list on the root.
+ *   scn_comm_unique_id   rank 0 creates the rendezvous id (ncclGetUniqueId) and hands its SCN_COMM_ID_BYTES to the
+ *                        other ranks by any means (the launcher's store, a file, MPI ...)
+ *   scn_comm_create      every rank, collectively (ncclCommInitRank) on its device
+ *   scn_gather_hits      collective: local = this rank's ordered list (host memory); on the root `all` receives
+ *                        min(*n_total, all_cap) records (SCN_E_TRUNCATED if fewer than all), per_rank[world_size]
+ *                        the counts; both may be NULL elsewhere.  *n_total is set on every rank.
+ *   scn_gather_layout    host-only helper: offsets[r] = first index of rank r's records in the gathered list,
+ *                        offsets[world_size] = total
+ * RCCL is loaded on first use (dlopen), not at link time.
+ * ------------------------------------------------------------------------------------ */
+#define SCN_COMM_ID_BYTES 128
+typedef struct scn_comm scn_comm;
+int scn_comm_unique_id(void *id);
+int scn_comm_create(const void *id, int rank, int world_size, int device_id, scn_comm **out);
+int scn_comm_destroy(scn_comm *comm);
+int scn_gather_hits(scn_comm *comm, const scn_hit *local, uint32_t n_local, uint32_t root, scn_hit *all,
+                    uint64_t all_cap, uint64_t *n_total, uint32_t *per_rank);
+int scn_gather_layout(const uint32_t *per_rank, uint32_t world_size, uint64_t *offsets);
 
 /* HackRFSource::interpolateSamples (hackRFSource.cpp:186-222), the in-band header of HackRF
  * sweep-mode transfers: when the transfer starts with the bytes 0x7F 0x7F, bytes 2..9 hold the

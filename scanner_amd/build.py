@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libscanner_hip.so")
-SOURCES = ["scn_kernels.hip", "scn_welch.hip", "scn_api.hip"]
+SOURCES = ["scn_kernels.hip", "scn_hits.hip", "scn_welch.hip", "scn_gather.hip", "scn_api.hip"]
 HEADERS = ["scn_kernels.h", "scn_device.h", os.path.join("..", "..", "include", "scanner_hip.h")]
 ARCH = "gfx950"
 
@@ -52,7 +52,7 @@ def build(force=False, verbose=False, defines=(), out=None):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCN_LIB selects an experiment build (scripts/build_variants.py); the product library otherwise
 LIB_PATH = os.environ.get("SCN_LIB") or os.path.join(_HERE, "libscanner_hip.so")
 
-OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_TRUNCATED, E_NO_DEVICE = range(7)
+OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_TRUNCATED, E_NO_DEVICE, E_COMM = range(8)
 KIND_BYTE_COMPLEX, KIND_SHORT, KIND_SHORT_COMPLEX, KIND_FLOAT_COMPLEX = 1, 2, 3, 4
 MODE_TIME_DOMAIN, MODE_FREQUENCY_DOMAIN = 1, 2
 WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 3, 5
@@ -20,7 +20,8 @@ OUT_SPECTRUM, OUT_HITS = 1, 2
 PLAN_OVERLAP_SLOTS = 4  # each slot on its own compute stream (scanner_hip.h)
 DC_IGNORE_NONE = 0xFFFFFFFF
 NUM_SLOTS = 2
-ABI_VERSION = 1
+ABI_VERSION = 2
+COMM_ID_BYTES = 128
 
 BYTES_PER_SAMPLE = {KIND_BYTE_COMPLEX: 2, KIND_SHORT: 4, KIND_SHORT_COMPLEX: 4, KIND_FLOAT_COMPLEX: 8}
 
@@ -79,6 +80,8 @@ SYMBOLS = {
     "scn_submit": (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, _vp]),
     "scn_submit_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, _vp, _vp, _vp]),
     "scn_collect": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), _vp]),
+    "scn_collect_more": (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "scn_hits_view": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint32)]),
     "scn_collect_time_domain": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "scn_convert_raw": (C.c_int, [_vp, _vp, C.c_uint32, _vp]),
     "scn_wait": (C.c_int, [_vp, C.c_int]),
@@ -95,6 +98,11 @@ SYMBOLS = {
     "scn_welch_collect": (C.c_int, [_vp, C.c_int, _vp]),
     "scn_frequency_table": (C.c_int, [C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32,
                                       C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "scn_comm_unique_id": (C.c_int, [_vp]),
+    "scn_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "scn_comm_destroy": (C.c_int, [_vp]),
+    "scn_gather_hits": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64), _vp]),
+    "scn_gather_layout": (C.c_int, [_vp, C.c_uint32, _vp]),
     "scn_hackrf_sweep_fixup": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double),
                                          C.POINTER(C.c_uint32)]),
 }
@@ -151,6 +159,14 @@ def frequency_table(sample_rate, start, stop, use_bandwidth=0.75, dc_ignore_widt
                                 out.ctypes.data_as(_vp), cnt.value, C.byref(cnt), C.byref(first)),
           "scn_frequency_table")
     return first.value, out
+
+
+def gather_layout(per_rank):
+    """offsets[r] of rank r's records in the rank-major gathered hit list, total last (scn_gather_layout)."""
+    per_rank = np.ascontiguousarray(per_rank, np.uint32)
+    off = np.empty(per_rank.size + 1, np.uint64)
+    check(lib().scn_gather_layout(per_rank.ctypes.data_as(_vp), per_rank.size, off.ctypes.data_as(_vp)), "scn_gather_layout")
+    return off
 
 
 def hackrf_sweep_fixup(transfer, scan_offset_hz=0):

@@ -33,6 +33,21 @@ int fail(int status, const char *fmt, ...) {
   return status;
 }
 
+}  // namespace
+
+// shared with scn_gather.hip (not part of the public header)
+int scn_set_last_error(int status, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return status;
+}
+
+namespace {
+
 #define SCN_HIP(call)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (call);                                                                    \
@@ -61,16 +76,24 @@ struct Slot {
   uint32_t *d_work_counter = nullptr;
   uint32_t work_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool own_stream = false;
-  ScnDevHit *d_hits = nullptr;      // [max_batch][hit_region] per-buffer hit regions
-  ScnDevHit *d_ov_hits = nullptr;   // [max_hits] overflow list (buffers with > hit_region hits)
-  uint32_t *d_ov_counter = nullptr; // device-side overflow slot allocator, never reset
-  uint32_t ov_base = 0;             // its value before the pending submit (host-tracked)
+  ScnDevHit *d_hits = nullptr;      // [max_batch][hit_region] per-buffer hit regions (unordered, scn_kernels.hip)
+  // the ordered list (scn_hits.hip): offsets = exclusive scan of the counts; fc / seq = device copies of the
+  // submit's MessageHeader fields (staged through the pinned h_meta); h_list = the first max_hits completed records,
+  // written by the compaction kernel straight into pinned host memory; d_window = where scn_collect_more re-runs
+  // the compaction for a later window of the list
+  uint32_t *d_offsets = nullptr;
+  double *d_fc = nullptr;
+  uint64_t *d_seq = nullptr;
+  void *h_meta = nullptr;           // pinned [max_batch] doubles then [max_batch] u64
+  scn_hit *h_list = nullptr;        // pinned [max_hits]
+  hipEvent_t list_done = nullptr;   // compaction of the pending / last submit finished
+  bool list_valid = false;          // regions, counts and offsets of the last collected submit are still on the device
+  uint32_t total_hits = 0;          // of the last collected submit
+  scn_hit *d_window = nullptr;      // [d_window_cap] scratch of scn_collect_more
+  uint32_t d_window_cap = 0;
   hipEvent_t done = nullptr;
   bool pending = false;
   uint32_t n_buffers = 0;
-  std::vector<double> fc;
-  std::vector<uint64_t> seq;
-  std::vector<ScnDevHit> host_hits;
 };
 
 }  // namespace
@@ -84,7 +107,7 @@ struct scn_plan {
   size_t buf_bytes = 0;
   float scale = 1.0f;
   uint32_t i_lo = 0, i_hi = 0;
-  uint32_t hit_region = 0;  // hit slots each buffer owns before it spills to the overflow list
+  uint32_t hit_region = 0;  // hit slots each buffer owns = the bins the mask of process.cpp:46-52 evaluates (cannot overflow)
   std::vector<float> h_window;
   float *d_window = nullptr;
   scn_v2f *d_twiddle = nullptr;
@@ -143,17 +166,38 @@ int ensure_slot_outputs(scn_plan *p, Slot &s) {
     if (!s.h_td) SCN_HIP(hipHostMalloc(&s.h_td, sizeof(float) * 2 * p->d.max_batch, hipHostMallocDefault));
     return SCN_OK;
   }
-  if ((p->d.flags & SCN_OUT_HITS) && !s.d_hits) {
-    SCN_HIP(hipMalloc(&s.d_hits, sizeof(ScnDevHit) * (size_t)p->hit_region * p->d.max_batch));
-    SCN_HIP(hipMalloc(&s.d_ov_hits, sizeof(ScnDevHit) * (size_t)p->d.max_hits));
-    SCN_HIP(hipMalloc(&s.d_ov_counter, sizeof(uint32_t)));
-    SCN_HIP(hipMalloc(&s.d_buf_hits, sizeof(uint32_t) * p->d.max_batch));
-    SCN_HIP(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
-    SCN_HIP(hipMemsetAsync(s.d_ov_counter, 0, sizeof(uint32_t), s.stream));
-    SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * p->d.max_batch, hipHostMallocDefault));
-    s.ov_base = 0;
+  if (p->d.flags & SCN_OUT_HITS) {
+    // every resource under its own check: a failed allocation leaves a state the next call completes or fails on again
+    const uint32_t mb = p->d.max_batch;
+    if (!s.d_hits) SCN_HIP(hipMalloc(&s.d_hits, sizeof(ScnDevHit) * (size_t)p->hit_region * mb));
+    if (!s.d_buf_hits) SCN_HIP(hipMalloc(&s.d_buf_hits, sizeof(uint32_t) * mb));
+    if (!s.h_buf_hits) SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * mb, hipHostMallocDefault));
+    if (!s.d_offsets) SCN_HIP(hipMalloc(&s.d_offsets, sizeof(uint32_t) * ((size_t)mb + 1u)));
+    if (!s.d_fc) SCN_HIP(hipMalloc(&s.d_fc, sizeof(double) * mb));
+    if (!s.d_seq) SCN_HIP(hipMalloc(&s.d_seq, sizeof(uint64_t) * mb));
+    if (!s.h_meta) SCN_HIP(hipHostMalloc(&s.h_meta, 16u * (size_t)mb, hipHostMallocDefault));
+    if (!s.h_list) SCN_HIP(hipHostMalloc(&s.h_list, sizeof(scn_hit) * (size_t)p->d.max_hits, hipHostMallocDefault));
+    if (!s.kernel_done) SCN_HIP(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
+    if (!s.list_done) SCN_HIP(hipEventCreateWithFlags(&s.list_done, hipEventDisableTiming));
   }
   return SCN_OK;
+}
+
+ScnCompactArgs compact_args(const scn_plan *p, const Slot &s, uint32_t first, uint32_t cap, void *out) {
+  ScnCompactArgs c;
+  c.regions = s.d_hits;
+  c.hit_region = p->hit_region;
+  c.counts = s.d_buf_hits;
+  c.offsets = s.d_offsets;
+  c.center_freq = s.d_fc;
+  c.seq_id = s.d_seq;
+  c.out = out;
+  c.first = first;
+  c.out_cap = std::min<uint32_t>(cap, 0x7fffffffu - first);  // first + out_cap must not wrap
+  c.n_buffers = s.n_buffers;
+  c.n = p->d.n;
+  c.sample_rate = p->d.sample_rate;
+  return c;
 }
 
 int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const double *fc, const uint64_t *seq,
@@ -164,9 +208,6 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   if (p->d.mode == SCN_MODE_TIME_DOMAIN) {
     s.cur_power = nullptr;
     s.n_buffers = nb;
-    s.fc.assign(fc, fc + nb);
-    s.seq.resize(nb);
-    for (uint32_t b = 0; b < nb; b++) s.seq[b] = seq ? seq[b] : (uint64_t)b;
     ScnTdArgs a;
     a.raw = d_raw;
     a.n = n;
@@ -185,9 +226,25 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   }
   s.cur_power = d_power;
   s.n_buffers = nb;
-  s.fc.assign(fc, fc + nb);
-  s.seq.resize(nb);
-  for (uint32_t b = 0; b < nb; b++) s.seq[b] = seq ? seq[b] : (uint64_t)b;
+  s.list_valid = false;
+  const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
+  // where everything behind the kernel goes: the side stream (the compute stream then carries nothing but FFT
+  // kernels), or, with overlapped slots, the slot's own stream -- its next kernel is two submits away, and one stream
+  // less keeps both compute streams on hardware queues of their own (HIP maps streams onto 4 queues by default; with a
+  // fifth active stream the two compute streams ended up sharing one)
+  hipStream_t aux = s.own_stream ? s.stream : p->d2h_stream;
+  if (hits && nb) {
+    double *h_fc = static_cast<double *>(s.h_meta);
+    uint64_t *h_seq = reinterpret_cast<uint64_t *>(h_fc + p->d.max_batch);
+    memcpy(h_fc, fc, sizeof(double) * nb);
+    for (uint32_t b = 0; b < nb; b++) h_seq[b] = seq ? seq[b] : (uint64_t)b;
+    // the previous compaction on this slot read d_fc / d_seq on `aux`: same stream, so these copies queue behind it
+    SCN_HIP(hipMemcpyAsync(s.d_fc, h_fc, sizeof(double) * nb, hipMemcpyHostToDevice, aux));
+    SCN_HIP(hipMemcpyAsync(s.d_seq, h_seq, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, aux));
+    // ... and read this slot's regions and counts, which the kernel below overwrites: a collect that only asked for
+    // the counts does not wait for the list, so the kernel does (a GPU-side dependency that is met long before)
+    if (!s.own_stream) SCN_HIP(hipStreamWaitEvent(s.stream, s.list_done, 0));
+  }
 
   ScnFftArgs a;
   memset(&a, 0, sizeof(a));
@@ -204,28 +261,24 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.i_hi = p->i_hi;
   a.hits = s.d_hits;
   a.hit_region = p->hit_region;
-  a.ov_hits = s.d_ov_hits;
-  a.ov_counter = s.d_ov_counter;
-  a.ov_base = s.ov_base;
-  a.ov_cap = p->d.max_hits;
   a.per_buffer_hits = s.d_buf_hits;
   a.work_counter = s.d_work_counter;
   for (uint32_t x = 0; x < 8; x++) a.work_base[x] = s.work_base[x];
-  const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
   SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, s.stream));
   if (scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
-  if (hits && nb && s.own_stream) {
-    // overlapped slots: the counts follow the kernel on the slot's own stream -- the next kernel there is two
-    // submits away, and one stream less keeps both compute streams on hardware queues of their own (HIP maps
-    // streams onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one)
-    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, s.stream));
-    SCN_HIP(hipEventRecord(s.done, s.stream));
-  } else if (hits && nb) {
-    SCN_HIP(hipEventRecord(s.kernel_done, s.stream));
-    SCN_HIP(hipStreamWaitEvent(p->d2h_stream, s.kernel_done, 0));
-    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, p->d2h_stream));
-    SCN_HIP(hipEventRecord(s.done, p->d2h_stream));
+  if (hits && nb) {
+    if (!s.own_stream) {
+      SCN_HIP(hipEventRecord(s.kernel_done, s.stream));
+      SCN_HIP(hipStreamWaitEvent(aux, s.kernel_done, 0));
+    }
+    // counts first (a DMA: needs no CU), then the ordered list
+    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, aux));
+    SCN_HIP(hipEventRecord(s.done, aux));
+    ScnCompactArgs c = compact_args(p, s, 0, p->d.max_hits, s.h_list);
+    SCN_HIP(scn_launch_hit_scan(c, aux));
+    SCN_HIP(scn_launch_hit_compact(c, aux));
+    SCN_HIP(hipEventRecord(s.list_done, aux));
   } else {
     SCN_HIP(hipEventRecord(s.done, s.stream));
   }
@@ -248,8 +301,13 @@ void free_slot(Slot &s) {
   if (s.staged) (void)hipEventDestroy(s.staged);
   if (s.h_td) (void)hipHostFree(s.h_td);
   if (s.d_hits) (void)hipFree(s.d_hits);
-  if (s.d_ov_hits) (void)hipFree(s.d_ov_hits);
-  if (s.d_ov_counter) (void)hipFree(s.d_ov_counter);
+  if (s.d_offsets) (void)hipFree(s.d_offsets);
+  if (s.d_fc) (void)hipFree(s.d_fc);
+  if (s.d_seq) (void)hipFree(s.d_seq);
+  if (s.d_window) (void)hipFree(s.d_window);
+  if (s.h_meta) (void)hipHostFree(s.h_meta);
+  if (s.h_list) (void)hipHostFree(s.h_list);
+  if (s.list_done) (void)hipEventDestroy(s.list_done);
   if (s.done) (void)hipEventDestroy(s.done);
   s = Slot();
 }
@@ -267,6 +325,7 @@ const char *scn_error_name(int status) {
     case SCN_E_STATE: return "SCN_E_STATE";
     case SCN_E_TRUNCATED: return "SCN_E_TRUNCATED";
     case SCN_E_NO_DEVICE: return "SCN_E_NO_DEVICE";
+    case SCN_E_COMM: return "SCN_E_COMM";
     default: return "SCN_E_UNKNOWN";
   }
 }
@@ -328,7 +387,14 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   uint32_t use_window = (uint32_t)(d.use_bandwidth * d.n / 2.0);
   p->i_lo = d.n / 2 - use_window;
   p->i_hi = d.n / 2 + use_window;
-  p->hit_region = std::max<uint32_t>(8u, std::min<uint32_t>(d.n, d.max_hits / (2u * d.max_batch)));
+  {  // the mask exactly as the kernels apply it (process.cpp:46-52, uint32 arithmetic)
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < d.n; i++) {
+      const uint32_t j = (i + d.n / 2) % d.n;
+      kept += !(j < d.dc_ignore_bins || (d.n - j) < d.dc_ignore_bins) && !(i < p->i_lo || i > p->i_hi);
+    }
+    p->hit_region = std::max<uint32_t>(kept, 1u);
+  }
   build_window(d.window_type, d.n, p->h_window);
 
   hipDeviceProp_t prop;
@@ -510,7 +576,7 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   int st = check_slot(p, slot);
   if (st) return st;
   if (p->d.mode != SCN_MODE_FREQUENCY_DOMAIN) return fail(SCN_E_INVALID, "time-domain plan: use scn_collect_time_domain");
-  st = scn_wait(p, slot);
+  st = scn_wait(p, slot);  // the kernel and the per-buffer counts; the ordered list has an event of its own
   if (st) return st;
   Slot &s = p->slot[slot];
   s.pending = false;
@@ -519,74 +585,80 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   if ((hits || trigger) && !have_hits) return fail(SCN_E_INVALID, "plan was created without SCN_OUT_HITS");
   if (power_db && !s.cur_power) return fail(SCN_E_INVALID, "plan was created without SCN_OUT_SPECTRUM");
 
-  int result = SCN_OK;
-  uint32_t total = 0;
+  uint64_t total = 0;
   if (have_hits && nb) {
-    uint32_t in_regions = 0, overflow = 0;
     for (uint32_t b = 0; b < nb; b++) {
       const uint32_t c = s.h_buf_hits[b];
       total += c;
-      in_regions += std::min(c, p->hit_region);
-      overflow += c > p->hit_region ? c - p->hit_region : 0u;
       if (trigger) trigger[b] = c > p->d.trigger_count;  // process.cpp:62
     }
-    s.ov_base += overflow;  // wrapping, like the device counter
-    const uint32_t ov_kept = std::min(overflow, p->d.max_hits);
-    if (hits && total) {
-      // fetch the per-buffer regions (one copy) and the overflow list, then restore the order a
-      // single-threaded reference run prints: by buffer, then by i
-      std::vector<ScnDevHit> &hh = s.host_hits;
-      std::vector<ScnDevHit> regions((size_t)nb * p->hit_region);
-      SCN_HIP(hipMemcpyAsync(regions.data(), s.d_hits, sizeof(ScnDevHit) * regions.size(), hipMemcpyDeviceToHost,
-                             s.stream));
-      hh.resize((size_t)in_regions + ov_kept);
-      if (ov_kept)
-        SCN_HIP(hipMemcpyAsync(hh.data() + in_regions, s.d_ov_hits, sizeof(ScnDevHit) * ov_kept,
-                               hipMemcpyDeviceToHost, s.stream));
-      SCN_HIP(hipStreamSynchronize(s.stream));
-      // Region b already holds buffer b's hits (in arbitrary order), so buffer-major order needs
-      // no global sort: sort each small region by i; only the overflow list (rare) is sorted
-      // globally and merged in.
-      auto by_buf_i = [](const ScnDevHit &x, const ScnDevHit &y) {
-        return x.buffer != y.buffer ? x.buffer < y.buffer : x.i < y.i;
-      };
-      std::vector<ScnDevHit> ov(hh.begin() + in_regions, hh.end());
-      std::sort(ov.begin(), ov.end(), by_buf_i);
-      size_t w = 0, o = 0;
-      for (uint32_t b = 0; b < nb; b++) {
-        const uint32_t c = std::min(s.h_buf_hits[b], p->hit_region);
-        const size_t first = w;
-        std::copy_n(regions.begin() + (size_t)b * p->hit_region, c, hh.begin() + w);
-        w += c;
-        while (o < ov.size() && ov[o].buffer == b) hh[w++] = ov[o++];
-        std::sort(hh.begin() + first, hh.begin() + w, by_buf_i);
-      }
-      hh.resize(w);
-      const uint32_t bin_step = p->d.sample_rate / n;  // process.cpp:39 (truncating)
-      const uint32_t out_n = (uint32_t)std::min<size_t>(hh.size(), hit_cap);
-      for (uint32_t k = 0; k < out_n; k++) {
-        const ScnDevHit &h = hh[k];
-        double start_frequency = s.fc[h.buffer] - (double)(p->d.sample_rate / 2u);  // process.cpp:38
-        double frequency = start_frequency + (double)(uint32_t)(h.i * bin_step);    // process.cpp:55
-        hits[k].seq_id = s.seq[h.buffer];
-        hits[k].i = h.i;
-        hits[k].power_db = h.power_db;
-        hits[k].freq_hz = (uint64_t)frequency;  // process.cpp:57
-      }
-    }
-    if (hits && (overflow > p->d.max_hits || total > hit_cap)) result = SCN_E_TRUNCATED;  // only when records were asked for
-
+    s.list_valid = true;
   } else if (trigger) {
     memset(trigger, 0, nb);
   }
-  if (n_hits) *n_hits = total;
+  if (total > 0x7fffffffu) return fail(SCN_E_INVALID, "%llu hits in one submit: split the batch", (unsigned long long)total);
+  s.total_hits = (uint32_t)total;
+  if (n_hits) *n_hits = (uint32_t)total;
+  uint32_t copied = 0;
+  if (hits && total) {
+    // the compaction kernel has written the first max_hits records, ordered and complete, to pinned memory
+    SCN_HIP(hipEventSynchronize(s.list_done));
+    copied = std::min(std::min((uint32_t)total, hit_cap), p->d.max_hits);
+    memcpy(hits, s.h_list, sizeof(scn_hit) * copied);
+  }
   if (power_db && nb) {
     SCN_HIP(hipMemcpyAsync(power_db, s.cur_power, sizeof(float) * (size_t)n * nb, hipMemcpyDeviceToHost, s.stream));
     SCN_HIP(hipStreamSynchronize(s.stream));
   }
-  if (result == SCN_E_TRUNCATED)
-    return fail(result, "%u hits: more than the caller's capacity %u or the device overflow capacity %u", total,
-                hit_cap, p->d.max_hits);
+  if (hits && copied < total)
+    return fail(SCN_E_TRUNCATED, "%u hits, %u returned (caller capacity %u, plan max_hits %u): scn_collect_more fetches the rest",
+                (uint32_t)total, copied, hit_cap, p->d.max_hits);
+  return SCN_OK;
+}
+
+int scn_collect_more(scn_plan *p, int slot, uint32_t first, scn_hit *hits, uint32_t hit_cap, uint32_t *n_written) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if (!hits || !n_written) return fail(SCN_E_INVALID, "null argument");
+  *n_written = 0;
+  Slot &s = p->slot[slot];
+  if (s.pending || !s.list_valid) return fail(SCN_E_STATE, "slot %d: no collected submit whose hit list is still on the device", slot);
+  if (first >= s.total_hits || hit_cap == 0) return SCN_OK;
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  const uint32_t want = std::min(hit_cap, s.total_hits - first);
+  if (first + want <= p->d.max_hits) {  // still inside the part that is already in pinned memory
+    SCN_HIP(hipEventSynchronize(s.list_done));
+    memcpy(hits, s.h_list + first, sizeof(scn_hit) * want);
+    *n_written = want;
+    return SCN_OK;
+  }
+  // re-run the compaction for the window [first, first + want): regions, counts and offsets stay valid until the
+  // slot's next submit
+  if (s.d_window_cap < want) {
+    if (s.d_window) (void)hipFree(s.d_window);
+    s.d_window = nullptr;
+    s.d_window_cap = 0;
+    SCN_HIP(hipMalloc(&s.d_window, sizeof(scn_hit) * (size_t)want));
+    s.d_window_cap = want;
+  }
+  hipStream_t aux = s.own_stream ? s.stream : p->d2h_stream;
+  SCN_HIP(scn_launch_hit_compact(compact_args(p, s, first, want, s.d_window), aux));
+  SCN_HIP(hipMemcpyAsync(hits, s.d_window, sizeof(scn_hit) * want, hipMemcpyDeviceToHost, aux));
+  SCN_HIP(hipStreamSynchronize(aux));
+  *n_written = want;
+  return SCN_OK;
+}
+
+int scn_hits_view(scn_plan *p, int slot, const scn_hit **hits, uint32_t *n) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if (!hits || !n) return fail(SCN_E_INVALID, "null argument");
+  Slot &s = p->slot[slot];
+  if (s.pending || !s.list_valid) return fail(SCN_E_STATE, "slot %d: no collected submit whose hit list is still available", slot);
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  SCN_HIP(hipEventSynchronize(s.list_done));
+  *hits = s.h_list;
+  *n = std::min(s.total_hits, p->d.max_hits);
   return SCN_OK;
 }
 

@@ -12,12 +12,12 @@
 
 typedef float scn_v2f __attribute__((ext_vector_type(2)));
 
-// A hit as the kernel records it (unordered); the host adds seq_id / freq and sorts.
+// A hit as the FFT kernel records it: slot `pos` of its buffer's region, in arbitrary order.  The compaction
+// kernels (scn_hits.hip) put the batch's records into the order a single-threaded reference run prints them
+// (buffer, then i: process.cpp:46-61) and complete them to the public scn_hit (seq_id, freq_hz).
 struct ScnDevHit {
-  uint32_t buffer;  // index within the submit
-  uint32_t i;       // fftshift-ordered bin index (process.cpp:46)
-  float power_db;
-  uint32_t pad;
+  uint32_t i;      // fftshift-ordered bin index (process.cpp:46)
+  float power_db;  // magnitudes[j]
 };
 
 struct ScnFftArgs {
@@ -34,15 +34,12 @@ struct ScnFftArgs {
   float threshold;
   uint32_t dc_ignore;       // m_dcIgnoreWindow
   uint32_t i_lo, i_hi;      // halfSampleCount -/+ m_useWindow (wrapping)
-  // hit records: buffer b owns slots [b*hit_region, (b+1)*hit_region) (allocated with an LDS
-  // atomic inside its workgroup -- no global atomics on the common path); a buffer with more
-  // hits spills the rest to the overflow list through one device-scope counter.
+  // hit records: buffer b owns slots [b*hit_region, (b+1)*hit_region), hit_region = the number of bins the mask of
+  // process.cpp:46-52 lets through, so a region can never overflow (sized for 288 GB of HBM: 8 B x ~0.75 N per
+  // buffer, written only where there is a detection).  Slots are allocated with one LDS atomic per wave inside the
+  // buffer's workgroup: no global atomics anywhere on the hit path.
   ScnDevHit *hits;            // [n_buffers][hit_region]
   uint32_t hit_region;
-  ScnDevHit *ov_hits;         // [ov_cap]
-  uint32_t *ov_counter;       // monotonically increasing across submits
-  uint32_t ov_base;           // its value before this submit (host-tracked)
-  uint32_t ov_cap;
   uint32_t *per_buffer_hits;  // [n_buffers] total hits of each buffer (device memory)
   // buffer queue of the persistent workgroups: 8 heads, 32 words (one 128-byte line) apart, never reset; head x
   // serves the buffers b = 8 j + x; work_base[x] is its value before this launch and a launch adds exactly the
@@ -86,6 +83,23 @@ struct ScnWelchArgs {
   float inv_k;
 };
 hipError_t scn_launch_welch(const ScnWelchArgs &args, int num_cus, hipStream_t stream);
+
+// Ordered hit list (scn_hits.hip): exclusive scan of the per-buffer counts, then one wave per buffer with hits ranks
+// its records by bin (a bitmap in LDS) and writes the completed scn_hit records [first, first + out_cap) of the
+// batch's ordered list to `out` (device or pinned host memory).
+struct ScnCompactArgs {
+  const ScnDevHit *regions;  // [n_buffers][hit_region]
+  uint32_t hit_region;
+  const uint32_t *counts;    // [n_buffers]
+  uint32_t *offsets;         // [n_buffers + 1]: exclusive prefix sums, total at [n_buffers]
+  const double *center_freq; // [n_buffers] device copies of the MessageHeader fields
+  const uint64_t *seq_id;    // [n_buffers]
+  void *out;                 // scn_hit[out_cap]
+  uint32_t first, out_cap;
+  uint32_t n_buffers, n, sample_rate;
+};
+hipError_t scn_launch_hit_scan(const ScnCompactArgs &args, hipStream_t stream);
+hipError_t scn_launch_hit_compact(const ScnCompactArgs &args, hipStream_t stream);
 
 // K1 alone (capture path)
 hipError_t scn_launch_convert(int kind, bool correct_dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers,

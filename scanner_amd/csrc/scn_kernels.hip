@@ -526,16 +526,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
           uint32_t base = 0;
           if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
           base = __builtin_amdgcn_readfirstlane(base);
-          // This wave's records take the buffer's slots [base, base + total); those at or past hit_region go to
-          // the overflow list, reserved with ONE device-scope atomic per wave (one per overflowing output index
-          // made a hit-dense int16 launch -- 17 k overflow records -- 15-20 us slower: a single counter takes ~88
-          // returning atomics per us).
-          const uint32_t ov_from = base > args.hit_region ? base : args.hit_region;  // first overflowing slot of this wave
-          uint32_t ov_first = 0;
-          if (base + total > ov_from) {
-            if (lane == 0) ov_first = atomicAdd(args.ov_counter, base + total - ov_from);
-            ov_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ov_first) - args.ov_base;
-          }
+          // this wave's records take the buffer's slots [base, base + total); a region holds every bin the mask lets
+          // through, so there is no overflow path (and no global atomic)
+          ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
           while (wm) {
             const int o = __builtin_ctz(wm);  // wave-uniform
             wm &= wm - 1u;
@@ -544,13 +537,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
             if (hit) {
               const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
               const uint32_t joff = (M == 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M);
-              const ScnDevHit rec = ScnDevHit{buf, (jbase + joff) ^ (N / 2), db[o], 0u};
-              if (pos < args.hit_region) {
-                args.hits[(size_t)buf * args.hit_region + pos] = rec;
-              } else {  // region full: this wave's reserved part of the overflow list
-                const uint32_t opos = ov_first + (pos - ov_from);
-                if (opos < args.ov_cap) args.ov_hits[opos] = rec;
-              }
+              if (pos < args.hit_region) region[pos] = ScnDevHit{(jbase + joff) ^ (N / 2), db[o]};
             }
             base += (uint32_t)__popcll(m);
           }
@@ -813,14 +800,8 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
           uint32_t base = 0;
           if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
           base = __builtin_amdgcn_readfirstlane(base);
-          // slots [base, base + total) of the buffer; the part past hit_region is reserved in the overflow list with
-          // one device-scope atomic per wave (see scn_fft_kernel)
-          const uint32_t ov_from = base > args.hit_region ? base : args.hit_region;
-          uint32_t ov_first = 0;
-          if (base + total > ov_from) {
-            if (lane == 0) ov_first = atomicAdd(args.ov_counter, base + total - ov_from);
-            ov_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)ov_first) - args.ov_base;
-          }
+          // slots [base, base + total) of the buffer's region (never overflows, see scn_fft_kernel)
+          ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
           while (wm) {
             const int r = __builtin_ctz(wm);  // wave-uniform
             wm &= wm - 1u;
@@ -828,13 +809,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
             const unsigned long long m = __ballot(hit);
             if (hit) {
               const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-              const ScnDevHit rec = ScnDevHit{buf, (t + 256u * (uint32_t)r) ^ (N / 2), db[r], 0u};
-              if (pos < args.hit_region) {
-                args.hits[(size_t)buf * args.hit_region + pos] = rec;
-              } else {
-                const uint32_t opos = ov_first + (pos - ov_from);
-                if (opos < args.ov_cap) args.ov_hits[opos] = rec;
-              }
+              if (pos < args.hit_region) region[pos] = ScnDevHit{(t + 256u * (uint32_t)r) ^ (N / 2), db[r]};
             }
             base += (uint32_t)__popcll(m);
           }

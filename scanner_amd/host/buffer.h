@@ -37,9 +37,11 @@ class CopyBufferProcessInterface : public ProcessInterface<fftwf_complex> {
 class FileWriteProcessInterface : public ProcessInterface<fftwf_complex> {
   uint32_t m_count, m_expectedCount;
   FILE *m_outFile;
+  bool m_failed;
 
  public:
   explicit FileWriteProcessInterface(const char *outFileName);
+  bool Failed() const { return m_failed; }  // the file could not be created, or a write came up short
   ~FileWriteProcessInterface() override;
   void Begin(uint64_t sequenceId, uint32_t totalItemCount) override;
   void Process(const fftwf_complex *items, uint32_t count) override;

@@ -10,11 +10,12 @@ FileSource::FileSource(const std::string &path, uint32_t sampleRate, uint32_t sa
   size_t per = kind == SampleQueue::FloatComplex ? 8 : kind == SampleQueue::ByteComplex ? 2 : 4;
   m_bufferBytes = per * sampleCount;
   m_file = fopen(path.c_str(), "rb");
-  if (!m_file) {
-    fprintf(stderr, "FileSource: cannot open '%s'\n", path.c_str());
-    exit(1);  // the device sources exit(1) on open failure too (e.g. hackRFSource.cpp:19-30)
-  }
+  // (the device sources exit(1) on open failure, e.g. hackRFSource.cpp:19-30; a library reports it: Start() and
+  // StartStreaming() return false)
+  if (!m_file) fprintf(stderr, "FileSource: cannot open '%s'\n", path.c_str());
 }
+
+bool FileSource::Start() { return m_file != nullptr; }
 
 FileSource::~FileSource() {
   if (m_file) fclose(m_file);
@@ -22,7 +23,7 @@ FileSource::~FileSource() {
 
 bool FileSource::ReadOne(std::vector<unsigned char> &raw) {
   raw.resize(m_bufferBytes);
-  if (fread(raw.data(), 1, m_bufferBytes, m_file) != m_bufferBytes) return false;
+  if (!m_file || fread(raw.data(), 1, m_bufferBytes, m_file) != m_bufferBytes) return false;
   m_read++;
   return true;
 }
@@ -48,7 +49,7 @@ bool FileSource::GetNextSamples(SampleQueue *q, double_t &centerFrequency) {
 }
 
 bool FileSource::StartStreaming(uint32_t numIterations, SampleQueue &sampleQueue) {
-  return StartThread(numIterations, sampleQueue);
+  return m_file != nullptr && StartThread(numIterations, sampleQueue);
 }
 
 void FileSource::ThreadWorker() {

@@ -15,6 +15,7 @@ class FileSource : public SignalSource {
   FileSource(const std::string &path, uint32_t sampleRate, uint32_t sampleCount, double startFrequency,
              double stopFrequency, SampleQueue::SampleKind kind, double useBandWidth = 0.75, double dcIgnoreWidth = 0.0);
   ~FileSource() override;
+  bool Start() override;  // false when the file could not be opened
   bool GetNextSamples(SampleQueue *sampleQueue, double_t &centerFrequency) override;
   bool StartStreaming(uint32_t numIterations, SampleQueue &sampleQueue) override;
   void ThreadWorker() override;

@@ -3,6 +3,8 @@
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
 
 #include "../../include/scanner_hip.h"
 
@@ -12,10 +14,8 @@ FrequencyTable::FrequencyTable(uint32_t sampleRate, double startFrequency, doubl
   uint32_t count = 0, first = 0;
   int st = scn_frequency_table(sampleRate, startFrequency, stopFrequency, useBandWidth, dcIgnoreWidth, 0, 1, nullptr,
                                0, &count, &first);
-  if (st != SCN_OK) {
-    fprintf(stderr, "FrequencyTable: %s\n", scn_last_error());
-    exit(1);  // the reference asserts (frequencyTable.cpp:29)
-  }
+  // the reference asserts count > 0 (frequencyTable.cpp:29); a constructor of a library class throws instead
+  if (st != SCN_OK) throw std::invalid_argument(std::string("FrequencyTable: ") + scn_last_error());
   std::vector<double> f(count);
   scn_frequency_table(sampleRate, startFrequency, stopFrequency, useBandWidth, dcIgnoreWidth, 0, 1, f.data(), count,
                       &count, &first);

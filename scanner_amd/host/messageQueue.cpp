@@ -19,8 +19,8 @@ SampleQueue::SampleQueue(SampleKind kind, uint32_t enob, uint32_t sampleCount, u
     : m_kind(kind), m_enob(enob), m_sampleCount(sampleCount), m_bufferCount(bufferCount),
       m_correctDCOffset(correctDCOffset), m_doWrite(doWrite), m_bufferBytes(bytesPerSample(kind) * sampleCount),
       m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_nextSequenceId(0),
-      m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0), m_writeFile(nullptr),
-      m_writeActive(false), m_writeShutdown(false), m_writeNext(0) {
+      m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0),
+      m_writeShutdown(false), m_writeErrors(0) {
   assert(kind > Illegal && kind <= FloatComplex);  // messageQueue.h:163
   assert(bufferCount > 0);
   if (m_poolSize <= bufferCount) m_poolSize = bufferCount + 1;
@@ -46,7 +46,8 @@ SampleQueue::~SampleQueue() {
     }
     m_writeThread->join();
   }
-  if (m_writeFile) fclose(m_writeFile);
+  for (CaptureJob &job : m_captures)
+    if (job.file) fclose(job.file);  // only without a write thread
   for (MessageType *m : m_history) delete m;
   for (MessageType *m : m_buffer) delete m;
   for (MessageType *m : m_free) delete m;
@@ -138,9 +139,7 @@ void SampleQueue::MessageProcessed(MessageType *message) {
   if (m_history.size() >= m_historyCapacity) {
     // Back-pressure the reference lacks: the oldest message is not recycled while the capture
     // writer still has to dump it (the reference silently loses records when its ring laps the writer).
-    while (m_writeActive && !m_history.empty()) {
-      const uint64_t oldest = m_history.back()->GetHeader().m_sequenceId;
-      if (oldest < m_writeNext || oldest >= m_writeEnd) break;
+    while (!m_history.empty() && WriterNeeds(m_history.back()->GetHeader().m_sequenceId)) {
       m_writeWake.notify_one();
       m_writeDrained.wait(lock);
     }
@@ -149,20 +148,35 @@ void SampleQueue::MessageProcessed(MessageType *message) {
     Free(old);
   }
   m_history.push_front(message);
-  if (m_writeActive) m_writeWake.notify_one();  // messageQueue.h:272
+  if (!m_captures.empty()) m_writeWake.notify_one();  // messageQueue.h:272
+}
+
+bool SampleQueue::WriterNeeds(uint64_t sequenceId) const {
+  for (const CaptureJob &job : m_captures)
+    if (sequenceId >= job.next && sequenceId < job.end) return true;
+  return false;
+}
+
+void SampleQueue::SetConverter(Converter c) {
+  std::unique_lock<std::mutex> lock(m_historyMutex);
+  m_converter = c;
 }
 
 void SampleQueue::BeginWrite(uint64_t startSequenceId, std::string fileName) {
   printf("BeginWrite %s: %lu\n", fileName.c_str(), (unsigned long)startSequenceId);  // messageQueue.h:276
+  FILE *file = nullptr;
+  if (m_doWrite) {
+    file = fopen(fileName.c_str(), "w");
+    if (!file) {
+      fprintf(stderr, "Failed to open file '%s'\n", fileName.c_str());
+      m_writeErrors++;
+    }
+  }
   std::unique_lock<std::mutex> lock(m_historyMutex);
   m_writeStart = startSequenceId;
   m_writeEnd = std::numeric_limits<uint64_t>::max();
-  if (m_doWrite) {
-    if (m_writeFile) fclose(m_writeFile);
-    m_writeFile = fopen(fileName.c_str(), "w");
-    if (!m_writeFile) fprintf(stderr, "Failed to open file '%s'\n", fileName.c_str());
-    m_writeNext = startSequenceId;
-    m_writeActive = m_writeFile != nullptr;
+  if (file) {
+    m_captures.push_back(CaptureJob{file, startSequenceId, m_writeEnd});
     m_writeWake.notify_one();
   }
 }
@@ -171,12 +185,13 @@ void SampleQueue::EndWrite(uint64_t sequenceId) {
   printf("EndWrite %lu\n", (unsigned long)sequenceId);  // messageQueue.h:285
   std::unique_lock<std::mutex> lock(m_historyMutex);
   m_writeEnd = sequenceId;
+  if (!m_captures.empty()) m_captures.back().end = sequenceId;
   m_writeWake.notify_one();
 }
 
-// messageQueue.h:98-139, restated without the iterator games: write, in sequence order, every
-// processed message with id in [m_writeStart, m_writeEnd) as it reaches the history ring; close the
-// file once a message at or past the end id (or the end of the stream) shows up.
+// messageQueue.h:98-139 restated as a job loop: for the oldest queued capture write, in sequence order, every
+// processed message with an id in [next, end) as it reaches the history ring; the job is finished -- and its file
+// closed, by this thread only -- once a message at or past its end id (or the end of the stream) shows up.
 void SampleQueue::WriteThreadWorker() {
   std::vector<unsigned char> raw(m_bufferBytes);
   std::vector<float> converted(2 * (size_t)m_sampleCount);
@@ -184,15 +199,16 @@ void SampleQueue::WriteThreadWorker() {
   while (true) {
     // (the reference's writer gives up as soon as the PRODUCER is done, messageQueue.h:100-121, losing
     // whatever the consumers had not processed yet; this one runs until the queue is torn down)
-    while (!m_writeShutdown && !m_writeActive) m_writeWake.wait(lock);
-    if (!m_writeActive) break;  // shutting down, nothing being written
-    // oldest -> newest: find the first message the writer still wants
+    while (!m_writeShutdown && m_captures.empty()) m_writeWake.wait(lock);
+    if (m_captures.empty()) break;  // shutting down, nothing being written
+    CaptureJob &job = m_captures.front();
+    // oldest -> newest: find the first message this capture still wants
     MessageType *next = nullptr;
     bool pastEnd = false;
     for (auto it = m_history.rbegin(); it != m_history.rend(); ++it) {
-      uint64_t seq = (*it)->GetHeader().m_sequenceId;
-      if (seq < m_writeNext) continue;
-      if (seq >= m_writeEnd) {
+      const uint64_t seq = (*it)->GetHeader().m_sequenceId;
+      if (seq < job.next) continue;
+      if (seq >= job.end) {
         pastEnd = true;
       } else {
         next = *it;
@@ -202,31 +218,31 @@ void SampleQueue::WriteThreadWorker() {
     if (next) {
       const uint64_t seq = next->GetHeader().m_sequenceId;
       memcpy(raw.data(), next->GetRawData(), m_bufferBytes);
-      m_writeNext = seq + 1;
-      FILE *f = m_writeFile;
+      job.next = seq + 1;  // the ring may recycle the message from here on
+      FILE *const file = job.file;  // stays open: only this thread closes it, and only after this record
+      const Converter convert = m_converter;
       lock.unlock();
       printf("Writing %lu\n", (unsigned long)seq);  // messageQueue.h:125
-      const float *data = reinterpret_cast<const float *>(raw.data());
+      const void *data = raw.data();
+      size_t bytes = m_bufferBytes;
       if (m_kind != FloatComplex) {
-        if (m_converter) {
-          m_converter(raw.data(), 1, converted.data());
+        if (convert) {
+          convert(raw.data(), 1, converted.data());
           data = converted.data();
+          bytes = sizeof(fftwf_complex) * m_sampleCount;
         } else {
           fprintf(stderr, "SampleQueue: no converter installed, writing raw samples\n");
         }
       }
-      fwrite(data, m_kind != FloatComplex && !m_converter ? 1 : sizeof(fftwf_complex),
-             m_kind != FloatComplex && !m_converter ? m_bufferBytes : m_sampleCount, f);
+      if (fwrite(data, 1, bytes, file) != bytes) m_writeErrors++;
       lock.lock();
       m_writeDrained.notify_all();
       continue;
     }
-    if (pastEnd || m_writeShutdown) {  // capture complete (or the queue is going away): close the file
-      if (m_writeFile) fclose(m_writeFile);
-      m_writeFile = nullptr;
-      m_writeActive = false;
+    if (pastEnd || m_writeShutdown) {  // capture complete (or the queue is going away): close its file
+      fclose(job.file);
+      m_captures.pop_front();
       m_writeDrained.notify_all();
-      if (m_writeShutdown) break;
       continue;
     }
     m_writeWake.wait(lock);

@@ -72,8 +72,12 @@ class SampleQueue {
   // (K1 on the GPU, scn_convert_raw) that the consumer installs with SetConverter.
   void BeginWrite(uint64_t startSequenceId, std::string fileName);
   void EndWrite(uint64_t sequenceId);
+  // Captures are jobs the write thread owns: BeginWrite opens the file and queues {file, [start, end)}, EndWrite
+  // fixes the end of the newest job, and the writer alone writes to and closes each file once it has dumped the
+  // job's last record -- so a re-trigger while the previous capture is still draining (a record costs a GPU
+  // round trip for the integer formats) starts a second job instead of closing a file in use.
   typedef std::function<void(const void *raw, uint32_t nBuffers, float *out)> Converter;
-  void SetConverter(Converter c) { m_converter = c; }
+  void SetConverter(Converter c);  // install before the consumers start; the writer calls a copy taken under the lock
 
   void SetIsDone();
   bool GetIsDone();
@@ -89,6 +93,7 @@ class SampleQueue {
   uint32_t GetBufferCount() const { return m_bufferCount; }
   uint64_t GetWriteStartSequenceId() const { return m_writeStart; }
   uint64_t GetWriteEndSequenceId() const { return m_writeEnd; }
+  uint32_t GetWriteErrorCount() const { return m_writeErrors; }  // files that could not be opened / short writes
 
  private:
   void SynchronizedAppend(const void *a, size_t aBytes, const void *b, size_t bBytes, double centerFrequency,
@@ -110,14 +115,18 @@ class SampleQueue {
   uint32_t m_iterationCount;
   std::atomic<bool> m_done;
   std::atomic<bool> m_acknowledged;
-  uint64_t m_writeStart, m_writeEnd;
+  uint64_t m_writeStart, m_writeEnd;  // bounds of the newest capture (the reference's two fields, messageQueue.h:52-53)
   // write thread state (guarded by m_historyMutex)
+  struct CaptureJob {
+    FILE *file;
+    uint64_t next, end;  // the writer still owes the records with ids in [next, end)
+  };
   void WriteThreadWorker();
+  bool WriterNeeds(uint64_t sequenceId) const;  // some queued capture has not dumped this record yet
   std::unique_ptr<std::thread> m_writeThread;
   std::condition_variable m_writeWake, m_writeDrained;
-  FILE *m_writeFile;
-  bool m_writeActive;
+  std::deque<CaptureJob> m_captures;  // front = the one being written
   bool m_writeShutdown;  // set by the destructor: the consumers are gone, drain what is there and stop
-  uint64_t m_writeNext;  // next sequence id the writer wants
+  std::atomic<uint32_t> m_writeErrors;
   Converter m_converter;
 };

@@ -10,15 +10,23 @@
 
 #include "../../include/scanner_hip.h"
 
-namespace {
-void check(int st, const char *what) {
-  // the reference's device layers print and exit(1) on any library error (hackRFSource.cpp:19-30)
-  if (st != SCN_OK) {
-    fprintf(stderr, "%s failed: %s: %s\n", what, scn_error_name(st), scn_last_error());
-    exit(1);
-  }
+// The reference's device layers print and exit(1) on any library error (hackRFSource.cpp:19-30).  This is a library:
+// a failed C-ABI call is logged, remembered (GetLastError) and makes StartProcessing / Run return false.
+bool ProcessSamples::Ok(int st, const char *what) {
+  if (st == SCN_OK) return true;
+  char text[600];
+  snprintf(text, sizeof(text), "%s failed: %s: %s", what, scn_error_name(st), scn_last_error());
+  fprintf(stderr, "%s\n", text);
+  std::lock_guard<std::mutex> g(m_errorMutex);
+  if (m_error.empty()) m_error = text;
+  m_failed = true;
+  return false;
 }
-}  // namespace
+
+std::string ProcessSamples::GetLastError() {
+  std::lock_guard<std::mutex> g(m_errorMutex);
+  return m_error;
+}
 
 ProcessSamples::ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_t enob, float threshold,
                                gr::fft::window::win_type windowType, Mode mode, uint32_t threadCount,
@@ -28,26 +36,18 @@ ProcessSamples::ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_
       m_preTrigger(preTrigger), m_postTrigger(postTrigger), m_endSequenceId(0), m_writing(false), m_mode(mode),
       m_fileNameBase(fileNameBase), m_threshold(threshold), m_useBandWidth(useBandWidth), m_windowType(windowType),
       m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_firstDevice(0), m_hitCount(0),
-      m_bufferCount(0), m_convertPlan(nullptr) {
+      m_bufferCount(0), m_failed(false) {
   (void)dcIgnoreWidth;  // the reference ignores it too and hard-codes 4 bins (process.cpp:86-88)
   assert(mode > Illegal && mode <= FrequencyDomain);  // process.cpp:99
   assert(threadCount <= MAX_THREADS);                 // process.cpp:100
 }
 
-ProcessSamples::~ProcessSamples() {
-  if (m_convertPlan) scn_plan_destroy(static_cast<scn_plan *>(m_convertPlan));
-}
+ProcessSamples::~ProcessSamples() {}
 
 void ProcessSamples::TimeToString(time_t time, char *buffer, uint32_t length) {  // process.cpp:146-158
-  struct tm *t = localtime(&time);
-  if (!t) {
-    perror("localtime");
-    exit(1);
-  }
-  if (strftime(buffer, length, "%Y%m%d-%T", t) == 0) {
-    fprintf(stderr, "strftime returned 0");
-    exit(1);
-  }
+  struct tm parts;
+  if (!localtime_r(&time, &parts) || strftime(buffer, length, "%Y%m%d-%T", &parts) == 0)
+    snprintf(buffer, length, "%lld", (long long)time);  // (the reference exits; a timestamp is not worth a process)
 }
 
 std::string ProcessSamples::GenerateFileName(std::string base, time_t startTime, double_t fc) {  // :160-171
@@ -107,17 +107,22 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   d.max_batch = std::min<uint32_t>(m_maxBatch, std::max<uint32_t>(1u, q.GetBufferCount()));
   d.max_hits = d.max_batch * 64u;
   d.flags = SCN_OUT_HITS;  // the reference reports hits only; the spectra never leave the GPU
+  // a worker that cannot go on still has to empty the queue, or the producer blocks on a full one forever
+  auto abandon = [&](scn_plan *plan) {
+    if (plan) scn_plan_destroy(plan);
+    while (SampleQueue::MessageType *m = q.GetNextSamples()) q.MessageProcessed(m);
+  };
   int nDevices = 1;
-  check(scn_device_count(&nDevices), "scn_device_count");
+  if (!Ok(scn_device_count(&nDevices), "scn_device_count")) return abandon(nullptr);
   d.device_id = (m_firstDevice + (int)threadId) % nDevices;  // consumer threads spread over the node's GPUs
   scn_plan *plan = nullptr;
-  check(scn_plan_create(&d, &plan), "scn_plan_create");
+  if (!Ok(scn_plan_create(&d, &plan), "scn_plan_create")) return abandon(nullptr);
 
   unsigned char *stage[SCN_NUM_SLOTS];
   size_t stageBytes = 0, bufBytes = 0;
-  for (int s = 0; s < SCN_NUM_SLOTS; s++) check(scn_host_buffer(plan, s, (void **)&stage[s], &stageBytes), "scn_host_buffer");
-  check(scn_buffer_bytes(plan, &bufBytes), "scn_buffer_bytes");
-  assert(bufBytes == q.GetBufferBytes());
+  for (int s = 0; s < SCN_NUM_SLOTS; s++)
+    if (!Ok(scn_host_buffer(plan, s, (void **)&stage[s], &stageBytes), "scn_host_buffer")) return abandon(plan);
+  if (!Ok(scn_buffer_bytes(plan, &bufBytes), "scn_buffer_bytes") || bufBytes != q.GetBufferBytes()) return abandon(plan);
 
   std::vector<double> fc(d.max_batch);
   std::vector<uint64_t> seq(d.max_batch);
@@ -130,22 +135,25 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   double lastFrequency = 0;
 
   auto drain = [&](int s) {
-    uint32_t nHits = 0;
+    uint32_t nHits = 0, have = 0;
     int st = SCN_OK;
     if (timeDomain)
       st = scn_collect_time_domain(plan, s, tdMax.data(), tdMin.data(), trig.data());
     else
       st = scn_collect(plan, s, nullptr, hits.data(), (uint32_t)hits.size(), &nHits, trig.data());
-    if (st == SCN_E_TRUNCATED) {  // more detections than this worker buffers: report what was kept
-      fprintf(stderr, "ProcessSamples: %u hits in one batch, reporting the first %zu\n", nHits, hits.size());
-      nHits = (uint32_t)std::min<size_t>(nHits, hits.size());
-    } else {
-      check(st, "scn_collect");
-    }
+    // More detections than `hits` holds (a wideband burst: every triggered buffer alone has > 1047): the list on the
+    // GPU is complete and ordered, so the rest is fetched window by window below -- the reference prints every line.
+    bool failed = st != SCN_OK && st != SCN_E_TRUNCATED && !Ok(st, "scn_collect");
+    have = (uint32_t)std::min<size_t>(nHits, hits.size());
+    uint32_t first = 0;  // index, in the batch's ordered hit list, of hits[0]
     size_t k = 0;
     for (size_t b = 0; b < inflight[s].size(); b++) {
       SampleQueue::MessageType *m = inflight[s][b];
       SampleQueue::MessageHeader &h = m->GetHeader();
+      if (failed) {  // nothing to report for this batch; hand the message back so the producer can go on
+        q.MessageProcessed(m);
+        continue;
+      }
       if (h.m_time != 0) {  // process.cpp:280-287
         char timeBuffer[64];
         TimeToString(h.m_time, timeBuffer, sizeof(timeBuffer));
@@ -158,7 +166,16 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
                tdMin[b]);
         nHits++;
       }
-      while (!timeDomain && k < nHits && hits[k].seq_id == h.m_sequenceId) {  // hits arrive ordered by (buffer, i)
+      while (!timeDomain && first + k < nHits) {  // hits arrive ordered by (buffer, i)
+        if (k == have) {                          // window exhausted: fetch the next one
+          first += have;
+          if (!Ok(scn_collect_more(plan, s, first, hits.data(), (uint32_t)hits.size(), &have), "scn_collect_more") || !have) {
+            nHits = first;  // give up on the rest of this batch's lines
+            break;
+          }
+          k = 0;
+        }
+        if (hits[k].seq_id != h.m_sequenceId) break;
         printf("freq %lu power_db %f\n", (unsigned long)hits[k].freq_hz, hits[k].power_db);  // process.cpp:57
         k++;
       }
@@ -169,7 +186,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
       lastFrequency = h.m_frequency;
       q.MessageProcessed(m);                                  // process.cpp:309
     }
-    m_hitCount += nHits;
+    if (!failed) m_hitCount += nHits;
     m_bufferCount += inflight[s].size();
     inflight[s].clear();
     pending[s] = false;
@@ -195,8 +212,14 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
       }
     }
     if (n) {
-      check(scn_submit(plan, slot, n, fc.data(), seq.data()), "scn_submit");
-      pending[slot] = true;
+      if (Ok(scn_submit(plan, slot, n, fc.data(), seq.data()), "scn_submit")) {
+        pending[slot] = true;
+      } else {  // the GPU path is gone: hand everything back and stop consuming
+        for (SampleQueue::MessageType *m : inflight[slot]) q.MessageProcessed(m);
+        inflight[slot].clear();
+        if (pending[slot ^ 1]) drain(slot ^ 1);
+        return abandon(plan);
+      }
     }
     slot ^= 1;
   }
@@ -208,10 +231,10 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
 
 bool ProcessSamples::StartProcessing(SampleQueue &sampleQueue) {  // process.cpp:316-331
   m_sampleQueue = &sampleQueue;
-  // Triggered capture writes converted samples (fftwf_complex records); the queue holds raw ones,
-  // so give it K1 on the GPU through a small dedicated plan.
-  scn_plan *convertPlan = nullptr;
-  std::mutex convertMutex;
+  // Triggered capture writes converted samples (fftwf_complex records); the queue holds raw ones, so give it K1
+  // on the GPU through a small dedicated plan.  The converter is installed once, before any thread can call it,
+  // and OWNS what it uses (plan and lock are shared_ptr captures): the queue's write thread may still be
+  // converting its last records after this function has returned and after this object is gone.
   if (m_fileNameBase != "" && sampleQueue.m_kind != SampleQueue::FloatComplex) {
     scn_plan_desc d;
     memset(&d, 0, sizeof(d));
@@ -225,10 +248,17 @@ bool ProcessSamples::StartProcessing(SampleQueue &sampleQueue) {  // process.cpp
     d.threshold = m_threshold;
     d.max_batch = 1;
     d.device_id = m_firstDevice;
-    check(scn_plan_create(&d, &convertPlan), "scn_plan_create");
-    sampleQueue.SetConverter([convertPlan, &convertMutex](const void *raw, uint32_t n, float *out) {
-      std::lock_guard<std::mutex> g(convertMutex);
-      check(scn_convert_raw(convertPlan, raw, n, out), "scn_convert_raw");
+    scn_plan *raw = nullptr;
+    if (!Ok(scn_plan_create(&d, &raw), "scn_plan_create")) return false;
+    std::shared_ptr<scn_plan> plan(raw, [](scn_plan *p) { scn_plan_destroy(p); });
+    std::shared_ptr<std::mutex> lock = std::make_shared<std::mutex>();
+    const uint32_t n = m_sampleCount;
+    sampleQueue.SetConverter([plan, lock, n](const void *in, uint32_t nBuffers, float *out) {
+      std::lock_guard<std::mutex> g(*lock);
+      if (scn_convert_raw(plan.get(), in, nBuffers, out) != SCN_OK) {
+        fprintf(stderr, "scn_convert_raw failed: %s\n", scn_last_error());
+        memset(out, 0, sizeof(float) * 2 * (size_t)n * nBuffers);  // keep the record layout of the capture file
+      }
     });
   }
   std::vector<std::thread> threads;
@@ -240,19 +270,11 @@ bool ProcessSamples::StartProcessing(SampleQueue &sampleQueue) {  // process.cpp
     threads[t].join();
     printf("Stopped process thread %u\n", t);
   }
-  if (convertPlan) {
-    // the write thread may still be converting its last records: the queue's destructor joins it
-    // before the plan could be needed again, so hand the plan's lifetime to the converter
-    sampleQueue.SetConverter([convertPlan](const void *raw, uint32_t n, float *out) {
-      check(scn_convert_raw(convertPlan, raw, n, out), "scn_convert_raw");
-    });
-    m_convertPlan = convertPlan;
-  }
-  return true;
+  return !m_failed;
 }
 
-void ProcessSamples::Run(int16_t sample_buffer[][2], uint32_t centerFrequency) {
-  if (m_mode != FrequencyDomain) return;  // process.cpp:138
+bool ProcessSamples::Run(int16_t sample_buffer[][2], uint32_t centerFrequency) {
+  if (m_mode != FrequencyDomain) return true;  // process.cpp:138
   scn_plan_desc d;
   memset(&d, 0, sizeof(d));
   d.struct_size = sizeof(d);
@@ -269,19 +291,24 @@ void ProcessSamples::Run(int16_t sample_buffer[][2], uint32_t centerFrequency) {
   d.flags = SCN_OUT_HITS;
   d.device_id = m_firstDevice;
   scn_plan *plan = nullptr;
-  check(scn_plan_create(&d, &plan), "scn_plan_create");
+  if (!Ok(scn_plan_create(&d, &plan), "scn_plan_create")) return false;
   void *stage = nullptr;
   size_t bytes = 0;
-  check(scn_host_buffer(plan, 0, &stage, &bytes), "scn_host_buffer");
-  memcpy(stage, sample_buffer, sizeof(int16_t) * 2 * m_sampleCount);
-  double fc = centerFrequency;
-  check(scn_submit(plan, 0, 1, &fc, nullptr), "scn_submit");
   std::vector<scn_hit> hits(m_sampleCount);
   uint32_t nHits = 0;
-  check(scn_collect(plan, 0, nullptr, hits.data(), (uint32_t)hits.size(), &nHits, nullptr), "scn_collect");
-  for (uint32_t k = 0; k < nHits; k++)
-    printf("freq %lu power_db %f\n", (unsigned long)hits[k].freq_hz, hits[k].power_db);
-  m_hitCount += nHits;
-  m_bufferCount += 1;
+  double fc = centerFrequency;
+  bool ok = Ok(scn_host_buffer(plan, 0, &stage, &bytes), "scn_host_buffer");
+  if (ok) {
+    memcpy(stage, sample_buffer, sizeof(int16_t) * 2 * m_sampleCount);
+    ok = Ok(scn_submit(plan, 0, 1, &fc, nullptr), "scn_submit") &&
+         Ok(scn_collect(plan, 0, nullptr, hits.data(), (uint32_t)hits.size(), &nHits, nullptr), "scn_collect");
+  }
+  if (ok) {
+    for (uint32_t k = 0; k < nHits; k++)
+      printf("freq %lu power_db %f\n", (unsigned long)hits[k].freq_hz, hits[k].power_db);
+    m_hitCount += nHits;
+    m_bufferCount += 1;
+  }
   scn_plan_destroy(plan);
+  return ok;
 }

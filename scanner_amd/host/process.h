@@ -9,6 +9,8 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,8 +34,11 @@ class ProcessSamples {
 
   // One-shot on a single int16 buffer (process.cpp:131-144).  Unlike the reference -- where
   // this dereferences a null header -- it reports against the given centre frequency.
-  void Run(int16_t sample_buffer[][2], uint32_t centerFrequency);
-  bool StartProcessing(SampleQueue &sampleQueue);  // blocks until the queue is done and drained
+  // Returns false when the GPU path failed (the reference's void return is still source compatible at its call sites).
+  bool Run(int16_t sample_buffer[][2], uint32_t centerFrequency);
+  // Blocks until the queue is done and drained; false if a worker had to give up (GetLastError says why).
+  bool StartProcessing(SampleQueue &sampleQueue);
+  std::string GetLastError();
 
   // knobs the reference hard-codes; set before StartProcessing
   void SetMaxBatch(uint32_t maxBatch) { m_maxBatch = maxBatch; }
@@ -50,6 +55,7 @@ class ProcessSamples {
   void WriteSamplesToFile(uint64_t sequenceId, double centerFrequency);
   void UpdateEndSequenceId(uint64_t newEndSequenceId);
   void ProcessWrite(bool doWrite, double centerFrequency, uint64_t sequenceId);
+  bool Ok(int status, const char *what);  // logs and remembers the first failed C-ABI call
 
   static const uint32_t MAX_THREADS = 8;  // process.h:49
   uint32_t m_sampleCount, m_sampleRate, m_enob;
@@ -66,5 +72,7 @@ class ProcessSamples {
   uint32_t m_maxBatch;
   int m_firstDevice;
   std::atomic<uint64_t> m_hitCount, m_bufferCount;
-  void *m_convertPlan;  // scn_plan used by the capture writer (K1 on the GPU); outlives StartProcessing
+  std::atomic<bool> m_failed;
+  std::mutex m_errorMutex;
+  std::string m_error;
 };

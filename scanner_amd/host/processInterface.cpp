@@ -17,12 +17,12 @@ void CopyBufferProcessInterface::End() {
 }
 
 FileWriteProcessInterface::FileWriteProcessInterface(const char *name)
-    : ProcessInterface(true), m_count(0), m_expectedCount(0), m_outFile(nullptr) {
+    : ProcessInterface(true), m_count(0), m_expectedCount(0), m_outFile(nullptr), m_failed(false) {
   if (name) {
     m_outFile = fopen(name, "w");
-    if (!m_outFile) {
-      fprintf(stderr, "Error opening file '%s'\n", name);
-      exit(1);
+    if (!m_outFile) {  // (processInterface.cpp:20-23 exits; here the visitor reports it through Failed())
+      fprintf(stderr, "FileWriteProcessInterface: cannot create '%s'\n", name);
+      m_failed = true;
     }
   }
 }
@@ -31,10 +31,7 @@ FileWriteProcessInterface::~FileWriteProcessInterface() {
 }
 void FileWriteProcessInterface::Begin(uint64_t, uint32_t total) { m_expectedCount = total; }
 void FileWriteProcessInterface::Process(const fftwf_complex *items, uint32_t count) {
-  if (m_outFile && fwrite(items, sizeof(fftwf_complex), count, m_outFile) != count) {
-    fprintf(stderr, "Error writing to file\n");
-    exit(1);
-  }
+  if (m_outFile && fwrite(items, sizeof(fftwf_complex), count, m_outFile) != count) m_failed = true;  // short write
   m_count += count;
 }
 void FileWriteProcessInterface::End() {

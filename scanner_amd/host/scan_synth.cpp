@@ -76,7 +76,7 @@ int main(int argc, char **argv) {
 
   SyntheticSource source(fs, n, start, stop, kind, seed, sigma);
   for (auto &e : emitters) source.AddEmitter(e.frequency, e.amplitude);
-  if (!dump.empty()) source.SetDumpFile(dump);
+  if (!dump.empty() && !source.SetDumpFile(dump)) return 1;
   source.SetBurst(burstFirst, burstLast, burstGain);
   if (sweepBlocks) source.SetSweepFraming(sweepBlocks, scanOffset);  // HackRF sweep-mode transfers
 
@@ -87,10 +87,13 @@ int main(int argc, char **argv) {
   SampleQueue sampleQueue(kind, enob, n, depth, correctDC, outFile != "");  // scan.cpp:223
 
   // scan.cpp:234-238 (the source delivers numIterations+1 sweeps: the first one is the queue's warm-up discard)
-  source.Start();
-  source.StartStreaming(iterations + 1, sampleQueue);
-  process.StartProcessing(sampleQueue);
+  if (!source.Start() || !source.StartStreaming(iterations + 1, sampleQueue)) {
+    sampleQueue.SetIsDone();
+    return 1;
+  }
+  const bool ok = process.StartProcessing(sampleQueue);
   source.StopStreaming();
+  if (!ok) fprintf(stderr, "scan_synth: %s\n", process.GetLastError().c_str());
   fprintf(stderr, "buffers %lu hits %lu\n", (unsigned long)process.GetBufferCount(), (unsigned long)process.GetHitCount());
-  return 0;
+  return ok ? 0 : 1;
 }

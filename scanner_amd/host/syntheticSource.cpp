@@ -29,12 +29,11 @@ SyntheticSource::~SyntheticSource() {
   if (m_dump) fclose(m_dump);
 }
 
-void SyntheticSource::SetDumpFile(const std::string &path) {
+bool SyntheticSource::SetDumpFile(const std::string &path) {
+  if (m_dump) fclose(m_dump);
   m_dump = fopen(path.c_str(), "wb");
-  if (!m_dump) {
-    fprintf(stderr, "SyntheticSource: cannot open dump file '%s'\n", path.c_str());
-    exit(1);
-  }
+  if (!m_dump) fprintf(stderr, "SyntheticSource: cannot open dump file '%s'\n", path.c_str());
+  return m_dump != nullptr;
 }
 
 void SyntheticSource::GenerateN(double fc, uint64_t bufferIndex, void *raw, const uint32_t n) {
@@ -126,6 +125,13 @@ bool SyntheticSource::GetNextSamples(SampleQueue *q, double_t &centerFrequency) 
 }
 
 bool SyntheticSource::StartStreaming(uint32_t numIterations, SampleQueue &sampleQueue) {
+  if (m_sweepBlocks) {  // hackRFSource.cpp:254: a transfer is a whole number of buffers
+    const uint32_t count = m_sweepBlocks * 8192u;
+    if (m_kind != SampleQueue::ByteComplex || count < m_sampleCount || count % m_sampleCount) {
+      fprintf(stderr, "SyntheticSource: sweep framing needs byte IQ and a transfer that is a multiple of the buffer\n");
+      return false;
+    }
+  }
   return StartThread(numIterations, sampleQueue);
 }
 
@@ -155,10 +161,6 @@ void SyntheticSource::ThreadWorker() {
 // every one of them carrying the scan-start time when the transfer opened a sweep.
 void SyntheticSource::SweepWorker() {
   const uint32_t count = m_sweepBlocks * 8192u;
-  if (m_kind != SampleQueue::ByteComplex || count < m_sampleCount || count % m_sampleCount) {  // :254
-    fprintf(stderr, "SyntheticSource: sweep framing needs byte IQ and a transfer that is a multiple of the buffer\n");
-    exit(1);
-  }
   std::vector<uint8_t> transfer(2u * (size_t)count);
   Retune(GetCurrentFrequency());
   while (!GetIsDone() && !m_finished) {
@@ -173,9 +175,10 @@ void SyntheticSource::SweepWorker() {
     }
     double centerFrequency = 0;
     int st = scn_hackrf_sweep_fixup(transfer.data(), 2u * count, m_scanOffset, &centerFrequency, nullptr);
-    if (st != SCN_OK) {
+    if (st != SCN_OK) {  // cannot happen for a well-formed transfer; end the stream rather than the process
       fprintf(stderr, "scn_hackrf_sweep_fixup: %s: %s\n", scn_error_name(st), scn_last_error());
-      exit(1);
+      SetIsDone();
+      break;
     }
     time_t startTime = (time_t)(86400 + GetIterationCount());
     double next = GetNextFrequency();

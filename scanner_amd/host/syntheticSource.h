@@ -28,7 +28,7 @@ class SyntheticSource : public SignalSource {
   void SetBurst(uint64_t first, uint64_t last, double gain) { m_burstFirst = first; m_burstLast = last; m_burstGain = gain; }
   // Also append every generated raw buffer (queue order, including the discarded warm-up
   // sweep) to this file, so a test can replay the exact bytes through the CPU oracle.
-  void SetDumpFile(const std::string &path);
+  bool SetDumpFile(const std::string &path);  // false if the file cannot be created
   // HackRF sweep-mode framing (hackRFSource.cpp:186-270), ByteComplex only: every tune delivers ONE
   // transfer of blocksPerTransfer x 8192 samples whose blocks start with the firmware's in-band header
   // (0x7F 0x7F + tuned frequency, little-endian u64); the worker runs scn_hackrf_sweep_fixup on it and

@@ -119,7 +119,9 @@ class Plan:
 
     def collect(self, slot, want_power=True, want_hits=True, hit_cap=None):
         """Block on the slot and return (power_db [B,n] | None, hits (HIT_DTYPE) | None, trigger uint8[B] | None).
-        Raises ScannerError(E_TRUNCATED) when more hits exist than hit_cap / the plan's max_hits."""
+        The hit list arrives ordered by (buffer, i) and complete from the GPU.  With hit_cap=None every hit is returned
+        however many there are (the part beyond the plan's pinned list is fetched with scn_collect_more); with an
+        explicit hit_cap the C-ABI's own behaviour shows: ScannerError(E_TRUNCATED) when more hits exist."""
         nb = self._nb[slot]
         have_hits = bool(self.flags & capi.OUT_HITS)
         power = np.empty((nb, self.n), np.float32) if (want_power and self.flags & capi.OUT_SPECTRUM) else None
@@ -132,14 +134,36 @@ class Plan:
         st = self._L.scn_collect(self._h, slot, vp(power), vp(hits), cap if want_hits else 0, C.byref(n_hits),
                                  vp(trig))
         self._keep[slot] = None
-        if st == capi.E_TRUNCATED and want_hits and hit_cap is None:
-            # grow once to the true total and report everything the device kept
-            raise capi.ScannerError(st, "scn_collect", f"{n_hits.value} hits exceed capacity {cap}")
-        capi.check(st, "scn_collect")
         self.last_n_hits = n_hits.value
+        if st == capi.E_TRUNCATED and want_hits and hit_cap is None:
+            hits = self.collect_more(slot, 0, n_hits.value)
+            st = capi.OK
+        capi.check(st, "scn_collect")
         if want_hits:
-            hits = hits[: min(n_hits.value, cap)]
+            hits = hits[: min(n_hits.value, len(hits))]
         return power, hits, trig
+
+    def collect_more(self, slot, first, count):
+        """Records [first, first+count) of the ordered hit list of the slot's last collected submit (scn_collect_more)."""
+        out = np.zeros(count, capi.HIT_DTYPE)
+        done = 0
+        while done < count:
+            got = C.c_uint32()
+            capi.check(self._L.scn_collect_more(self._h, slot, first + done, out[done:].ctypes.data_as(C.c_void_p),
+                                                count - done, C.byref(got)), "scn_collect_more")
+            if not got.value:
+                break
+            done += got.value
+        return out[:done]
+
+    def hits_view(self, slot):
+        """Zero-copy numpy view of the plan's pinned ordered hit list (valid until the slot's next submit)."""
+        ptr, n = C.c_void_p(), C.c_uint32()
+        capi.check(self._L.scn_hits_view(self._h, slot, C.byref(ptr), C.byref(n)), "scn_hits_view")
+        if not n.value:
+            return np.zeros(0, capi.HIT_DTYPE)
+        raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n.value * capi.HIT_DTYPE.itemsize,))
+        return raw.view(capi.HIT_DTYPE)
 
     def collect_time_domain(self, slot):
         """Time-domain plans: (max_db float32[B], min_db float32[B], above uint8[B]) -- process.cpp:203-237."""

@@ -1,11 +1,15 @@
 """Multi-GPU sweep plumbing: the frequency table (frequencyTable.cpp:9-37) is range-sharded
 over ranks -- rank r of R owns the contiguous centre-frequency indices
 [floor(C*r/R), floor(C*(r+1)/R)) -- every buffer is independent, so the data path needs no
-collective.  Only the final hit list is gathered (RCCL over xGMI when the process group's
-backend is "nccl"; gloo on CPU for tests): one all_gather of counts, one padded gather of
-24-byte scn_hit records to the destination rank.  Because shards are contiguous,
-rank-major concatenation is already the global (centre index, i) order.
+collective.  Only the final hit list is gathered, by the C-ABI's scn_gather_hits (RCCL over xGMI:
+ncclAllGather of the counts + one group of ncclSend/ncclRecv to the root, scn_gather.hip).
+torch.distributed is used for ONE thing on that path: handing rank 0's 128-byte RCCL rendezvous id to
+the other ranks.  On CPU (the gloo tests) the same gather runs over torch.distributed with the layout
+computed by the C-ABI's scn_gather_layout.  Because shards are contiguous, rank-major concatenation is
+already the global (centre index, i) order.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import capi
@@ -16,26 +20,102 @@ def shard_range(count, rank, world):
     return (count * rank) // world, (count * (rank + 1)) // world
 
 
-def gather_hits(hits, device, group=None, dst=0):
-    """Gather every rank's (already ordered) scn_hit array to `dst`.
-    Returns the concatenated array on dst, an empty array elsewhere."""
-    import torch
-    import torch.distributed as dist
+class HitGather:
+    """The sweep's communicator: scn_comm (RCCL) on a GPU, torch.distributed (gloo) on CPU."""
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    hits = np.ascontiguousarray(hits, dtype=capi.HIT_DTYPE)
-    cnt = torch.tensor([len(hits)], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
-    width = max(max(counts), 1) * capi.HIT_DTYPE.itemsize
-    buf = torch.zeros(width, dtype=torch.uint8, device=device)
-    if len(hits):
-        buf[: hits.nbytes] = torch.from_numpy(hits.view(np.uint8).reshape(-1).copy()).to(device)
-    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, out, dst=dst, group=group)
-    if rank != dst:
-        return np.zeros(0, capi.HIT_DTYPE)
-    parts = [out[r][: counts[r] * capi.HIT_DTYPE.itemsize].cpu().numpy().view(capi.HIT_DTYPE) for r in range(world)]
-    return np.concatenate(parts) if parts else np.zeros(0, capi.HIT_DTYPE)
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device = device
+        self._comm = None
+        if device is not None and torch.device(device).type == "cuda":
+            L = capi.lib()
+            uid = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8)
+            if self.rank == 0:
+                buf = (C.c_uint8 * capi.COMM_ID_BYTES)()
+                capi.check(L.scn_comm_unique_id(buf), "scn_comm_unique_id")
+                uid = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            if self.world > 1:
+                obj = [uid.numpy().tobytes()]
+                dist.broadcast_object_list(obj, src=0, group=group)  # 128 bytes through the launcher's store
+                uid = torch.frombuffer(bytearray(obj[0]), dtype=torch.uint8)
+            raw = (C.c_uint8 * capi.COMM_ID_BYTES).from_buffer_copy(uid.numpy().tobytes())
+            h = C.c_void_p()
+            capi.check(L.scn_comm_create(raw, self.rank, self.world, torch.device(device).index or 0, C.byref(h)),
+                       "scn_comm_create")
+            self._comm = h
+
+    def close(self):
+        if self._comm:
+            capi.lib().scn_comm_destroy(self._comm)
+            self._comm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def gather(self, hits, dst=0):
+        """Every rank passes its ordered scn_hit array; returns (all hits on dst / empty elsewhere, per-rank counts)."""
+        hits = np.ascontiguousarray(hits, dtype=capi.HIT_DTYPE)
+        if self._comm:
+            return self._gather_rccl(hits, dst)
+        return self._gather_torch(hits, dst)
+
+    def _gather_rccl(self, hits, dst):
+        L = capi.lib()
+        total = C.c_uint64()
+        per_rank = np.zeros(self.world, np.uint32)
+        # first call learns the total (all == NULL), the root then receives into an exact-size array
+        out = None
+        vp = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        if self.rank == dst:
+            # counts are only known after the all-gather inside the call: size for the worst case cheaply by asking twice
+            st = L.scn_gather_hits(self._comm, vp(hits), len(hits), dst, None, 0, C.byref(total),
+                                   per_rank.ctypes.data_as(C.c_void_p))
+            capi.check(st, "scn_gather_hits")
+            out = np.zeros(total.value, capi.HIT_DTYPE)
+            st = L.scn_gather_hits(self._comm, vp(hits), len(hits), dst, vp(out), out.size, C.byref(total),
+                                   per_rank.ctypes.data_as(C.c_void_p))
+            capi.check(st, "scn_gather_hits")
+            return out, per_rank
+        for _ in range(2):
+            capi.check(L.scn_gather_hits(self._comm, vp(hits), len(hits), dst, None, 0, C.byref(total),
+                                         per_rank.ctypes.data_as(C.c_void_p)), "scn_gather_hits")
+        return np.zeros(0, capi.HIT_DTYPE), per_rank
+
+    def _gather_torch(self, hits, dst):
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return hits, np.array([len(hits)], np.uint32)
+        dev = self.device or "cpu"
+        cnt = torch.tensor([len(hits)], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(cnt) for _ in range(self.world)]
+        dist.all_gather(counts, cnt, group=self.group)
+        per_rank = np.array([int(c.item()) for c in counts], np.uint32)
+        off = capi.gather_layout(per_rank)
+        width = max(int(per_rank.max()), 1) * capi.HIT_DTYPE.itemsize
+        buf = torch.zeros(width, dtype=torch.uint8, device=dev)
+        if len(hits):
+            buf[: hits.nbytes] = torch.from_numpy(hits.view(np.uint8).reshape(-1).copy()).to(dev)
+        out = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == dst else None
+        dist.gather(buf, out, dst=dst, group=self.group)
+        if self.rank != dst:
+            return np.zeros(0, capi.HIT_DTYPE), per_rank
+        all_hits = np.zeros(int(off[-1]), capi.HIT_DTYPE)
+        for r in range(self.world):
+            all_hits[int(off[r]):int(off[r + 1])] = out[r][: int(per_rank[r]) * capi.HIT_DTYPE.itemsize].cpu().numpy().view(capi.HIT_DTYPE)
+        return all_hits, per_rank
+
+
+def gather_hits(hits, device, group=None, dst=0):
+    """One-shot form: gather every rank's (already ordered) scn_hit array to `dst`."""
+    with HitGather(device, group) as g:
+        return g.gather(hits, dst)[0]

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -191,7 +192,91 @@ static void test_file_source() {
   remove(path);
 }
 
+// Triggered capture as a queue of jobs the writer owns: a second BeginWrite while the first capture is still
+// draining (the converter is slow: a GPU round trip per record for the integer formats) must neither close the
+// file in use nor lose the first capture's tail; both files end up complete, each closed by the writer.
+static std::vector<float> read_floats(const char *path) {
+  std::vector<float> v;
+  if (FILE *f = fopen(path, "rb")) {
+    float x;
+    while (fread(&x, sizeof x, 1, f) == 1) v.push_back(x);
+    fclose(f);
+  }
+  return v;
+}
+
+static void test_capture_retrigger_while_draining() {
+  const uint32_t n = 8;
+  const char *a = "/tmp/scn_capture_a.bin", *b = "/tmp/scn_capture_b.bin";
+  {
+    SampleQueue q(SampleQueue::ShortComplex, 12, n, 16, false, /*doWrite=*/true);
+    std::atomic<uint32_t> converted(0);
+    q.SetConverter([&](const void *raw, uint32_t nb, float *out) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(5));  // slower than the consumer below
+      const int16_t *s = static_cast<const int16_t *>(raw);
+      for (uint32_t i = 0; i < 2 * n * nb; i++) out[i] = (float)s[i];
+      converted += nb;
+    });
+    int16_t buf[n][2];
+    auto push = [&](int tag, time_t t) {
+      for (uint32_t i = 0; i < n; i++) buf[i][0] = buf[i][1] = (int16_t)tag;
+      q.AppendSamples(buf, 1e6, t);
+    };
+    push(-1, 1);  // warm-up sweep, discarded
+    auto feed = [&](int tag, time_t t) {  // produce + consume one message (sequence id == tag)
+      push(tag, t);
+      SampleQueue::MessageType *m = q.GetNextSamples();
+      CHECK(m && m->GetHeader().m_sequenceId == (uint64_t)tag);
+      q.MessageProcessed(m);
+    };
+    feed(0, 2);
+    feed(1, 0);
+    q.BeginWrite(0, a);  // capture A: ids [0, 4)
+    feed(2, 0);
+    feed(3, 0);
+    q.EndWrite(4);
+    feed(4, 0);
+    q.BeginWrite(3, b);  // re-trigger at once, pre-trigger reaches back into A: ids [3, 7); A is still draining
+    CHECK(converted < 4);
+    feed(5, 0);
+    feed(6, 0);
+    q.EndWrite(7);
+    feed(7, 0);
+    q.SetIsDone();
+    CHECK(q.GetWriteErrorCount() == 0);
+  }  // ~SampleQueue joins the writer
+  std::vector<float> fa = read_floats(a), fb = read_floats(b);
+  CHECK(fa.size() == 4 * 2 * n && fb.size() == 4 * 2 * n);
+  for (size_t k = 0; k < fa.size() && fa.size() == 4 * 2 * n; k++) CHECK(fa[k] == (float)(k / (2 * n)));
+  for (size_t k = 0; k < fb.size() && fb.size() == 4 * 2 * n; k++) CHECK(fb[k] == (float)(3 + k / (2 * n)));
+  remove(a);
+  remove(b);
+}
+
+// errors are reported, not exit(1): a library must leave that decision to its caller
+static void test_failures_are_reported() {
+  FileSource missing("/nonexistent/dir/iq.bin", 8000000, 64, 88e6, 100e6, SampleQueue::ShortComplex);
+  SampleQueue q(SampleQueue::ShortComplex, 12, 64, 4, false, false);
+  CHECK(!missing.Start() && !missing.StartStreaming(1, q));
+  FileWriteProcessInterface w("/nonexistent/dir/out.bin");
+  CHECK(w.Failed());
+  SyntheticSource src(8000000, 64, 88e6, 100e6, SampleQueue::ShortComplex);
+  CHECK(!src.SetDumpFile("/nonexistent/dir/dump.bin"));
+  src.SetSweepFraming(1, 0);  // sweep framing needs byte IQ
+  CHECK(!src.StartStreaming(1, q));
+  bool threw = false;
+  try {
+    FrequencyTable bad(8000000, 0.0, 1e9, 0.0, 0.0, true);  // zero step
+  } catch (const std::invalid_argument &) {
+    threw = true;
+  }
+  CHECK(threw);
+  q.SetIsDone();
+}
+
 int main() {
+  test_capture_retrigger_while_draining();
+  test_failures_are_reported();
   test_queue_basic();
   test_queue_blocking_and_recycle();
   test_queue_kinds();

@@ -31,6 +31,18 @@ def test_host_classes_cpu(host_build, tmp_path):
     assert "host cpu tests ok" in out.stdout
 
 
+def test_reference_style_subclass_compiles_and_runs(host_build, tmp_path):
+    """SignalSource keeps the protected state the reference's device classes use by name (signalSource.h:11-43;
+    bladerfSource.cpp:91-99 walks this->m_frequencyTable): a front-end written that way builds and streams."""
+    exe = tmp_path / "subclass_compat"
+    subprocess.check_call(["g++", "-std=gnu++11", "-O1", "-g", "-Wall", "-Werror", "-pthread", "-I", HOST,
+                           os.path.join(ROOT, "tests", "cpp", "test_subclass_compat.cpp"), "-o", str(exe),
+                           "-L" + os.path.join(ROOT, "scanner_amd"), "-lscanner_host", "-lscanner_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "scanner_amd")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, cwd=tmp_path)
+    assert out.returncode == 0 and "-> ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("san", ["thread", "address,undefined"])
 def test_host_classes_under_sanitizers(host_build, tmp_path, san):
     """CPU-only sanitizer runs of the queue / buffer / source classes (the reference ships none and has a

@@ -16,8 +16,14 @@ contiguous range of the frequency table (its own batch: weak scaling, no data-pa
 collective); the final hit list is gathered to rank 0 once, after the timed region.
 
   python bench.py                                   # 1 GPU
+  python bench.py --gpus 8                          # launches itself: a parent that never touches the GPU spawns
+                                                    # `python -m torch.distributed.run ... bench.py --gpus 8` and forwards
+                                                    # the one JSON line (non-zero exit if any rank fails)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-         --master-port 29500 bench.py --gpus 8
+         --master-port 29500 bench.py --gpus 8      # what the parent runs (and what the driver may run itself)
+  python bench.py --config c4 --gpus 8              # BASELINE config 4: 16384 centres x 4096-pt, 16384/N per rank
+                                                    # (strong scaling), planted emitters, gathered list checked on rank 0
+  python bench.py --gpus 2 --dry-run                # CPU/gloo run of the launcher, sharding, gather and JSON plumbing
 """
 import argparse
 import json
@@ -55,6 +61,18 @@ def parse():
     ap.add_argument("--no-overlap-leg", action="store_true",
                     help="skip the extra leg that times the same steps on a plan with SCN_PLAN_OVERLAP_SLOTS "
                          "(reported separately under \"overlap\"; value / roofline are always the single-stream plan)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="c2 (default): --batch buffers per GPU, weak scaling.  c4: BASELINE config 4, the full frequency table "
+                         "FrequencyTable(8e6, 0, 16384*6e6) sharded 16384/N per rank (strong scaling), one 4096-pt cfloat buffer "
+                         "per centre, emitters planted at known absolute frequencies, a step = one sweep of the rank's shard, "
+                         "the gathered hit list is compared with the computed expectation on rank 0")
+    ap.add_argument("--centres", type=int, default=16384, help="c4: number of centre frequencies in the table")
+    ap.add_argument("--no-records-leg", action="store_true",
+                    help="skip the extra leg that times the same steps with the ordered hit records fetched every step")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: every rank (gloo) shards the table, fabricates its shard's expected hit list, the list is "
+                         "gathered and checked on rank 0 -- exercises the launcher, rendezvous, sharding, gather and the JSON line")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0: pick a free one)")
     ap.add_argument("--welch", action="store_true", help="BASELINE config C5: streaming 65536-pt 50%%-overlap Welch PSD")
     ap.add_argument("--welch-psd", type=int, default=8, help="PSDs per submit (K=16 segments each)")
     ap.add_argument("--welch-pinned", action="store_true", help="feed from pinned host memory through the captured hipGraph")
@@ -216,50 +234,180 @@ def emit(obj):
         os.write(_RESULT_FD, line)
 
 
-def main():
-    args = parse()
-    claim_stdout()
-    if args.welch:
-        return welch_main(args)
-    import torch
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_self(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process becomes a parent that never touches
+    the GPU (it does not even import torch), starts one rank per GPU through torch.distributed.run, forwards the single
+    JSON line rank 0 prints and exits non-zero if any rank failed."""
+    import subprocess
+
+    port = args.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(f"bench.py launcher: torch.distributed.run exited {proc.returncode} with {len(lines)} result line(s)\n")
+        sys.stderr.write(proc.stdout[-4000:])
+        sys.exit(proc.returncode or 1)
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    sys.exit(0)
+
+
+def compare_hit_lists(got, want, power_tol=0.15):
+    ok = len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in ("seq_id", "i", "freq_hz"))
+    worst = float(np.abs(got["power_db"].astype(np.float64) - want["power_db"]).max()) if ok and len(got) else None
+    return bool(ok and (worst is None or worst <= power_tol)), worst
+
+
+def dist_setup(args, backend):
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    return dist, rank, local_rank, world
+
+
+def dry_run_main(args):
+    """CPU / gloo: everything of the N > 1 path except the kernels.  Every rank takes its shard of the C4 table, writes
+    down the hits the planted emitters of its shard must give (the closed form the GPU run is checked against), the
+    lists are gathered (the layout comes from the C-ABI's scn_gather_layout) and rank 0 checks the concatenation."""
+    import torch
+    import torch.distributed as dist
+
+    from scanner_amd import capi, sweep
+
+    _, rank, _, world = dist_setup(args, "gloo")
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n, n_centres = 4096, args.centres
+    _, fc_all = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0)
+    first, fc = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
+    lo, hi = sweep.shard_range(n_centres, rank, world)
+    assert (first, first + len(fc)) == (lo, hi) and np.array_equal(fc, fc_all[lo:hi])
+    from scanner_amd import synth
+
+    centres, i0 = synth.c4_emitters(n_centres, n)
+    want = synth.c4_expected_hits(synth.blackman_harris(n), fc_all, centres, i0, n, FS, args.threshold)
+    mine = want[(want["seq_id"] >= lo) & (want["seq_id"] < hi)]
+    t0 = time.perf_counter()
+    with sweep.HitGather(torch.device("cpu")) as g:
+        got, per_rank = g.gather(mine)
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
+        ok, _ = compare_hit_lists(got, want, power_tol=0.0)
+        emit({"metric": "Msamples/s (complex samples through convert->window->FFT->dB->threshold)", "value": 0.0,
+              "unit": "Msamples/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": round(elapsed * 1e3, 3),
+              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "dry_run": True,
+              "config": {"workload": f"DRY RUN on CPU (gloo), no kernels: C4 table of {n_centres} centres sharded over {world} "
+                                     f"rank(s), planted-emitter hit lists gathered to rank 0", "n": n, "centres": n_centres},
+              "c4_check": {"expected_hits": int(len(want)), "gathered_hits": int(len(got)), "match": ok,
+                           "per_rank": [int(c) for c in per_rank]}})
+        if not ok:
+            sys.exit(3)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def kernel_name(n, kind, hits=True):
+    k = {"cfloat": "SCN_K_FLOAT_COMPLEX", "int16": "SCN_K_SHORT_COMPLEX", "int8": "SCN_K_BYTE_COMPLEX"}[kind]
+    h = "true" if hits else "false"
+    if n == 8192:
+        return f"scn_fft8k_kernel<{k}, false, {h}>"
+    if n == 16384:
+        return f"scn_fft16k_kernel<{k}, false, {h}>"
+    return f"scn_fft_kernel<{n // 256}, {k}, false, {h}>"
+
+
+def tracked_profile(n, kind, nb):
+    """Numbers that come from their own rocprofv3 passes (scripts/prof.sh -> profiles/measured_shapes.json): the PMC
+    traffic per launch and the kernel-trace average duration; only valid for the launch shape they were collected on."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "measured_shapes.json")))
+        return j.get(f"{n}/{kind}/{nb}", {})
+    except Exception:
+        return {}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_self(args)
+    claim_stdout()
+    if args.dry_run:
+        return dry_run_main(args)
+    if args.welch:
+        return welch_main(args)
+    import torch
+    import torch.distributed as dist
+
+    _, rank, local_rank, world = dist_setup(args, "nccl")
     force_dist = world == 1 and "RANK" in os.environ and os.environ.get("SCN_BENCH_FORCE_DIST")  # 1-rank self-test
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback (--dry-run exercises the N>1 plumbing on CPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or force_dist:
+    use_dist = world > 1 or bool(force_dist)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
     from scanner_amd import Plan, capi, synth, sweep
 
-    n, nb = args.n, args.batch
+    c4 = args.config == "c4"
+    if c4:
+        args.n, args.kind = 4096, "cfloat"
+    n = args.n
     kind = {"cfloat": capi.KIND_FLOAT_COMPLEX, "int16": capi.KIND_SHORT_COMPLEX, "int8": capi.KIND_BYTE_COMPLEX}[args.kind]
     enob = {"cfloat": 12, "int16": 12, "int8": 8}[args.kind]
     in_bytes = capi.BYTES_PER_SAMPLE[kind]
     algo_bytes_per_sample = in_bytes + 4  # raw sample in + one float dB out (SURVEY 8d)
 
     # this rank's shard of the frequency table (frequencyTable.cpp:9-37), contiguous range
-    first, fc = capi.frequency_table(FS, 0.0, world * nb * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
-    assert len(fc) == nb and first == rank * nb
-    seq = np.arange(first, first + nb, dtype=np.uint64)
+    if c4:
+        n_centres = args.centres
+        _, fc_all = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0)
+        first, fc = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
+        shard = len(fc)                      # buffers this rank sweeps per step
+        nb = min(shard, 8192)                # buffers per launch
+    else:
+        nb = args.batch
+        first, fc = capi.frequency_table(FS, 0.0, world * nb * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
+        assert len(fc) == nb and first == rank * nb
+        shard = nb
+    seq = np.arange(first, first + shard, dtype=np.uint64)
+    chunks = [(lo, min(lo + nb, shard)) for lo in range(0, shard, nb)]  # launches of one step
 
     # synthetic IQ generated in HBM (seeded per rank and per rotation slot); quantised on device for
     # the int kinds.  R batches in, R spectra out: footprint >= 1.5 GiB >> 256 MiB Infinity Cache.
-    step_bytes = nb * n * algo_bytes_per_sample
+    step_bytes = shard * n * algo_bytes_per_sample
     R = args.rotate or max(2, -(-(3 << 29) // step_bytes))
     raws, outs = [], []
+    if c4:
+        centres, i0 = synth.c4_emitters(n_centres, n)
     for r in range(R):
-        x = synth.cfloat_batch_torch(n, nb, seed=2 + rank + 1000 * r, device=dev)
+        if c4:
+            x = synth.c4_shard_torch(n, first, shard, centres, i0, seed=4 + 1000 * r, device=dev)
+        else:
+            x = synth.cfloat_batch_torch(n, nb, seed=2 + rank + 1000 * r, device=dev)
         if kind == capi.KIND_SHORT_COMPLEX:
             raws.append(torch.clamp(torch.round(x * 2047.0), -2048, 2047).to(torch.int16).contiguous())
         elif kind == capi.KIND_BYTE_COMPLEX:
@@ -267,40 +415,56 @@ def main():
         else:
             raws.append(x)
         del x
-        outs.append(torch.empty((nb, n), dtype=torch.float32, device=dev))
+        outs.append(torch.empty((shard, n), dtype=torch.float32, device=dev))
     raw = raws[0]
     torch.cuda.synchronize()
 
     plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=nb * 64, device_id=local_rank)
     ext = torch.cuda.ExternalStream(plan.stream_handle, device=dev)
 
-    pending = [False, False]
+    def make_loop(pl, want_records):
+        """step(k): one pass over this rank's batch = len(chunks) launches, double-buffered over the plan's two slots; the
+        results of a slot are collected right before it is reused (counts + trigger flags; the ordered records too if asked)"""
+        pending = [False, False]
+        state = {"launch": 0, "hits": 0}
 
-    def step(k):
-        s = k & 1
-        if pending[s]:  # results of the launch two steps ago: per-buffer hit counts + trigger flags
-            plan.collect(s, want_power=False, want_hits=False)
-        plan.submit_device(s, raws[k % R], nb, fc, seq, sync_producer=False, d_power_db=outs[k % R])
-        pending[s] = True
+        def collect(s):
+            _, h, _ = pl.collect(s, want_power=False, want_hits=want_records, hit_cap=nb * 64 if want_records else None)
+            if want_records:
+                state["hits"] += len(h)
+            pending[s] = False
 
-    def drain(k_total):
-        for s in ((k_total & 1), ((k_total + 1) & 1)):  # older slot first
-            if pending[s]:
-                plan.collect(s, want_power=False, want_hits=False)
-                pending[s] = False
+        def step(k):
+            for lo, hi in chunks:
+                s = state["launch"] & 1
+                state["launch"] += 1
+                if pending[s]:
+                    collect(s)
+                pl.submit_device(s, raws[k % R][lo:hi], hi - lo, fc[lo:hi], seq[lo:hi], sync_producer=False,
+                                 d_power_db=outs[k % R][lo:hi])
+                pending[s] = True
+
+        def drain():
+            for s in ((state["launch"] & 1), ((state["launch"] + 1) & 1)):  # older slot first
+                if pending[s]:
+                    collect(s)
+
+        return step, drain, state
+
+    step, drain, _ = make_loop(plan, False)
 
     # settle: the same steps, untimed and reported, until the GPU is out of its idle power state
     settle_steps = 0
     if args.settle > 0:
         t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < args.settle or (settle_steps & 1):
+        while time.perf_counter() - t_settle < args.settle:
             step(settle_steps)
             settle_steps += 1
-        drain(settle_steps)
+        drain()
         torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
-    drain(args.warmup)
+    drain()
     torch.cuda.synchronize()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -314,17 +478,59 @@ def main():
         step(k)
     with torch.cuda.stream(ext):
         ev1.record(ext)
-    drain(args.steps)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch-to-launch duration on the plan's stream
+    launches = args.steps * len(chunks)
+    kernel_ms = ev0.elapsed_time(ev1) / launches  # average launch-to-launch duration on the plan's stream
 
     if world > 1:
         tt = torch.tensor([elapsed, kernel_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = tt.tolist()
+
+    def timed_leg(pl, want_records, warm):
+        st, dr, state = make_loop(pl, want_records)
+        for k in range(warm):
+            st(k)
+        dr()
+        torch.cuda.synchronize()
+        state["hits"] = 0
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for k in range(args.steps):
+            st(k)
+        dr()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t2
+        if world > 1:
+            tt2 = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+            el = tt2.item()
+        return el, state["hits"]
+
+    # Extra leg, reported separately: the same steps with the ordered hit RECORDS fetched every step (what
+    # ProcessSamples needs to print the reference's `freq ... power_db ...` lines), plus the host cost of one such
+    # scn_collect alone (everything already on the host side of PCIe: counts loop + one memcpy out of pinned memory).
+    records = None
+    if not args.no_records_leg:
+        el3, nh = timed_leg(plan, True, min(args.warmup, 20))
+        plan.submit_device(0, raws[0][chunks[0][0]:chunks[0][1]], chunks[0][1] - chunks[0][0], fc[:chunks[0][1]], seq[:chunks[0][1]],
+                           sync_producer=False)
+        plan.wait(0)
+        time.sleep(0.002)  # the compaction behind the kernel has finished too
+        tc = time.perf_counter()
+        _, h1, _ = plan.collect(0, want_power=False, want_hits=True, hit_cap=nb * 64)
+        collect_us = (time.perf_counter() - tc) * 1e6
+        records = {"value": round(world * shard * n * args.steps / el3 / 1e6, 1), "unit": "Msamples/s",
+                   "ms_per_step": round(el3 / args.steps * 1e3, 5), "hits_per_step": round(nh / max(args.steps, 1), 1),
+                   "collect_with_records_us": round(collect_us, 1), "collect_hits": int(len(h1)),
+                   "note": "same steps, scn_collect returns the ordered, completed scn_hit records (built on the GPU) every step"}
 
     # Extra leg, reported separately: the same steps on a plan whose two slots have streams of their own
     # (SCN_PLAN_OVERLAP_SLOTS), so consecutive launches overlap: the next launch's workgroups fill the CUs the
@@ -334,76 +540,57 @@ def main():
     if not args.no_overlap_leg:
         plan2 = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=nb * 64, device_id=local_rank,
                      flags=capi.OUT_SPECTRUM | capi.OUT_HITS | capi.PLAN_OVERLAP_SLOTS)
-        pend2 = [False, False]
-
-        def step2(k):
-            s = k & 1
-            if pend2[s]:
-                plan2.collect(s, want_power=False, want_hits=False)
-            plan2.submit_device(s, raws[k % R], nb, fc, seq, sync_producer=False, d_power_db=outs[k % R])
-            pend2[s] = True
-
-        def drain2():
-            for s in (0, 1):
-                if pend2[s]:
-                    plan2.collect(s, want_power=False, want_hits=False)
-                    pend2[s] = False
-
-        for k in range(max(args.warmup, 200)):
-            step2(k)
-        drain2()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t2 = time.perf_counter()
-        for k in range(args.steps):
-            step2(k)
-        drain2()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        el2 = time.perf_counter() - t2
-        if world > 1:
-            tt = torch.tensor([el2], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el2 = tt.item()
-        overlap = {"value": round(world * nb * n * args.steps / el2 / 1e6, 1), "unit": "Msamples/s",
+        el2, _ = timed_leg(plan2, False, max(args.warmup, 200))
+        overlap = {"value": round(world * shard * n * args.steps / el2 / 1e6, 1), "unit": "Msamples/s",
                    "ms_per_step": round(el2 / args.steps * 1e3, 5),
-                   "aggregate_algorithmic_GBs_per_gpu": round(nb * n * algo_bytes_per_sample * args.steps / el2 / 1e9, 1),
+                   "aggregate_algorithmic_GBs_per_gpu": round(shard * n * algo_bytes_per_sample * args.steps / el2 / 1e9, 1),
                    "plan_flags": "SCN_OUT_SPECTRUM|SCN_OUT_HITS|SCN_PLAN_OVERLAP_SLOTS",
                    "note": "same steps, slots on two streams so consecutive launches overlap; not used for value/roofline"}
         plan2.close()
 
-    # final sweep's hit list: collected with records, gathered to rank 0 over RCCL (not timed above)
-    plan.submit_device(0, raw, nb, fc, seq, sync_producer=False)
+    # final sweep's hit list: collected with records, gathered to rank 0 by the C-ABI's scn_gather_hits
+    # (RCCL: count all-gather + grouped send/recv), not timed above
     tg0 = time.perf_counter()
-    _, hits, trig = plan.collect(0, want_power=False, want_hits=True, hit_cap=nb * 64)
-    all_hits = sweep.gather_hits(hits, dev) if (world > 1 or force_dist) else hits
+    parts = []
+    for j, (lo, hi) in enumerate(chunks):
+        plan.submit_device(j & 1, raw[lo:hi], hi - lo, fc[lo:hi], seq[lo:hi], sync_producer=False)
+        parts.append(plan.collect(j & 1, want_power=False, want_hits=True)[1])
+    hits = np.concatenate(parts) if len(parts) > 1 else parts[0]
+    gather_info = {"transport": "none (1 rank)"}
+    all_hits, per_rank = hits, np.array([len(hits)])
+    if use_dist:
+        try:
+            with sweep.HitGather(dev) as g:
+                all_hits, per_rank = g.gather(hits)
+            gather_info = {"transport": "scn_gather_hits (RCCL: ncclAllGather counts + grouped ncclSend/ncclRecv to rank 0)"}
+        except Exception as e:  # the line must survive a transport problem: say so and use the launcher's process group
+            from scanner_amd.sweep import HitGather
+
+            fb = HitGather(None)
+            fb.device = dev
+            all_hits, per_rank = fb._gather_torch(np.ascontiguousarray(hits, dtype=capi.HIT_DTYPE), 0)
+            gather_info = {"transport": "torch.distributed fallback", "scn_gather_hits_error": str(e)[:300]}
     gather_ms = (time.perf_counter() - tg0) * 1e3
+    if rank == 0:
+        sid = all_hits["seq_id"].astype(np.int64)
+        order_ok = bool(np.all((np.diff(sid) > 0) | ((np.diff(sid) == 0) & (np.diff(all_hits["i"].astype(np.int64)) > 0)))) if len(all_hits) > 1 else True
+        gather_info.update({"per_rank": [int(c) for c in per_rank], "globally_ordered": order_ok})
 
     # BASELINE.json config this run corresponds to (shape, format); anything else is labelled as what it is
-    config_tag = ("C2" if (n, args.kind, nb) == (4096, "cfloat", 8192) else
-                  "C4 per-GPU share" if (n, args.kind, nb) == (4096, "cfloat", 2048) else
+    config_tag = ("C4" if c4 and args.centres == 16384 else "C4 shape" if c4 else
+                  "C2" if (n, args.kind, nb) == (4096, "cfloat", 8192) else
+                  "C4 per-GPU share (shape only)" if (n, args.kind, nb) == (4096, "cfloat", 2048) else
                   "C3 shape, batched" if (n, args.kind) == (8192, "int16") else
                   "C1 shape, batched" if (n, args.kind) == (1024, "cfloat") else "other")
-    samples_per_step = world * nb * n
+    samples_per_step = world * shard * n if not c4 else n_centres * n
     value = samples_per_step * args.steps / elapsed / 1e6
-    buffers_per_s = world * nb * args.steps / elapsed
+    buffers_per_s = samples_per_step / n * args.steps / elapsed
     algo_bytes_per_launch = nb * n * algo_bytes_per_sample
     achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    wall_launch_ms = elapsed / launches * 1e3
 
     if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            # counters come from their own rocprofv3 passes (scripts/prof.sh); only valid for the launch shape they
-            # were collected on
-            try:
-                j = json.load(open(pmc))
-                if (j.get("n"), j.get("sample_kind"), j.get("batch_per_gpu")) == (n, args.kind, nb):
-                    traffic = j.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        prof = tracked_profile(n, args.kind, nb)
         out = {
             "metric": "Msamples/s (complex samples through convert->window->FFT->dB->threshold)",
             "value": round(value, 1),
@@ -414,43 +601,68 @@ def main():
             "settle_steps": settle_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if c4 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{config_tag}: {n}-pt FFT+power+threshold, batch {nb} {args.kind} buffers per GPU resident in HBM, "
-                            f"Blackman-Harris, fs={FS} Hz, threshold {args.threshold} dB; frequency table "
-                            f"range-sharded over {world} GPU(s)",
-                "n": n, "batch_per_gpu": nb, "sample_kind": args.kind, "parallelism": f"table-shard x{world}",
-                "rotating_batches": R, "footprint_MiB": round(R * step_bytes / 2**20),
+                "workload": (f"{config_tag}: full frequency table of {n_centres} centres x {n}-pt FFT+power+threshold, "
+                             f"{shard} cfloat buffers per GPU per sweep in launches of {nb}, emitters planted on {len(centres)} centres, "
+                             if c4 else
+                             f"{config_tag}: {n}-pt FFT+power+threshold, batch {nb} {args.kind} buffers per GPU resident in HBM, ") +
+                            f"Blackman-Harris, fs={FS} Hz, threshold {args.threshold} dB; frequency table range-sharded over "
+                            f"{world} GPU(s); {settle_steps} untimed settle steps ({args.settle} s) before the {args.warmup} warm-up steps",
+                "n": n, "batch_per_gpu": shard, "buffers_per_launch": nb, "sample_kind": args.kind,
+                "parallelism": f"table-shard x{world}", "rotating_batches": R, "footprint_MiB": round(R * step_bytes / 2**20),
             },
             "swept_GHz_per_s": round(buffers_per_s * USE_BW * FS / 1e9, 1),
             "buffers_per_s": round(buffers_per_s, 1),
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "scn_fft_kernel<M=n/256, kind, dc, hits>", "kernel_avg_ms": round(kernel_ms, 5),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("hbm_bytes_per_launch"),
+                "kernel": kernel_name(n, args.kind), "kernel_avg_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_sample": algo_bytes_per_sample,
                 "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                # the same bytes over three clocks, side by side: HIP events launch-to-launch on the plan's stream (what
+                # `achieved` uses), host wall time per launch, and the kernel's own begin-to-end time under rocprofv3
+                # (a separate run: profiles/measured_shapes.json, null if this shape was not profiled)
+                "frac_event": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_wall": round(algo_bytes_per_launch / (wall_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_kernel_rocprof": (round(algo_bytes_per_launch / (prof["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                        if prof.get("kernel_avg_us") else None),
             },
             "final_sweep_hits": int(len(all_hits)),
             "final_sweep_collect_gather_ms": round(gather_ms, 3),
+            "gather": gather_info,
         }
+        rc = 0
+        if c4:
+            want = synth.c4_expected_hits(plan.window(), fc_all, centres, i0, n, FS, args.threshold)
+            ok, worst = compare_hit_lists(all_hits, want)
+            out["c4_check"] = {"expected_hits": int(len(want)), "gathered_hits": int(len(all_hits)), "match": ok,
+                               "max_power_db_diff": worst,
+                               "expectation": "closed form: on-bin tone x window DFT, reference frequency arithmetic"}
+            rc = 0 if ok else 3
+        out["with_hit_records"] = records
         out["overlap"] = overlap
         if not args.no_cpu_baseline and world == 1:
-            host = raw[: min(nb, 4096)].cpu().numpy()
+            host = raw[: min(shard, 4096)].cpu().numpy()
             okind = {"cfloat": 4, "int16": 3, "int8": 1}[args.kind]
             if args.kind == "cfloat":
                 host = host.view(np.complex64).reshape(host.shape[0], n)
+            args.batch = shard
             out["cpu_baseline"] = cpu_baseline(args, host, okind, enob, args.cpu_seconds)
         elif world == 1:
             out["cpu_baseline"] = None
         emit(out)
+    else:
+        rc = 0
     plan.close()
-    if world > 1 or force_dist:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

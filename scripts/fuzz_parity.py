@@ -77,7 +77,7 @@ def run(budget, seed):
             cases += 1
             launches += 2
             continue
-        region_scale = int(rng.choice([1, 64, 64, 400]))   # small max_hits -> small hit regions -> overflow path
+        region_scale = int(rng.choice([1, 64, 64, 400]))   # small max_hits -> most of the list beyond the pinned part
         max_hits = max(64, max_nb * region_scale)
         nl = int(rng.integers(1, 6))
         o = O.Oracle(n, FS, thr, kind=kind, enob=enob, correct_dc=dc)
@@ -88,18 +88,9 @@ def run(budget, seed):
 
                 def check(slot, raw, fc, seq, nb):
                     want_p, want_h = bool(out_flags & 1), bool(out_flags & 2)
-                    try:
-                        p, h, t = plan.collect(slot, want_power=want_p, want_hits=want_h, hit_cap=nb * n + 1)
-                        truncated = False
-                    except capi.ScannerError as e:
-                        if e.status != capi.E_TRUNCATED:
-                            raise
-                        truncated = True
-                        p = h = t = None
+                    # small max_hits: most of the list lies beyond the plan's pinned part and comes through scn_collect_more
+                    p, h, t = plan.collect(slot, want_power=want_p, want_hits=want_h)
                     p_ref, h_ref, t_ref = o.run(raw, fc, seq, threads=8)
-                    if truncated:       # device overflow capacity (max_hits) exceeded: must really be that many hits
-                        assert len(h_ref) > max_hits, (len(h_ref), max_hits)
-                        return
                     if want_p and nb:
                         try:
                             tol.compare_spectra(p, p_ref)

@@ -51,7 +51,11 @@ def test_bench_line_single_process():
     assert c["kind"] == "port" and c["unit"] == "Msamples/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     o = d["overlap"]
     assert o["unit"] == "Msamples/s" and o["value"] > 0
-    assert d["settle_steps"] >= 2
+    assert d["settle_steps"] >= 2 and "settle" in d["config"]["workload"]
+    r = d["with_hit_records"]
+    assert r["value"] > 0 and r["collect_hits"] > 0 and r["collect_with_records_us"] > 0
+    assert d["roofline"]["kernel"].startswith("scn_fft_kernel<16, SCN_K_FLOAT_COMPLEX")
+    assert d["roofline"]["frac_wall"] <= d["roofline"]["frac_event"] * 1.05
 
 
 def test_bench_line_through_torch_distributed_one_rank():
@@ -62,3 +66,7 @@ def test_bench_line_through_torch_distributed_one_rank():
     assert d["cpu_baseline"] is None and d["overlap"] is None
     assert d["config"]["sample_kind"] == "int16" and d["roofline"]["algorithmic_bytes_per_sample"] == 8
     assert d["final_sweep_hits"] >= 0
+    assert d["roofline"]["kernel"].startswith("scn_fft8k_kernel<SCN_K_SHORT_COMPLEX")      # the kernel that actually ran
+    g = d["gather"]                                                                        # the C-ABI's RCCL gather, not torch's
+    assert g["transport"].startswith("scn_gather_hits") and g["globally_ordered"] is True
+    assert g["per_rank"] == [d["final_sweep_hits"]]

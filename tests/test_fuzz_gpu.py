@@ -17,3 +17,7 @@ def test_seeded_fuzz_slice(built_lib, oracle_mod, seed):
     spec.loader.exec_module(fuzz)
     plans, launches = fuzz.run(12.0, seed)
     assert plans >= 5 and launches >= plans
+    # The script tolerates -- and records -- spectra between 1x and 2x the bar (the float32 noise floor of a buffer
+    # dominated by one component reaches 1.0e-5 about once per 25 minutes of fuzzing); this
+    # suite does not: a green slice means every spectrum was within the 1e-5 bar itself.
+    assert fuzz.near_misses == [], fuzz.near_misses

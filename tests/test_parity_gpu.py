@@ -398,22 +398,49 @@ def test_trigger_threshold_edge(torch_cuda, oracle_mod):
     assert len(h) == 1047 + 1048 and t.tolist() == [0, 1]
 
 
-def test_hit_capacity_truncation(torch_cuda):
+def test_hit_capacity_truncation(torch_cuda, oracle_mod):
+    """More hits than the caller's buffer / the plan's pinned list: SCN_E_TRUNCATED with the FIRST records of the ordered
+    list in the buffer, the true total in n_hits, and nothing lost -- scn_collect_more walks the rest."""
     n, nb = 4096, 4
     x = synth.cfloat_batch(n, nb, seed=9)
+    fc = 100e6 + 6e6 * np.arange(nb)
+    _, h_ref, _ = oracle_mod.Oracle(n, FS, -200.0).run(x, fc)
+    assert len(h_ref) == nb * 3066
     with Plan(n, FS, -200.0, max_batch=nb, max_hits=1000) as plan:
-        plan.submit_device(0, _to_dev(torch_cuda, x), nb)
+        plan.submit_device(0, _to_dev(torch_cuda, x), nb, fc)
         with pytest.raises(capi.ScannerError) as e:
             plan.collect(0, hit_cap=5000)
-        assert e.value.status == capi.E_TRUNCATED
-        # the plan stays usable and the counter logic survives an overflow
-        plan.submit_device(0, _to_dev(torch_cuda, x), nb)
-        with pytest.raises(capi.ScannerError):
-            plan.collect(0, hit_cap=5000)
+        assert e.value.status == capi.E_TRUNCATED and plan.last_n_hits == len(h_ref)
+        _assert_hits_equal(plan.hits_view(0), h_ref[:1000])                 # what the plan keeps in pinned memory
+        _assert_hits_equal(plan.collect_more(0, 0, len(h_ref)), h_ref)      # ... and the whole list, from the GPU
+        _assert_hits_equal(plan.collect_more(0, 2500, 777), h_ref[2500:3277])
+        assert len(plan.collect_more(0, len(h_ref), 10)) == 0
+        # the plan stays usable; the default collect fetches everything by itself
+        plan.submit_device(0, _to_dev(torch_cuda, x), nb, fc)
+        _, h, _ = plan.collect(0)
+        _assert_hits_equal(h, h_ref)
+        with pytest.raises(capi.ScannerError) as e2:                        # a submitted slot has no list to walk yet
+            plan.submit_device(1, _to_dev(torch_cuda, x), nb, fc)
+            plan.collect_more(1, 0, 10)
+        assert e2.value.status == capi.E_STATE
+        plan.collect(1)
     with Plan(n, FS, 1e9, max_batch=nb) as plan:           # and a quiet plan reports zero
         plan.submit_device(0, _to_dev(torch_cuda, x), nb)
         p, h, t = plan.collect(0)
-        assert plan.last_n_hits == 0 and len(h) == 0
+        assert plan.last_n_hits == 0 and len(h) == 0 and len(plan.hits_view(0)) == 0
+
+
+def test_negative_frequency_cast_follows_x86(torch_cuda, oracle_mod):
+    """A sweep that starts at 0 Hz has start_frequency = 3 MHz - 4 MHz < 0 for its first centre; process.cpp:57 casts the
+    (negative) double of the lowest evaluated bins to uint64, which on the reference's x86-64 build wraps -- the
+    compaction kernel reproduces that, bit for bit with the oracle compiled here."""
+    n = 4096
+    centres, i0 = np.array([0]), np.array([515])
+    x = synth.c4_shard(n, 0, 2, centres, i0, seed=3)
+    fc = capi.frequency_table(FS, 0.0, 2 * 0.75 * FS)[1]
+    (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, capi.KIND_FLOAT_COMPLEX, x, fc, None, 10.0)
+    assert h_ref["i"][0] == 512 and h_ref["freq_hz"][0] == np.uint64(2**64 - 64)
+    _assert_hits_equal(h, h_ref)
 
 
 def test_spectrum_only_and_hits_only_modes(torch_cuda, oracle_mod):

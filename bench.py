@@ -427,9 +427,13 @@ def main():
         results of a slot are collected right before it is reused (counts + trigger flags; the ordered records too if asked)"""
         pending = [False, False]
         state = {"launch": 0, "hits": 0}
+        rec_buf = np.zeros(nb * 64, capi.HIT_DTYPE) if want_records else None  # the caller's record buffer, reused
 
         def collect(s):
-            _, h, _ = pl.collect(s, want_power=False, want_hits=want_records, hit_cap=nb * 64 if want_records else None)
+            tc0 = time.perf_counter()
+            _, h, _ = pl.collect(s, want_power=False, want_hits=want_records, hits_out=rec_buf)
+            state["collect_s"] = state.get("collect_s", 0.0) + time.perf_counter() - tc0
+            state["collects"] = state.get("collects", 0) + 1
             if want_records:
                 state["hits"] += len(h)
             pending[s] = False
@@ -498,6 +502,7 @@ def main():
         dr()
         torch.cuda.synchronize()
         state["hits"] = 0
+        state["collect_s"], state["collects"] = 0.0, 0
         if world > 1:
             dist.barrier()
         t2 = time.perf_counter()
@@ -512,25 +517,30 @@ def main():
             tt2 = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
             el = tt2.item()
-        return el, state["hits"]
+        return el, state
 
     # Extra leg, reported separately: the same steps with the ordered hit RECORDS fetched every step (what
     # ProcessSamples needs to print the reference's `freq ... power_db ...` lines), plus the host cost of one such
     # scn_collect alone (everything already on the host side of PCIe: counts loop + one memcpy out of pinned memory).
     records = None
     if not args.no_records_leg:
-        el3, nh = timed_leg(plan, True, min(args.warmup, 20))
+        el3, st3 = timed_leg(plan, True, min(args.warmup, 20))
+        nh = st3["hits"]
         plan.submit_device(0, raws[0][chunks[0][0]:chunks[0][1]], chunks[0][1] - chunks[0][0], fc[:chunks[0][1]], seq[:chunks[0][1]],
                            sync_producer=False)
         plan.wait(0)
         time.sleep(0.002)  # the compaction behind the kernel has finished too
+        rec_buf = np.zeros(nb * 64, capi.HIT_DTYPE)
         tc = time.perf_counter()
-        _, h1, _ = plan.collect(0, want_power=False, want_hits=True, hit_cap=nb * 64)
+        _, h1, _ = plan.collect(0, want_power=False, want_hits=True, hits_out=rec_buf)
         collect_us = (time.perf_counter() - tc) * 1e6
         records = {"value": round(world * shard * n * args.steps / el3 / 1e6, 1), "unit": "Msamples/s",
                    "ms_per_step": round(el3 / args.steps * 1e3, 5), "hits_per_step": round(nh / max(args.steps, 1), 1),
                    "collect_with_records_us": round(collect_us, 1), "collect_hits": int(len(h1)),
-                   "note": "same steps, scn_collect returns the ordered, completed scn_hit records (built on the GPU) every step"}
+                   "collect_call_avg_us_in_loop": round(st3["collect_s"] / max(st3["collects"], 1) * 1e6, 1),
+                   "note": "same steps, scn_collect returns the ordered, completed scn_hit records (built on the GPU) every step; "
+                           "collect_with_records_us = one such call on an idle plan whose list is already complete (event wait + "
+                           "top-up DMA if the prefetch was short + one memcpy out of pinned memory into the caller's buffer)"}
 
     # Extra leg, reported separately: the same steps on a plan whose two slots have streams of their own
     # (SCN_PLAN_OVERLAP_SLOTS), so consecutive launches overlap: the next launch's workgroups fill the CUs the
@@ -541,6 +551,7 @@ def main():
         plan2 = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=nb * 64, device_id=local_rank,
                      flags=capi.OUT_SPECTRUM | capi.OUT_HITS | capi.PLAN_OVERLAP_SLOTS)
         el2, _ = timed_leg(plan2, False, max(args.warmup, 200))
+
         overlap = {"value": round(world * shard * n * args.steps / el2 / 1e6, 1), "unit": "Msamples/s",
                    "ms_per_step": round(el2 / args.steps * 1e3, 5),
                    "aggregate_algorithmic_GBs_per_gpu": round(shard * n * algo_bytes_per_sample * args.steps / el2 / 1e9, 1),

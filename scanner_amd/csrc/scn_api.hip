@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -67,7 +68,12 @@ struct Slot {
   // so the compute stream carries nothing but the kernel.  (Letting the kernel store to pinned
   // host memory directly was measured: the PCIe acknowledgements delay every kernel's completion
   // by ~4 us, 5 % of a C2 launch.)
-  uint32_t *d_buf_hits = nullptr;
+  // Everything the FFT kernel writes for the hit list has TWO generations per slot, alternating per submit: the
+  // compaction of submit k may still be running (beside launch k+1) when launch k+2 starts writing -- with a
+  // generation of its own nothing has to wait, neither the host at submit nor the compute stream behind a barrier
+  // packet (measured: ~10 us per launch even when the barrier is already satisfied, ~16 us when it is not).
+  uint32_t gen = 0;                 // generation of the pending / last submit
+  uint32_t *d_buf_hits[2] = {nullptr, nullptr};
   uint32_t *h_buf_hits = nullptr;
   hipEvent_t kernel_done = nullptr, staged = nullptr;
   hipStream_t stream = nullptr;     // where this slot's kernels run: the plan's compute stream, or its own (SCN_PLAN_OVERLAP_SLOTS)
@@ -76,18 +82,20 @@ struct Slot {
   uint32_t *d_work_counter = nullptr;
   uint32_t work_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool own_stream = false;
-  ScnDevHit *d_hits = nullptr;      // [max_batch][hit_region] per-buffer hit regions (unordered, scn_kernels.hip)
-  // the ordered list (scn_hits.hip): offsets = exclusive scan of the counts; fc / seq = device copies of the
-  // submit's MessageHeader fields (staged through the pinned h_meta); h_list = the first max_hits completed records,
-  // written by the compaction kernel straight into pinned host memory; d_window = where scn_collect_more re-runs
-  // the compaction for a later window of the list
+  ScnDevHit *d_hits[2] = {nullptr, nullptr};  // [max_batch][hit_region] per-buffer hit regions (unordered, scn_kernels.hip)
+  // the ordered list (scn_hits.hip): offsets = exclusive scan of the counts; h_meta = the submit's MessageHeader
+  // fields, pinned, read by the compaction kernel in place; d_list = the first max_hits completed records; h_list =
+  // their pinned host copy (prefetched of them are there); d_window = where scn_collect_more re-runs the compaction
+  // for a window beyond max_hits
   uint32_t *d_offsets = nullptr;
-  double *d_fc = nullptr;
-  uint64_t *d_seq = nullptr;
-  void *h_meta = nullptr;           // pinned [max_batch] doubles then [max_batch] u64
+  void *h_meta = nullptr;           // pinned, two generations of {[max_batch] doubles, [max_batch] u64}
+  scn_hit *d_list = nullptr;        // device [max_hits]
   scn_hit *h_list = nullptr;        // pinned [max_hits]
-  hipEvent_t list_done = nullptr;   // compaction of the pending / last submit finished
+  uint32_t prefetched = 0;          // leading records of the current list that are (being) copied to h_list
+  hipEvent_t list_done[2] = {nullptr, nullptr};  // per generation: scan + compaction (+ prefetch) finished
+  bool list_used[2] = {false, false};            // ... and whether that event has ever been recorded
   bool list_valid = false;          // regions, counts and offsets of the last collected submit are still on the device
+  bool list_built = false;          // the scan + compaction of the pending / last submit have been enqueued
   uint32_t total_hits = 0;          // of the last collected submit
   scn_hit *d_window = nullptr;      // [d_window_cap] scratch of scn_collect_more
   uint32_t d_window_cap = 0;
@@ -98,12 +106,26 @@ struct Slot {
 
 }  // namespace
 
+// Where the ordered hit list of a submit is built (experiment knob SCN_EXP_COMPACT, read at plan creation):
+//   0 (default) automatic: behind the kernel on the list stream, overlapping the next launch (plus a DMA of the
+//               expected number of records to pinned host memory), IF the plan's previous collect asked for records;
+//               otherwise on demand, when a collect call asks -- callers that only want counts / trigger flags pay nothing
+//   1           always behind the kernel, on the compute stream itself (in order, before the next launch)
+//   2           always on demand
+//   3           always behind the kernel on the list stream
+enum { SCN_COMPACT_AUTO = 0, SCN_COMPACT_INLINE = 1, SCN_COMPACT_LAZY = 2, SCN_COMPACT_SIDE = 3 };
+
 struct scn_plan {
   scn_plan_desc d;
   int num_cus = 0;
+  int compact_mode = SCN_COMPACT_AUTO;
+  bool records_wanted = false;  // did the last scn_collect ask for hit records? (the automatic mode's hint)
+  uint32_t predict = 0;         // records the next list is expected to hold (last total + 25 %): the prefetch size
+  int fft_cus = 0;  // CUs the FFT launch is sized for (num_cus unless SCN_EXP_RESERVE_CUS leaves some to the side stream)
   hipStream_t stream = nullptr;      // compute
   hipStream_t h2d_stream = nullptr;  // staging copies of scn_submit (overlap the other slot's kernel)
   hipStream_t d2h_stream = nullptr;  // per-buffer hit counts back to the host
+  hipStream_t list_stream = nullptr; // the ordered hit list: scan + compaction kernels, the list's DMA
   size_t buf_bytes = 0;
   float scale = 1.0f;
   uint32_t i_lo = 0, i_hi = 0;
@@ -169,28 +191,29 @@ int ensure_slot_outputs(scn_plan *p, Slot &s) {
   if (p->d.flags & SCN_OUT_HITS) {
     // every resource under its own check: a failed allocation leaves a state the next call completes or fails on again
     const uint32_t mb = p->d.max_batch;
-    if (!s.d_hits) SCN_HIP(hipMalloc(&s.d_hits, sizeof(ScnDevHit) * (size_t)p->hit_region * mb));
-    if (!s.d_buf_hits) SCN_HIP(hipMalloc(&s.d_buf_hits, sizeof(uint32_t) * mb));
+    for (int g = 0; g < 2; g++) {
+      if (!s.d_hits[g]) SCN_HIP(hipMalloc(&s.d_hits[g], sizeof(ScnDevHit) * (size_t)p->hit_region * mb));
+      if (!s.d_buf_hits[g]) SCN_HIP(hipMalloc(&s.d_buf_hits[g], sizeof(uint32_t) * mb));
+      if (!s.list_done[g]) SCN_HIP(hipEventCreateWithFlags(&s.list_done[g], hipEventDisableTiming));
+    }
     if (!s.h_buf_hits) SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * mb, hipHostMallocDefault));
     if (!s.d_offsets) SCN_HIP(hipMalloc(&s.d_offsets, sizeof(uint32_t) * ((size_t)mb + 1u)));
-    if (!s.d_fc) SCN_HIP(hipMalloc(&s.d_fc, sizeof(double) * mb));
-    if (!s.d_seq) SCN_HIP(hipMalloc(&s.d_seq, sizeof(uint64_t) * mb));
-    if (!s.h_meta) SCN_HIP(hipHostMalloc(&s.h_meta, 16u * (size_t)mb, hipHostMallocDefault));
+    if (!s.h_meta) SCN_HIP(hipHostMalloc(&s.h_meta, 2u * 16u * (size_t)mb, hipHostMallocDefault));
+    if (!s.d_list) SCN_HIP(hipMalloc(&s.d_list, sizeof(scn_hit) * (size_t)p->d.max_hits));
     if (!s.h_list) SCN_HIP(hipHostMalloc(&s.h_list, sizeof(scn_hit) * (size_t)p->d.max_hits, hipHostMallocDefault));
     if (!s.kernel_done) SCN_HIP(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
-    if (!s.list_done) SCN_HIP(hipEventCreateWithFlags(&s.list_done, hipEventDisableTiming));
   }
   return SCN_OK;
 }
 
 ScnCompactArgs compact_args(const scn_plan *p, const Slot &s, uint32_t first, uint32_t cap, void *out) {
   ScnCompactArgs c;
-  c.regions = s.d_hits;
+  c.regions = s.d_hits[s.gen];
   c.hit_region = p->hit_region;
-  c.counts = s.d_buf_hits;
+  c.counts = s.d_buf_hits[s.gen];
   c.offsets = s.d_offsets;
-  c.center_freq = s.d_fc;
-  c.seq_id = s.d_seq;
+  c.center_freq = static_cast<const double *>(s.h_meta) + (size_t)2u * p->d.max_batch * s.gen;
+  c.seq_id = reinterpret_cast<const uint64_t *>(c.center_freq + p->d.max_batch);
   c.out = out;
   c.first = first;
   c.out_cap = std::min<uint32_t>(cap, 0x7fffffffu - first);  // first + out_cap must not wrap
@@ -198,6 +221,45 @@ ScnCompactArgs compact_args(const scn_plan *p, const Slot &s, uint32_t first, ui
   c.n = p->d.n;
   c.sample_rate = p->d.sample_rate;
   return c;
+}
+
+// the stream the slot's ordered list is built and fetched on
+hipStream_t list_stream_of(const scn_plan *p, const Slot &s) {
+  return (s.own_stream || p->compact_mode == SCN_COMPACT_INLINE) ? s.stream : p->list_stream;
+}
+
+// Scan + compaction of the slot's pending / last submit into d_list, behind everything already queued on the list's
+// stream; with `prefetch`, followed by a DMA of the expected number of records into the pinned h_list (the size of a
+// copy has to be known when it is queued, long before this batch's own total is: the plan predicts it from the last
+// one, and fetch_list tops up whatever is missing).
+int build_list(scn_plan *p, Slot &s, bool prefetch) {
+  hipStream_t aux = list_stream_of(p, s);
+  ScnCompactArgs c = compact_args(p, s, 0, p->d.max_hits, s.d_list);
+  SCN_HIP(scn_launch_hit_scan(c, aux));
+  SCN_HIP(scn_launch_hit_compact(c, aux));
+  s.prefetched = prefetch ? std::min(p->predict, p->d.max_hits) : 0u;
+  if (s.prefetched)
+    SCN_HIP(hipMemcpyAsync(s.h_list, s.d_list, sizeof(scn_hit) * (size_t)s.prefetched, hipMemcpyDeviceToHost, aux));
+  SCN_HIP(hipEventRecord(s.list_done[s.gen], aux));
+  s.list_used[s.gen] = true;
+  s.list_built = true;
+  return SCN_OK;
+}
+
+// the first `count` records of the slot's list are in pinned host memory
+int fetch_list(scn_plan *p, Slot &s, uint32_t count) {
+  if (!s.list_built)
+    if (int st = build_list(p, s, false)) return st;
+  SCN_HIP(hipEventSynchronize(s.list_done[s.gen]));
+  count = std::min(count, p->d.max_hits);
+  if (count > s.prefetched) {
+    hipStream_t aux = list_stream_of(p, s);
+    SCN_HIP(hipMemcpyAsync(s.h_list + s.prefetched, s.d_list + s.prefetched, sizeof(scn_hit) * (size_t)(count - s.prefetched),
+                           hipMemcpyDeviceToHost, aux));
+    SCN_HIP(hipStreamSynchronize(aux));
+    s.prefetched = count;
+  }
+  return SCN_OK;
 }
 
 int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const double *fc, const uint64_t *seq,
@@ -228,22 +290,18 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   s.n_buffers = nb;
   s.list_valid = false;
   const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
-  // where everything behind the kernel goes: the side stream (the compute stream then carries nothing but FFT
-  // kernels), or, with overlapped slots, the slot's own stream -- its next kernel is two submits away, and one stream
-  // less keeps both compute streams on hardware queues of their own (HIP maps streams onto 4 queues by default; with a
-  // fifth active stream the two compute streams ended up sharing one)
-  hipStream_t aux = s.own_stream ? s.stream : p->d2h_stream;
+  s.list_built = false;
   if (hits && nb) {
-    double *h_fc = static_cast<double *>(s.h_meta);
+    // this submit's generation; the only thing that can still be using it is the compaction of the submit FOUR launches
+    // back on this plan (two on this slot) -- wait for it on the host, where it never blocks in practice
+    s.gen ^= 1u;
+    if (s.list_used[s.gen] && hipEventQuery(s.list_done[s.gen]) != hipSuccess) SCN_HIP(hipEventSynchronize(s.list_done[s.gen]));
+    // the header fields: read by the compaction kernel in place, over PCIe (two 8-byte reads per buffer that has hits;
+    // staging copies cost ~7 us each plus ~10 us of cross-engine hand-off, on the list's critical path)
+    double *h_fc = static_cast<double *>(s.h_meta) + (size_t)2u * p->d.max_batch * s.gen;
     uint64_t *h_seq = reinterpret_cast<uint64_t *>(h_fc + p->d.max_batch);
     memcpy(h_fc, fc, sizeof(double) * nb);
     for (uint32_t b = 0; b < nb; b++) h_seq[b] = seq ? seq[b] : (uint64_t)b;
-    // the previous compaction on this slot read d_fc / d_seq on `aux`: same stream, so these copies queue behind it
-    SCN_HIP(hipMemcpyAsync(s.d_fc, h_fc, sizeof(double) * nb, hipMemcpyHostToDevice, aux));
-    SCN_HIP(hipMemcpyAsync(s.d_seq, h_seq, sizeof(uint64_t) * nb, hipMemcpyHostToDevice, aux));
-    // ... and read this slot's regions and counts, which the kernel below overwrites: a collect that only asked for
-    // the counts does not wait for the list, so the kernel does (a GPU-side dependency that is met long before)
-    if (!s.own_stream) SCN_HIP(hipStreamWaitEvent(s.stream, s.list_done, 0));
   }
 
   ScnFftArgs a;
@@ -259,26 +317,35 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.dc_ignore = p->d.dc_ignore_bins;
   a.i_lo = p->i_lo;
   a.i_hi = p->i_hi;
-  a.hits = s.d_hits;
+  a.hits = s.d_hits[s.gen];
   a.hit_region = p->hit_region;
-  a.per_buffer_hits = s.d_buf_hits;
+  a.per_buffer_hits = s.d_buf_hits[s.gen];
   a.work_counter = s.d_work_counter;
   for (uint32_t x = 0; x < 8; x++) a.work_base[x] = s.work_base[x];
-  SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->num_cus, s.stream));
+  SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->fft_cus, s.stream));
   if (scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
   if (hits && nb) {
+    // two independent branches behind the kernel: the counts (a DMA on the d2h stream: needs no CU) and, when the
+    // caller is known to want records, the ordered list (two small kernels + a DMA on the list stream, beside the next
+    // launch).  With overlapped slots both follow the kernel on the slot's own stream -- its next kernel is two
+    // submits away, and fewer streams keep both compute streams on hardware queues of their own (HIP maps streams
+    // onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one).
+    const bool eager = p->compact_mode == SCN_COMPACT_INLINE || p->compact_mode == SCN_COMPACT_SIDE ||
+                       (p->compact_mode == SCN_COMPACT_AUTO && p->records_wanted);
+    hipStream_t cnt = s.own_stream ? s.stream : p->d2h_stream;
+    hipStream_t lst = list_stream_of(p, s);
     if (!s.own_stream) {
       SCN_HIP(hipEventRecord(s.kernel_done, s.stream));
-      SCN_HIP(hipStreamWaitEvent(aux, s.kernel_done, 0));
+      SCN_HIP(hipStreamWaitEvent(cnt, s.kernel_done, 0));
+      if (eager && lst != s.stream) SCN_HIP(hipStreamWaitEvent(lst, s.kernel_done, 0));
     }
-    // counts first (a DMA: needs no CU), then the ordered list
-    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, aux));
-    SCN_HIP(hipEventRecord(s.done, aux));
-    ScnCompactArgs c = compact_args(p, s, 0, p->d.max_hits, s.h_list);
-    SCN_HIP(scn_launch_hit_scan(c, aux));
-    SCN_HIP(scn_launch_hit_compact(c, aux));
-    SCN_HIP(hipEventRecord(s.list_done, aux));
+    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits[s.gen], sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, cnt));
+    SCN_HIP(hipEventRecord(s.done, cnt));
+    if (eager) {
+      int st2 = build_list(p, s, true);
+      if (st2) return st2;
+    }
   } else {
     SCN_HIP(hipEventRecord(s.done, s.stream));
   }
@@ -291,7 +358,12 @@ void free_slot(Slot &s) {
   if (s.d_raw) (void)hipFree(s.d_raw);
   if (s.d_power) (void)hipFree(s.d_power);
   if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
-  if (s.d_buf_hits) (void)hipFree(s.d_buf_hits);
+  for (int g = 0; g < 2; g++) {
+    if (s.d_buf_hits[g]) (void)hipFree(s.d_buf_hits[g]);
+    if (s.d_hits[g]) (void)hipFree(s.d_hits[g]);
+    if (s.list_done[g]) (void)hipEventDestroy(s.list_done[g]);
+  }
+  if (s.d_list) (void)hipFree(s.d_list);
   if (s.own_stream && s.stream) {
     (void)hipStreamSynchronize(s.stream);
     (void)hipStreamDestroy(s.stream);
@@ -300,14 +372,10 @@ void free_slot(Slot &s) {
   if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
   if (s.staged) (void)hipEventDestroy(s.staged);
   if (s.h_td) (void)hipHostFree(s.h_td);
-  if (s.d_hits) (void)hipFree(s.d_hits);
   if (s.d_offsets) (void)hipFree(s.d_offsets);
-  if (s.d_fc) (void)hipFree(s.d_fc);
-  if (s.d_seq) (void)hipFree(s.d_seq);
   if (s.d_window) (void)hipFree(s.d_window);
   if (s.h_meta) (void)hipHostFree(s.h_meta);
   if (s.h_list) (void)hipHostFree(s.h_list);
-  if (s.list_done) (void)hipEventDestroy(s.list_done);
   if (s.done) (void)hipEventDestroy(s.done);
   s = Slot();
 }
@@ -407,9 +475,17 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   }
     SCN_TRY(hipGetDeviceProperties(&prop, d.device_id));
     p->num_cus = prop.multiProcessorCount;
+    p->fft_cus = p->num_cus;
+    if (const char *e = getenv("SCN_EXP_COMPACT")) p->compact_mode = atoi(e);
+    if (const char *e = getenv("SCN_EXP_RESERVE_CUS")) p->fft_cus = std::max(1, p->num_cus - atoi(e));
     SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->h2d_stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->d2h_stream, hipStreamNonBlocking));
+    {  // the list stream's kernels are tiny and latency-critical: let the dispatcher take them first
+      int lo = 0, hi = 0;
+      SCN_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      SCN_TRY(hipStreamCreateWithPriority(&p->list_stream, hipStreamNonBlocking, hi));
+    }
     for (int k = 0; k < SCN_NUM_SLOTS; k++) {
       Slot &sl = p->slot[k];
       sl.stream = p->stream;
@@ -461,6 +537,7 @@ int scn_plan_destroy(scn_plan *p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->h2d_stream) (void)hipStreamSynchronize(p->h2d_stream);
   if (p->d2h_stream) (void)hipStreamSynchronize(p->d2h_stream);
+  if (p->list_stream) (void)hipStreamSynchronize(p->list_stream);
   for (int i = 0; i < SCN_NUM_SLOTS; i++) free_slot(p->slot[i]);
   if (p->d_window) (void)hipFree(p->d_window);
   if (p->d_twiddle) (void)hipFree(p->d_twiddle);
@@ -468,6 +545,7 @@ int scn_plan_destroy(scn_plan *p) {
   if (p->stream) (void)hipStreamDestroy(p->stream);
   if (p->h2d_stream) (void)hipStreamDestroy(p->h2d_stream);
   if (p->d2h_stream) (void)hipStreamDestroy(p->d2h_stream);
+  if (p->list_stream) (void)hipStreamDestroy(p->list_stream);
   delete p;
   return SCN_OK;
 }
@@ -598,12 +676,16 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   }
   if (total > 0x7fffffffu) return fail(SCN_E_INVALID, "%llu hits in one submit: split the batch", (unsigned long long)total);
   s.total_hits = (uint32_t)total;
+  if (have_hits) {  // what the automatic mode goes by at the next submit
+    p->records_wanted = hits != nullptr;
+    p->predict = (uint32_t)std::min<uint64_t>(total + total / 4u + 64u, p->d.max_hits);
+  }
   if (n_hits) *n_hits = (uint32_t)total;
   uint32_t copied = 0;
   if (hits && total) {
-    // the compaction kernel has written the first max_hits records, ordered and complete, to pinned memory
-    SCN_HIP(hipEventSynchronize(s.list_done));
+    // the compaction kernel has left the first max_hits records, ordered and complete, in device memory
     copied = std::min(std::min((uint32_t)total, hit_cap), p->d.max_hits);
+    if ((st = fetch_list(p, s, copied))) return st;
     memcpy(hits, s.h_list, sizeof(scn_hit) * copied);
   }
   if (power_db && nb) {
@@ -626,14 +708,15 @@ int scn_collect_more(scn_plan *p, int slot, uint32_t first, scn_hit *hits, uint3
   if (first >= s.total_hits || hit_cap == 0) return SCN_OK;
   SCN_HIP(hipSetDevice(p->d.device_id));
   const uint32_t want = std::min(hit_cap, s.total_hits - first);
-  if (first + want <= p->d.max_hits) {  // still inside the part that is already in pinned memory
-    SCN_HIP(hipEventSynchronize(s.list_done));
+  if (first + want <= p->d.max_hits) {  // still inside the part the plan keeps
+    if ((st = fetch_list(p, s, first + want))) return st;
     memcpy(hits, s.h_list + first, sizeof(scn_hit) * want);
     *n_written = want;
     return SCN_OK;
   }
   // re-run the compaction for the window [first, first + want): regions, counts and offsets stay valid until the
   // slot's next submit
+  if ((st = fetch_list(p, s, 0))) return st;  // (the offsets come from the scan; the slot's list must be complete)
   if (s.d_window_cap < want) {
     if (s.d_window) (void)hipFree(s.d_window);
     s.d_window = nullptr;
@@ -641,7 +724,7 @@ int scn_collect_more(scn_plan *p, int slot, uint32_t first, scn_hit *hits, uint3
     SCN_HIP(hipMalloc(&s.d_window, sizeof(scn_hit) * (size_t)want));
     s.d_window_cap = want;
   }
-  hipStream_t aux = s.own_stream ? s.stream : p->d2h_stream;
+  hipStream_t aux = list_stream_of(p, s);
   SCN_HIP(scn_launch_hit_compact(compact_args(p, s, first, want, s.d_window), aux));
   SCN_HIP(hipMemcpyAsync(hits, s.d_window, sizeof(scn_hit) * want, hipMemcpyDeviceToHost, aux));
   SCN_HIP(hipStreamSynchronize(aux));
@@ -656,9 +739,9 @@ int scn_hits_view(scn_plan *p, int slot, const scn_hit **hits, uint32_t *n) {
   Slot &s = p->slot[slot];
   if (s.pending || !s.list_valid) return fail(SCN_E_STATE, "slot %d: no collected submit whose hit list is still available", slot);
   SCN_HIP(hipSetDevice(p->d.device_id));
-  SCN_HIP(hipEventSynchronize(s.list_done));
-  *hits = s.h_list;
   *n = std::min(s.total_hits, p->d.max_hits);
+  if ((st = fetch_list(p, s, *n))) return st;
+  *hits = s.h_list;
   return SCN_OK;
 }
 

@@ -13,9 +13,12 @@
 //                           {seq_id, i, power_db, freq_hz} with the frequency in the reference's own arithmetic
 //                           (process.cpp:38-39,55-57: uint32 bin_step, uint32 i*bin_step, double sum, cast to uint64).
 //
-// Both are byte work on a few KB..MB (HBM/L2-latency bound, no roofline of their own): the C2 batch has ~69 k hits
-// = 0.5 MB of records in, 1.6 MB out.  The output window [first, first + out_cap) lets a caller with a small buffer
-// walk an arbitrarily long list (scn_collect_more) -- nothing is ever dropped on the device.
+// Both are byte work on a few KB..MB (L2-latency bound, no roofline of their own): the C2 batch has ~69 k hits
+// = 0.5 MB of records in, 1.6 MB out.  The list goes straight into pinned HOST memory (a buffer's records are
+// contiguous there; alone on the GPU the kernel takes ~4.5 us for a C2 batch, beside a running FFT launch ~30 us,
+// in its shadow either way), so a collect call is an event wait plus a copy out of host memory.  The output window
+// [first, first + out_cap) lets a caller with a small buffer walk an arbitrarily long list (scn_collect_more) --
+// nothing is ever dropped on the device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,34 +27,64 @@
 
 namespace {
 
-constexpr uint32_t kScanThreads = 1024;
+// Workgroups of 256 threads = one wave per SIMD: small enough to be dispatched NEXT TO the resident workgroups of
+// the following FFT launch (a 4096-point float workgroup set leaves ~100 VGPRs per SIMD and 49 KiB of LDS free; a
+// 1024-thread scan would need four waves per SIMD on one CU and therefore waits until that launch drains).
+// Workgroup j owns the 2048 counts [2048 j, 2048 (j+1)), 8 consecutive ones per thread in registers.  Instead of a
+// carry chain between workgroups (a grid-wide dependency), each workgroup sums the counts BEFORE its chunk itself:
+// redundant reads of at most n_buffers * 4 bytes from L2, all workgroups independent and in flight together.  (The
+// first version, one workgroup walking its chunks with a load-add-store loop, took 15-30 us per 8192 counts.)
+constexpr uint32_t kScanThreads = 256;
+constexpr uint32_t kScanChunk = kScanThreads * 8u;
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *s_part) {  // total over the 256 threads, in every thread
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();  // s_part free again
+  if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
 
 __global__ __launch_bounds__(kScanThreads) void scn_hit_scan_kernel(ScnCompactArgs a) {
-  __shared__ uint32_t s_wave[kScanThreads / 64];
-  __shared__ uint32_t s_carry;
+  __shared__ uint32_t s_part[kScanThreads / 64];
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  // (no s_setprio here: these waves usually run beside the next FFT launch's, and raising them made the scan twice as
+  // fast -- 25 -> 12 us -- but cost the FFT launch beside them ~20 us; nothing waits for the list except its reader)
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  if (t == 0) s_carry = 0;
-  __syncthreads();
-  // chunks of 1024 consecutive buffers, one count per thread, carry from chunk to chunk
-  for (uint32_t base = 0; base < a.n_buffers; base += kScanThreads) {
-    const uint32_t b = base + t;
-    const uint32_t c = b < a.n_buffers ? a.counts[b] : 0u;
-    uint32_t incl = c;  // inclusive scan inside the wave
+  const uint32_t chunk0 = blockIdx.x * kScanChunk;
+  // this chunk first (8 consecutive counts per thread), so that its loads and the ones below are in flight together
+  const uint32_t b0 = chunk0 + t * 8u;
+  uint32_t c[8];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t v = __shfl_up(incl, off, 64);
-      if (lane >= (uint32_t)off) incl += v;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t before = s_carry;  // everything in earlier chunks and earlier waves of this chunk
-    for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
-    if (b < a.n_buffers) a.offsets[b] = before + incl - c;
-    __syncthreads();
-    if (t == kScanThreads - 1) s_carry = before + incl;
-    __syncthreads();
+  for (uint32_t k = 0; k < 8u; k++) c[k] = b0 + k < a.n_buffers ? a.counts[b0 + k] : 0u;
+  // everything before this chunk (chunk0 is a multiple of 2048; counts is 16-byte aligned)
+  uint32_t before = 0;
+  for (uint32_t b = t * 4u; b < chunk0; b += kScanThreads * 4u) {
+    const v4u v = *reinterpret_cast<const v4u *>(a.counts + b);
+    before += v.x + v.y + v.z + v.w;
   }
-  if (t == 0) a.offsets[a.n_buffers] = s_carry;
+  before = block_sum(before, s_part);
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 8u; k++) sum += c[k];
+  uint32_t incl = sum;  // inclusive scan of the per-thread sums inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= (uint32_t)off) incl += v;
+  }
+  __syncthreads();
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  uint32_t run = before + incl - sum;
+  for (uint32_t w = 0; w < wave; w++) run += s_part[w];
+#pragma unroll
+  for (uint32_t k = 0; k < 8u; k++) {
+    if (b0 + k < a.n_buffers) a.offsets[b0 + k] = run;
+    run += c[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && t == kScanThreads - 1) a.offsets[a.n_buffers] = run;  // the total
 }
 
 // uint64_t(double) the way the reference's x86-64 build does it (process.cpp:57 casts a double that is negative for the
@@ -71,17 +104,21 @@ __global__ __launch_bounds__(256) void scn_hit_compact_kernel(ScnCompactArgs a) 
   const uint32_t last = a.first + a.out_cap;           // exclusive (out_cap <= 2^31: no wrap, checked by the caller)
   scn_hit *const out = static_cast<scn_hit *>(a.out);
   for (uint32_t b = blockIdx.x * 4u + wave; b < a.n_buffers; b += gridDim.x * 4u) {
-    const uint32_t c = a.counts[b];
-    if (c == 0) continue;
-    const uint32_t o0 = a.offsets[b];
-    if (o0 >= last || o0 + c <= a.first) continue;     // nothing of this buffer inside the window
+    // everything this buffer needs from memory is requested at once: its slice of the offsets (the count is the
+    // difference: no second array), its header fields, and -- speculatively -- the first 64 records of its region
     const ScnDevHit *const region = a.regions + (size_t)b * a.hit_region;
+    const uint32_t o0 = a.offsets[b], o1 = a.offsets[b + 1u];
+    const ScnDevHit first64 = region[lane < a.hit_region ? lane : 0u];
+    const double fc = a.center_freq[b];
+    const uint64_t seq = a.seq_id[b];
+    const uint32_t c = o1 - o0;
+    if (c == 0 || o0 >= last || o1 <= a.first) continue;  // no hits, or nothing of this buffer inside the window
     const uint32_t stored = c < a.hit_region ? c : a.hit_region;
     for (uint32_t w = lane; w < words; w += 64u) bits[w] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (uint32_t k = lane; k < stored; k += 64u) {
-      const uint32_t i = region[k].i;
+      const uint32_t i = k < 64u ? first64.i : region[k].i;
       atomicOr(&bits[i >> 5], 1u << (i & 31u));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -108,10 +145,9 @@ __global__ __launch_bounds__(256) void scn_hit_compact_kernel(ScnCompactArgs a) 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const double start_frequency = a.center_freq[b] - (double)(a.sample_rate / 2u);  // process.cpp:38 (uint32 division)
-    const uint64_t seq = a.seq_id[b];
+    const double start_frequency = fc - (double)(a.sample_rate / 2u);  // process.cpp:38 (uint32 division)
     for (uint32_t k = lane; k < stored; k += 64u) {
-      const ScnDevHit h = region[k];
+      const ScnDevHit h = k < 64u ? first64 : region[k];
       const uint32_t w = h.i >> 5;
       const uint32_t pos = o0 + below[w] + (uint32_t)__popc(bits[w] & ((1u << (h.i & 31u)) - 1u));
       if (pos >= a.first && pos < last) {
@@ -131,7 +167,8 @@ __global__ __launch_bounds__(256) void scn_hit_compact_kernel(ScnCompactArgs a) 
 }  // namespace
 
 hipError_t scn_launch_hit_scan(const ScnCompactArgs &a, hipStream_t stream) {
-  hipLaunchKernelGGL(scn_hit_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, a);
+  const uint32_t blocks = a.n_buffers ? (a.n_buffers + kScanChunk - 1u) / kScanChunk : 1u;
+  hipLaunchKernelGGL(scn_hit_scan_kernel, dim3(blocks), dim3(kScanThreads), 0, stream, a);
   return hipGetLastError();
 }
 

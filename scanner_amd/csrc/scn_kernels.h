@@ -92,8 +92,8 @@ struct ScnCompactArgs {
   uint32_t hit_region;
   const uint32_t *counts;    // [n_buffers]
   uint32_t *offsets;         // [n_buffers + 1]: exclusive prefix sums, total at [n_buffers]
-  const double *center_freq; // [n_buffers] device copies of the MessageHeader fields
-  const uint64_t *seq_id;    // [n_buffers]
+  const double *center_freq; // [n_buffers] the submit's MessageHeader fields, read IN PLACE from the plan's pinned host
+  const uint64_t *seq_id;    // [n_buffers] copy (two 8-byte reads per buffer that has hits: no staging copies on the stream)
   void *out;                 // scn_hit[out_cap]
   uint32_t first, out_cap;
   uint32_t n_buffers, n, sample_rate;

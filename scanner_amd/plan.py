@@ -117,17 +117,22 @@ class Plan:
     def wait(self, slot):
         capi.check(self._L.scn_wait(self._h, slot), "scn_wait")
 
-    def collect(self, slot, want_power=True, want_hits=True, hit_cap=None):
+    def collect(self, slot, want_power=True, want_hits=True, hit_cap=None, hits_out=None):
         """Block on the slot and return (power_db [B,n] | None, hits (HIT_DTYPE) | None, trigger uint8[B] | None).
         The hit list arrives ordered by (buffer, i) and complete from the GPU.  With hit_cap=None every hit is returned
         however many there are (the part beyond the plan's pinned list is fetched with scn_collect_more); with an
-        explicit hit_cap the C-ABI's own behaviour shows: ScannerError(E_TRUNCATED) when more hits exist."""
+        explicit hit_cap the C-ABI's own behaviour shows: ScannerError(E_TRUNCATED) when more hits exist.
+        hits_out: a caller-owned HIT_DTYPE array to receive the records (its length is the capacity): a loop that
+        collects every step should not pay for a fresh 12 MB allocation and its page faults each time."""
         nb = self._nb[slot]
         have_hits = bool(self.flags & capi.OUT_HITS)
         power = np.empty((nb, self.n), np.float32) if (want_power and self.flags & capi.OUT_SPECTRUM) else None
         want_hits = want_hits and have_hits
         cap = (nb * 64 + 1024) if hit_cap is None else hit_cap
-        hits = np.zeros(cap, capi.HIT_DTYPE) if want_hits else None
+        if hits_out is not None:
+            assert hits_out.dtype == capi.HIT_DTYPE and hits_out.flags.c_contiguous
+            cap, hit_cap = len(hits_out), len(hits_out)
+        hits = (hits_out if hits_out is not None else np.empty(cap, capi.HIT_DTYPE)) if want_hits else None
         trig = np.zeros(nb, np.uint8) if have_hits else None
         n_hits = C.c_uint32()
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
@@ -145,7 +150,7 @@ class Plan:
 
     def collect_more(self, slot, first, count):
         """Records [first, first+count) of the ordered hit list of the slot's last collected submit (scn_collect_more)."""
-        out = np.zeros(count, capi.HIT_DTYPE)
+        out = np.empty(count, capi.HIT_DTYPE)
         done = 0
         while done < count:
             got = C.c_uint32()

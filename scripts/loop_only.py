@@ -1,0 +1,29 @@
+"""The double-buffered counts-only step loop alone (for tracing):  python scripts/loop_only.py [steps] [records 0/1]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from scanner_amd import Plan, capi, synth
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+records = len(sys.argv) > 2 and sys.argv[2] == "1"
+n, nb = 4096, 8192
+dev = torch.device("cuda", 0)
+R = 4
+raws = [synth.cfloat_batch_torch(n, nb, seed=2 + 1000 * r, device=dev) for r in range(R)]
+outs = [torch.empty((nb, n), dtype=torch.float32, device=dev) for r in range(R)]
+fc = 3e6 + 6e6 * np.arange(nb)
+torch.cuda.synchronize()
+plan = Plan(n, 8000000, 10.0, max_batch=nb, max_hits=nb * 64)
+buf = np.zeros(nb * 64, capi.HIT_DTYPE) if records else None
+pend = [False, False]
+t0 = time.perf_counter()
+for k in range(steps):
+    s = k & 1
+    if pend[s]:
+        plan.collect(s, want_power=False, want_hits=records, hits_out=buf)
+    plan.submit_device(s, raws[k % R], nb, fc, None, sync_producer=False, d_power_db=outs[k % R])
+    pend[s] = True
+for s in (0, 1):
+    plan.collect(s, want_power=False, want_hits=records, hits_out=buf)
+torch.cuda.synchronize()
+print((time.perf_counter() - t0) / steps * 1e6, "us/step")

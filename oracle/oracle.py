@@ -60,6 +60,11 @@ _REF_LIB = os.path.join(_HERE, "_ref", "libref_frequency_table.so")
 _ref = None
 
 
+def ref_available():
+    """Whether oracle/_ref has been built -- without loading it (collection must not map reference code into a GPU run)."""
+    return os.path.exists(_REF_LIB)
+
+
 def ref_lib():
     """The reference's own frequencyTable.cpp, compiled from /root/reference by `make -C oracle ref` (the only
     reference source that builds in this image -- see ref_binding.cpp).  None where it has not been built."""

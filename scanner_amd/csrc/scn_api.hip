@@ -121,6 +121,13 @@ struct scn_plan {
   int compact_mode = SCN_COMPACT_AUTO;
   bool records_wanted = false;  // did the last scn_collect ask for hit records? (the automatic mode's hint)
   uint32_t predict = 0;         // records the next list is expected to hold (last total + 25 %): the prefetch size
+  // How the per-buffer counts reach the host.  false: a 4*n_buffers-byte copy on the d2h stream behind the kernel -- on
+  // this ROCm a blit KERNEL, which runs beside the next launch when that leaves it room (up to 4096 points: yes, ~6 us)
+  // and otherwise waits until that launch drains (8192 points: 254 VGPRs x 2 waves per SIMD; the copy took 46 us, the
+  // host learned the counts late and submitted the launch after next ~10 us late, every other launch).  true: the FFT
+  // kernel stores each count to pinned host memory as well (one 4-byte PCIe write per buffer; costs a 4096-point launch
+  // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
+  bool direct_counts = false;
   int fft_cus = 0;  // CUs the FFT launch is sized for (num_cus unless SCN_EXP_RESERVE_CUS leaves some to the side stream)
   hipStream_t stream = nullptr;      // compute
   hipStream_t h2d_stream = nullptr;  // staging copies of scn_submit (overlap the other slot's kernel)
@@ -320,6 +327,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.hits = s.d_hits[s.gen];
   a.hit_region = p->hit_region;
   a.per_buffer_hits = s.d_buf_hits[s.gen];
+  a.host_hits = (hits && p->direct_counts) ? s.h_buf_hits : nullptr;
   a.work_counter = s.d_work_counter;
   for (uint32_t x = 0; x < 8; x++) a.work_base[x] = s.work_base[x];
   SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->fft_cus, s.stream));
@@ -333,14 +341,14 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     // onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one).
     const bool eager = p->compact_mode == SCN_COMPACT_INLINE || p->compact_mode == SCN_COMPACT_SIDE ||
                        (p->compact_mode == SCN_COMPACT_AUTO && p->records_wanted);
-    hipStream_t cnt = s.own_stream ? s.stream : p->d2h_stream;
+    hipStream_t cnt = (s.own_stream || p->direct_counts) ? s.stream : p->d2h_stream;
     hipStream_t lst = list_stream_of(p, s);
-    if (!s.own_stream) {
-      SCN_HIP(hipEventRecord(s.kernel_done, s.stream));
-      SCN_HIP(hipStreamWaitEvent(cnt, s.kernel_done, 0));
-      if (eager && lst != s.stream) SCN_HIP(hipStreamWaitEvent(lst, s.kernel_done, 0));
-    }
-    SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits[s.gen], sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, cnt));
+    const bool fork_list = eager && lst != s.stream;
+    if (cnt != s.stream || fork_list) SCN_HIP(hipEventRecord(s.kernel_done, s.stream));
+    if (cnt != s.stream) SCN_HIP(hipStreamWaitEvent(cnt, s.kernel_done, 0));
+    if (fork_list) SCN_HIP(hipStreamWaitEvent(lst, s.kernel_done, 0));
+    if (!p->direct_counts)
+      SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits[s.gen], sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, cnt));
     SCN_HIP(hipEventRecord(s.done, cnt));
     if (eager) {
       int st2 = build_list(p, s, true);
@@ -437,7 +445,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   if (d.mode != SCN_MODE_FREQUENCY_DOMAIN && d.mode != SCN_MODE_TIME_DOMAIN)
     return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
   if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n))
-    return fail(SCN_E_INVALID, "unsupported FFT size %u (1024, 2048, 4096, 8192)", d.n);
+    return fail(SCN_E_INVALID, "unsupported FFT size %u (1024, 2048, 4096, 8192, 16384)", d.n);
   if (d.n == 0 || d.n > (1u << 24)) return fail(SCN_E_INVALID, "bad sample count %u", d.n);
   if (d.sample_rate == 0) return fail(SCN_E_INVALID, "sample_rate must be > 0");
 
@@ -478,6 +486,8 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     p->fft_cus = p->num_cus;
     if (const char *e = getenv("SCN_EXP_COMPACT")) p->compact_mode = atoi(e);
     if (const char *e = getenv("SCN_EXP_RESERVE_CUS")) p->fft_cus = std::max(1, p->num_cus - atoi(e));
+    p->direct_counts = d.n >= 8192;
+    if (const char *e = getenv("SCN_EXP_DIRECT_COUNTS")) p->direct_counts = atoi(e) != 0;
     SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->h2d_stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->d2h_stream, hipStreamNonBlocking));

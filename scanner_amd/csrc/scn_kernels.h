@@ -41,6 +41,8 @@ struct ScnFftArgs {
   ScnDevHit *hits;            // [n_buffers][hit_region]
   uint32_t hit_region;
   uint32_t *per_buffer_hits;  // [n_buffers] total hits of each buffer (device memory)
+  uint32_t *host_hits;        // optional second copy of the same counts in pinned HOST memory, written by the kernel (see
+                              // scn_plan::direct_counts in scn_api.hip for when that beats a copy behind the kernel)
   // buffer queue of the persistent workgroups: 8 heads, 32 words (one 128-byte line) apart, never reset; head x
   // serves the buffers b = 8 j + x; work_base[x] is its value before this launch and a launch adds exactly the
   // number of such buffers (scn_work_shard_count) to it
@@ -55,7 +57,7 @@ struct ScnFftArgs {
 // ... and only from 4096 points up: a launch of the same sample count makes 4x / 2x as many dequeues at 1024 / 2048
 // points, and the queue heads then become the bottleneck (1024-pt int16: 64.7 us static, 90.7 us with the queue)
 static constexpr bool scn_uses_queue(int kind, uint32_t n) {
-  return SCN_DYNAMIC_WORK != 0 && kind != SCN_K_FLOAT_COMPLEX && n >= 4096;
+  return SCN_DYNAMIC_WORK != 0 && kind != SCN_K_FLOAT_COMPLEX && n >= 4096 && n <= 8192;  // (16384: static, one workgroup per CU)
 }
 // number of buffers b < n_buffers with b % 8 == shard
 static inline uint32_t scn_work_shard_count(uint32_t n_buffers, uint32_t shard) {

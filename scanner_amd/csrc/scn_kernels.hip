@@ -427,6 +427,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       // every wave has passed the barrier above, so the previous buffer's recorders are done
       if (t == 0 && prev != 0xffffffffu) {
         args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
         lds_hits[par ^ 1] = 0;
       }
     }
@@ -564,7 +565,10 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #endif
   if (HITS) {
     __syncthreads();  // last buffer's recorders done
-    if (t == 0 && prev != 0xffffffffu) args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+    if (t == 0 && prev != 0xffffffffu) {
+      args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+      if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+    }
   }
 }
 
@@ -728,6 +732,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
     if (HITS) {
       if (t == 0 && prev != 0xffffffffu) {  // every wave is past the barrier: the previous buffer's recorders are done
         args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
         lds_hits[par ^ 1] = 0;
       }
     }
@@ -823,7 +828,247 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   }
   if (HITS) {
     __syncthreads();  // last buffer's recorders done
-    if (t == 0 && prev != 0xffffffffu) args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+    if (t == 0 && prev != 0xffffffffu) {
+      args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+      if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 16384 points: ONE workgroup of 256 threads per buffer, 64 points per thread, one workgroup per CU.
+//
+// The reference builds an FFTW plan for whatever --count it is given (fft.cpp:4-11, scan.cpp:85); 16384 is the largest
+// size whose buffer still fits the CU's LDS (128 KiB of complex floats + tables = 137 KiB of 160).  Same
+// decomposition as the other sizes (n = 1024a + 64b + c, k = p + 16q + 256r, passes 16 x 16 x 64): a thread plays
+// FOUR of the 1024 "virtual threads" of passes 1 and 2 (tau = t + 256h) and owns one whole 64-point DFT in pass 3
+// (four in-register 16-point DFTs over c = 4c' + e, the W_64^(e r') twiddles, one radix-4 step).  One wave per SIMD
+// means nothing hides a wave's latencies but its own instruction stream, so the kernel leans on the 512-register
+// budget instead: window taps stay resident, the next buffer's raw samples are prefetched for the integer formats
+// (64 registers; a float buffer would need 128 and is loaded at the top of the loop), and the pass-1 twiddles come
+// from their L2-resident table every buffer (120 registers otherwise).  LDS layouts: P1 = 1024, P2 = 257 -- the
+// same per-instruction bank behaviour as Geo8k (64 lanes = 64 consecutive c in exchange 1, consecutive kl in
+// exchange 2).
+// ------------------------------------------------------------------------------------
+namespace {
+struct Geo16k {
+  static constexpr uint32_t N = 16384, T = 256, M = 64, P1 = 1024, P2 = 257;
+  static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + 1024u * 8u + 16u * 4u + 2u * 4u + 8u;
+  static constexpr uint32_t WG_PER_CU = 1;
+};
+}  // namespace
+
+template <int KIND, bool DC, bool HITS>
+__global__ __launch_bounds__(256, 1) void scn_fft16k_kernel(ScnFftArgs args) {
+  typedef Geo16k G;
+  constexpr int AUX_LD = SCN_AUX_LD;
+  constexpr int AUX_ST = SCN_AUX_ST;
+  constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
+  constexpr bool PF = KIND != SCN_K_FLOAT_COMPLEX;  // register prefetch of the next buffer
+  typedef RawLoader<KIND> L;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+  v2f *lds_tw2 = lds + G::EXCH;                              // [16][64]: W_1024^(c q) at q*64 + c
+  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + 1024);   // [16] DC-sum scratch (re[8], im[8])
+  int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
+
+  const uint32_t t = threadIdx.x;
+  const uint32_t lane = t & 63, wave = t >> 6;
+  const uint32_t c2 = t & 63u, p2 = t >> 6;  // pass-2 identity of virtual thread t + 256h: (p2 + 4h, c2)
+
+  typename L::raw_t raw[64];
+  auto load_buffer = [&](uint32_t b, bool valid) {
+    const __amdgpu_buffer_rsrc_t r =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)b * L::kBufBytes(N), (valid && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
+#pragma unroll
+    for (int a = 0; a < 64; a++) raw[a] = L::template load<AUX_LD>(r, N, t, T * a);  // x[256 a' + t], a' = 4a + h
+  };
+  if (PF) load_buffer(blockIdx.x, blockIdx.x < args.n_buffers);
+  float win[64];
+#pragma unroll
+  for (int a = 0; a < 64; a++) win[a] = args.window[T * a + t] * args.scale;
+  // pass-2 twiddles W_1024^(c q) = W_N^(16 c q), entry q*64 + c: this thread fills entries t + 256h
+#pragma unroll
+  for (uint32_t h = 0; h < 4; h++) lds_tw2[t + 256u * h] = args.twiddle[(16u * (p2 + 4u * h) * c2) & (N - 1)];
+  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
+  __syncthreads();
+
+  v2f *w1 = lds + t;                       // + p*P1 + 256h
+  v2f *r1 = lds + p2 * P1 + c2;            // + b*64 + 4h*P1
+  v2f *w2 = lds + c2 * P2 + p2;            // + 16*q + 4h
+  v2f *r3 = lds + t;                       // + c*P2
+  const v2f *tw2 = lds_tw2 + c2;           // + q*64
+  const v2f *tw1 = args.tw1_table + t;     // + (p-1)*1024 + 256h
+  const uint32_t st_voff = t * 4u;         // output r of this thread is bin j = t + 256 r
+
+  uint64_t keepmask = 0;  // K5 mask of this thread's 64 bins (process.cpp:46-52)
+  if (HITS) {
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+      const uint32_t j = t + 256u * r;
+      const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
+      const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
+      keepmask |= keep ? (1ull << r) : 0ull;
+    }
+  }
+  uint32_t par = 0;
+  uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running
+
+  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
+    const uint32_t nxt = buf + gridDim.x;
+    const bool more = nxt < args.n_buffers;
+    if (!PF) load_buffer(buf, true);
+    // ---- K1 + K2 ----
+    int dc_re = 0, dc_im = 0;
+    if (DC) {
+      int sr = 0, si = 0;
+#pragma unroll
+      for (int a = 0; a < 64; a++) {
+        int re, im;
+        L::ints(raw[a], re, im);
+        sr += re;
+        si += im;
+      }
+      sr = wave_sum(sr);
+      si = wave_sum(si);
+      if (lane == 0) {
+        lds_cnt[wave] = sr;
+        lds_cnt[8 + wave] = si;
+      }
+      __syncthreads();
+      sr = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
+      si = lds_cnt[8] + lds_cnt[9] + lds_cnt[10] + lds_cnt[11];
+      dc_re = (int)((uint32_t)sr / N);  // int32 /= uint32, utility.cpp:77-78
+      dc_im = (int)((uint32_t)si / N);
+    }
+    // ---- pass 1: the four virtual threads t + 256h, one after the other (16 values live at a time) ----
+    cf v[4][16];
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+#pragma unroll
+      for (int a = 0; a < 16; a++) v[0][a] = L::conv(raw[4 * a + h], dc_re, dc_im, 1.0f) * win[4 * a + h];
+      fft16(v[0]);
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        cf y = v[0][OUT16(p)];
+        if (p) y = cmul(y, from_v2f(tw1[(p - 1) * 1024 + 256 * h]));
+        w1[p * P1 + 256 * h] = to_v2f(y);
+      }
+    }
+    // the raw registers are free: next buffer of this workgroup, branch-free (zero records past the end)
+    if (PF) load_buffer(more ? nxt : buf, more);
+    __syncthreads();
+    if (HITS) {
+      if (t == 0 && prev != 0xffffffffu) {  // every wave is past the barrier: the previous buffer's recorders are done
+        args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        lds_hits[par ^ 1] = 0;
+      }
+    }
+
+    // ---- pass 2: virtual threads (p2 + 4h, c2): all four read before anything is written back ----
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+#pragma unroll
+      for (int b = 0; b < 16; b++) v[h][b] = from_v2f(r1[b * 64 + 4 * h * P1]);
+    }
+#pragma unroll
+    for (int h = 0; h < 4; h++) fft16(v[h]);
+#pragma unroll
+    for (int q = 1; q < 16; q++) {
+      const cf w = from_v2f(tw2[q * 64]);
+#pragma unroll
+      for (int h = 0; h < 4; h++) v[h][OUT16(q)] = cmul(v[h][OUT16(q)], w);
+    }
+    __syncthreads();  // every exchange-1 read done before the area is re-used
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+#pragma unroll
+      for (int h = 0; h < 4; h++) w2[q * 16 + 4 * h] = to_v2f(v[h][OUT16(q)]);
+    }
+    __syncthreads();
+
+    // ---- pass 3: one 64-point DFT over c = 4c' + e per thread (kl = t) ----
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) v[e][c] = from_v2f(r3[(4 * c + e) * P2]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) fft16(v[e]);
+
+    // ---- K4 + K5: X[r' + 16 s] = sum_e W_4^(e s) W_64^(e r') Y_e[r'] ----
+    v32f db_lo, db_hi;  // dB of r = 0..31 and 32..63 (true vectors: the recording path indexes them wave-uniformly)
+    float dmax = -3.40282347e+38f;
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      cf y0 = v[0][OUT16(r)], y1 = v[1][OUT16(r)], y2 = v[2][OUT16(r)], y3 = v[3][OUT16(r)];
+      if (r) {
+        const double ang = 6.283185307179586476925286766559 * r / 64.0;
+        y1 = cmul(y1, cf{(float)__builtin_cos(ang), -(float)__builtin_sin(ang)});
+        y2 = cmul(y2, cf{(float)__builtin_cos(2.0 * ang), -(float)__builtin_sin(2.0 * ang)});
+        y3 = cmul(y3, cf{(float)__builtin_cos(3.0 * ang), -(float)__builtin_sin(3.0 * ang)});
+      }
+      radix4(y0, y1, y2, y3);  // -> X[r], X[r+16], X[r+32], X[r+48]
+      const float d0 = power_db(y0), d1 = power_db(y1), d2 = power_db(y2), d3 = power_db(y3);
+      db_lo[r] = d0;
+      db_lo[r + 16] = d1;
+      db_hi[r] = d2;
+      db_hi[r + 16] = d3;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d0), rout, st_voff, 1024u * r, AUX_ST);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), rout, st_voff, 1024u * (r + 16), AUX_ST);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d2), rout, st_voff, 1024u * (r + 32), AUX_ST);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d3), rout, st_voff, 1024u * (r + 48), AUX_ST);
+      if (HITS) dmax = fmaxf(fmaxf(dmax, fmaxf(d0, d1)), fmaxf(d2, d3));
+    }
+    __syncthreads();  // exchange area free again
+    if (HITS) {
+      if (__ballot(dmax > args.threshold)) {
+        uint32_t hit_lo = 0, hit_hi = 0;
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+          hit_lo |= (db_lo[r] > args.threshold) ? (1u << r) : 0u;  // strict >, process.cpp:54
+          hit_hi |= (db_hi[r] > args.threshold) ? (1u << r) : 0u;
+        }
+        hit_lo &= (uint32_t)keepmask;
+        hit_hi &= (uint32_t)(keepmask >> 32);
+        const uint32_t total = wave_add_u32((uint32_t)__popc(hit_lo) + (uint32_t)__popc(hit_hi));
+        if (total) {
+          uint32_t base = 0;
+          if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
+          base = __builtin_amdgcn_readfirstlane(base);
+          ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+#pragma unroll
+          for (int half = 0; half < 2; half++) {
+            const uint32_t mine = half ? hit_hi : hit_lo;
+            uint32_t wm = wave_or_u32(mine);
+            while (wm) {
+              const int r = __builtin_ctz(wm);  // wave-uniform
+              wm &= wm - 1u;
+              const bool hit = (mine >> r) & 1u;
+              const unsigned long long m = __ballot(hit);
+              if (hit) {
+                const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t j = t + 256u * (uint32_t)(r + 32 * half);
+                if (pos < args.hit_region) region[pos] = ScnDevHit{j ^ (N / 2), half ? db_hi[r] : db_lo[r]};
+              }
+              base += (uint32_t)__popcll(m);
+            }
+          }
+        }
+      }
+      prev = buf;
+      par ^= 1;
+    }
+  }
+  if (HITS) {
+    __syncthreads();  // last buffer's recorders done
+    if (t == 0 && prev != 0xffffffffu) {
+      args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+      if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+    }
   }
 }
 
@@ -1129,6 +1374,31 @@ static hipError_t launch_8k(int kind, bool dc, bool hits, const ScnFftArgs &args
   }
 }
 
+template <int KIND>
+static hipError_t launch_16k_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
+  typedef Geo16k G;
+  void (*k)(ScnFftArgs) = nullptr;
+  if (dc && hits) k = scn_fft16k_kernel<KIND, true, true>;
+  else if (dc) k = scn_fft16k_kernel<KIND, true, false>;
+  else if (hits) k = scn_fft16k_kernel<KIND, false, true>;
+  else k = scn_fft16k_kernel<KIND, false, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  int grid = num_cus * (int)G::WG_PER_CU;
+  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), G::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+static hipError_t launch_16k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream) {
+  switch (kind) {
+    case SCN_K_FLOAT_COMPLEX: return launch_16k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream);
+    case SCN_K_SHORT_COMPLEX: return launch_16k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream);
+    case SCN_K_SHORT: return launch_16k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream);
+    case SCN_K_BYTE_COMPLEX: return launch_16k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus,
                           hipStream_t stream) {
   if (args.n_buffers == 0) return hipSuccess;
@@ -1141,8 +1411,9 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFft
 #else
     case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream);  // the 512-thread form (variant build)
 #endif
+    case 16384: return launch_16k(kind, dc, hits, args, num_cus, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-bool scn_fft_size_supported(uint32_t n) { return n == 1024 || n == 2048 || n == 4096 || n == 8192; }
+bool scn_fft_size_supported(uint32_t n) { return n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }

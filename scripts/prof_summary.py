@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KER = "scn_fft"
+KER = os.environ.get("SCN_PROF_KERNEL", "scn_fft")  # substring of the kernel(s) being judged ("scn_welch" for C5)
 
 
 def find(pattern):
@@ -36,6 +36,16 @@ def stats(label, d):
           f"min={d[0]/1e3:.2f}us max={d[-1]/1e3:.2f}us")
 
 
+by_name = defaultdict(list)
+for f in find("trace/**/*kernel_trace.csv"):
+    for row in csv.DictReader(open(f)):
+        if KER in row.get("Kernel_Name", ""):
+            by_name[row["Kernel_Name"][:70]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+kernel_avg_us = {}
+for name, d in by_name.items():
+    tail = d[len(d) // 5:]  # drop the settle / warm-up fifth
+    kernel_avg_us[name] = sum(tail) / len(tail) / 1e3
+    print(f"  {name}: n={len(d)} avg(after first 20%)={kernel_avg_us[name]:.2f}us")
 if recs:
     recs.sort()
     print(f"{KER} launches in the trace (settle + warmup + timed steps + the final hit-list sweep):", meta)
@@ -47,14 +57,24 @@ if recs:
         print("  (timed region not separable:", e, ")")
 print("== PMC (average per launch of the FFT kernel) ==")
 summary = {}
+per_kernel = defaultdict(dict)
 for f in find("pmc_*/**/*counter_collection.csv"):
     acc = defaultdict(list)
+    acck = defaultdict(lambda: defaultdict(list))
     for row in csv.DictReader(open(f)):
         if KER in row.get("Kernel_Name", ""):
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            acck[row["Kernel_Name"][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in acc.items():
         summary[k] = sum(v) / len(v)
         print(f"{k:28s} {summary[k]:.4g}   (n={len(v)})")
+    for kn, cs in acck.items():
+        for k, v in cs.items():
+            per_kernel[kn][k] = sum(v) / len(v)
+if len(per_kernel) > 1:
+    for kn, cs in per_kernel.items():
+        if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
+            print(f"  {kn}: read {cs.get('FETCH_SIZE', 0) * 2048:.4g} B  write {cs.get('WRITE_SIZE', 0) * 1024:.4g} B per launch")
 if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
     # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
     # exactly half of the bytes of a wide coalesced streaming read -> double it.
@@ -64,10 +84,16 @@ if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
     shape = {}
     try:  # the launch shape the counters belong to (bench.py only reports them for the same shape)
         cfg = json.loads(open(os.path.join(out, "bench_trace.json")).read().strip().splitlines()[-1])["config"]
-        shape = {k: cfg[k] for k in ("n", "sample_kind", "batch_per_gpu")}
+        shape = {k: cfg.get(k) for k in ("n", "sample_kind", "batch_per_gpu", "buffers_per_launch", "segments_per_psd", "psd_per_submit")}
     except Exception:
         pass
+    if len(per_kernel) > 1:  # several kernels make up one step (Welch: columns + rows): bytes per step = the sum
+        fetch = sum(cs.get("FETCH_SIZE", 0) for cs in per_kernel.values()) * 1024 * 2
+        write = sum(cs.get("WRITE_SIZE", 0) for cs in per_kernel.values()) * 1024
+        print(f"hbm_bytes_per_step over {len(per_kernel)} kernels = {fetch + write:.4g}  (read {fetch:.4g}, write {write:.4g})")
     json.dump(dict({"hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write,
+                    "kernel_avg_us": sum(kernel_avg_us.values()) if kernel_avg_us else None,
+                    "kernels": {k: round(v, 3) for k, v in kernel_avg_us.items()},
                     "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 correction)"},
                    **shape),
               open(os.path.join(out, "pmc_traffic.json"), "w"))

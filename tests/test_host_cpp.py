@@ -262,3 +262,43 @@ def test_triggered_capture_file(host_build, oracle_mod, tmp_path, kind, enob):
     dt = {"short_complex": np.int16, "float": np.complex64}[kind]
     want = np.stack([o.convert(r.view(dt)) for r in raw])
     assert np.array_equal(got, want)                                     # bit-exact K1 on the GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,total,batch", [(4096, 37, 8), (1024, 100, 33)])
+def test_sample_buffer_through_pinned_staging_slots(host_build, oracle_mod, tmp_path, n, total, batch):
+    """SampleBuffer -> HipStagingProcessInterface -> the plan's pinned slots -> scn_submit, double-buffered (the north
+    star's replacement for sampleBuffer.cpp's host staging), in C++ on the GPU; spectra and hit list against the oracle."""
+    from scanner_amd import capi, synth
+    from tests import tolerances as tol
+
+    exe = tmp_path / "test_staging_gpu"
+    subprocess.check_call(["g++", "-std=gnu++11", "-O1", "-g", "-Wall", "-pthread", "-I", HOST,
+                           os.path.join(ROOT, "tests", "cpp", "test_staging_gpu.cpp"), "-o", str(exe),
+                           "-L" + os.path.join(ROOT, "scanner_amd"), "-lscanner_host", "-lscanner_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "scanner_amd")])
+    x = synth.cfloat_batch(n, total, seed=77)
+    fc = 100e6 + 6e6 * np.arange(total)
+    p_ref, _, _ = oracle_mod.Oracle(n, 8000000, 1e9).run(x)
+    thr = tol.pick_threshold(p_ref, n, start=9.0)
+    p_ref, h_ref, t_ref = oracle_mod.Oracle(n, 8000000, thr).run(x, fc, np.arange(total, dtype=np.uint64))
+    (tmp_path / "in.c64").write_bytes(x.tobytes())
+    out = subprocess.run([str(exe), str(tmp_path / "in.c64"), str(n), str(total), str(batch), repr(thr), str(tmp_path / "out.bin")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    raw = (tmp_path / "out.bin").read_bytes()
+    pos, powers, hits, trig, batches = 0, [], [], [], 0
+    while pos < len(raw):
+        nb, nh = np.frombuffer(raw, np.uint32, 2, pos)
+        pos += 8
+        powers.append(np.frombuffer(raw, np.float32, n * nb, pos).reshape(nb, n)); pos += 4 * n * nb
+        hits.append(np.frombuffer(raw, capi.HIT_DTYPE, nh, pos)); pos += 24 * nh
+        trig.append(np.frombuffer(raw, np.uint8, nb, pos)); pos += nb
+        batches += 1
+    assert batches == -(-total // batch) and batches > 2                   # both slots were used more than once
+    tol.compare_spectra(np.concatenate(powers), p_ref)
+    h = np.concatenate(hits)
+    assert len(h) == len(h_ref) > 10
+    for f in ("seq_id", "i", "freq_hz"):
+        assert np.array_equal(h[f], h_ref[f]), f
+    assert np.array_equal(np.concatenate(trig), t_ref)

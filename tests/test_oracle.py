@@ -88,7 +88,7 @@ def test_convert_known_answers(oracle_mod):
     assert np.array_equal(run(O.KIND_SHORT, 12, True, planar), k["s16_dcpos_out"])
 
 
-@pytest.mark.parametrize("n", [1024, 4096, 8192])
+@pytest.mark.parametrize("n", [1024, 4096, 8192, 16384])
 def test_oracle_spectrum_vs_float64_golden(oracle_mod, n):
     g = np.load(os.path.join(GOLD, f"spectrum_n{n}.npz"))
     x = synth.cfloat_batch(n, int(g["n_buffers"]), int(g["seed"]))

@@ -3,7 +3,8 @@
 /root/reference/frequencyTable.cpp needs only the standard library, so `make -C oracle ref` compiles it from where it
 lies (with oracle/ref_binding.cpp) into oracle/_ref/.  tests/golden/frequency_table_ref.npz was generated from that
 build (tests/golden/make_frequency_table_ref.py) and is what these tests always check; where oracle/_ref is present
-(this container, and the GPU box: built .so files travel) the live reference is compared on random sweeps too.
+the live reference is compared on random sweeps too.  All of it is CPU work (`-m "not gpu"`): the built file is loaded
+lazily, by those tests only, so a `-m gpu` run on the GPU box never maps it.
 Checked against it: the oracle's restatement, the product's scn_frequency_table (GPU-free entry point of the C-ABI
 library) and the host mirror's FrequencyTable class (tables and the GetCurrent/GetNext/GetIsScanStart walk)."""
 import ctypes as C
@@ -78,7 +79,7 @@ def test_host_mirror_walks_like_the_reference(host_table_lib, k):
     assert f.tobytes() == wf.tobytes() and np.array_equal(it, wit) and np.array_equal(ss, wss)
 
 
-needs_ref = pytest.mark.skipif(oracle.ref_lib() is None, reason="oracle/_ref not built (needs /root/reference)")
+needs_ref = pytest.mark.skipif(not oracle.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
 
 
 @needs_ref

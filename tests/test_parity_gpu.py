@@ -229,9 +229,9 @@ def test_c1_known_answer_tone_1024(torch_cuda, oracle_mod):
     assert "freq %d power_db %f" % (h["freq_hz"][2], h["power_db"][2]) == "freq 100999680 power_db 22.636375"
 
 
-@pytest.mark.parametrize("n", [1024, 2048, 8192])
+@pytest.mark.parametrize("n", [1024, 2048, 8192, 16384])
 def test_sizes_cfloat_vs_oracle_and_golden(torch_cuda, oracle_mod, n):
-    nb = {1024: 300, 2048: 130, 8192: 70}[n]          # not a multiple of the resident grid
+    nb = {1024: 300, 2048: 130, 8192: 70, 16384: 300}[n]          # not a multiple of the resident grid
     x = synth.cfloat_batch(n, nb, seed=40 + n)
     fc = 3e6 + 6e6 * np.arange(nb)
     p_ref, _, _ = oracle_mod.Oracle(n, FS, 1e9).run(x, threads=4)
@@ -260,6 +260,10 @@ def test_sizes_cfloat_vs_oracle_and_golden(torch_cuda, oracle_mod, n):
     (1024, capi.KIND_BYTE_COMPLEX, 8, True),
     (2048, capi.KIND_SHORT, 12, False),
     (2048, capi.KIND_SHORT_COMPLEX, 16, True),
+    (16384, capi.KIND_SHORT_COMPLEX, 12, False),   # the largest size that fits the LDS (scn_fft16k_kernel)
+    (16384, capi.KIND_SHORT_COMPLEX, 12, True),
+    (16384, capi.KIND_BYTE_COMPLEX, 8, True),
+    (16384, capi.KIND_SHORT, 14, False),
 ])
 def test_sizes_integer_kinds(torch_cuda, oracle_mod, n, kind, enob, dc):
     nb = 37
@@ -275,7 +279,7 @@ def test_sizes_integer_kinds(torch_cuda, oracle_mod, n, kind, enob, dc):
     assert np.array_equal(t, t_ref)
 
 
-@pytest.mark.parametrize("n", [1024, 8192])
+@pytest.mark.parametrize("n", [1024, 8192, 16384])
 def test_sizes_all_bins_hit_mask(torch_cuda, oracle_mod, n):
     """mask edges (DC window, use-band) and the i <-> j mapping at the other sizes"""
     nb = 3

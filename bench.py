@@ -74,7 +74,7 @@ def parse():
                          "gathered and checked on rank 0 -- exercises the launcher, rendezvous, sharding, gather and the JSON line")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0: pick a free one)")
     ap.add_argument("--welch", action="store_true", help="BASELINE config C5: streaming 65536-pt 50%%-overlap Welch PSD")
-    ap.add_argument("--welch-psd", type=int, default=8, help="PSDs per submit (K=16 segments each)")
+    ap.add_argument("--welch-psd", type=int, default=32, help="PSDs per submit (K=16 segments each)")
     ap.add_argument("--welch-pinned", action="store_true", help="feed from pinned host memory through the captured hipGraph")
     return ap.parse_args()
 
@@ -190,6 +190,11 @@ def welch_main(args):
         algo = new_samples * 8 + npsd * N * 4  # 8 B per NEW sample + 4N/K per segment
         ms = elapsed / args.steps * 1e3
         achieved = algo / (ms * 1e-3) / 1e9
+        prof = {}
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "measured_shapes.json"))).get(f"welch/{N}/{K}/{npsd}", {})
+        except Exception:
+            pass
         emit({
             "metric": "Msamples/s (new complex samples through 65536-pt 50%-overlap Welch PSD)",
             "value": round(world * new_samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
@@ -419,7 +424,8 @@ def main():
     raw = raws[0]
     torch.cuda.synchronize()
 
-    plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=nb * 64, device_id=local_rank)
+    hit_cap = nb * max(64, n // 64)  # records the plan keeps per slot / the caller's buffer: ample for this input
+    plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank)
     ext = torch.cuda.ExternalStream(plan.stream_handle, device=dev)
 
     def make_loop(pl, want_records):
@@ -427,7 +433,7 @@ def main():
         results of a slot are collected right before it is reused (counts + trigger flags; the ordered records too if asked)"""
         pending = [False, False]
         state = {"launch": 0, "hits": 0}
-        rec_buf = np.zeros(nb * 64, capi.HIT_DTYPE) if want_records else None  # the caller's record buffer, reused
+        rec_buf = np.zeros(hit_cap, capi.HIT_DTYPE) if want_records else None  # the caller's record buffer, reused
 
         def collect(s):
             tc0 = time.perf_counter()
@@ -530,7 +536,7 @@ def main():
                            sync_producer=False)
         plan.wait(0)
         time.sleep(0.002)  # the compaction behind the kernel has finished too
-        rec_buf = np.zeros(nb * 64, capi.HIT_DTYPE)
+        rec_buf = np.zeros(hit_cap, capi.HIT_DTYPE)
         tc = time.perf_counter()
         _, h1, _ = plan.collect(0, want_power=False, want_hits=True, hits_out=rec_buf)
         collect_us = (time.perf_counter() - tc) * 1e6
@@ -548,7 +554,7 @@ def main():
     # roofline object and rocprofv3 divide by -- grows while it shares the GPU, so it stays out of them.
     overlap = None
     if not args.no_overlap_leg:
-        plan2 = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=nb * 64, device_id=local_rank,
+        plan2 = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank,
                      flags=capi.OUT_SPECTRUM | capi.OUT_HITS | capi.PLAN_OVERLAP_SLOTS)
         el2, _ = timed_leg(plan2, False, max(args.warmup, 200))
 

@@ -860,6 +860,7 @@ struct WelchSlot {
   hipGraphExec_t graph = nullptr;  // captured H2D -> kernel A -> kernel B -> D2H for graph_npsd PSDs
   hipStream_t stream = nullptr;    // the pinned path's own stream: this slot's H2D overlaps the other slot's kernels
   void *d_work = nullptr;          // ... which needs a work buffer of its own ([max_psd*K][n] complex)
+  float *d_partial = nullptr;      // ... and its own partial sums
   uint32_t graph_npsd = 0;
   hipEvent_t done = nullptr;
   bool pending = false;
@@ -875,6 +876,9 @@ struct scn_welch {
   float *d_window = nullptr;
   scn_v2f *d_twiddle = nullptr;
   void *d_work = nullptr;  // [max_psd*K][n] complex
+  float *d_partial = nullptr;  // [parts][max_psd][n] partial power sums (row kernel -> combine kernel); shared by the slots
+                               // through stream order on the device path, per-slot copies on the pinned path
+  uint32_t parts = 1;
   WelchSlot slot[SCN_NUM_SLOTS];
 };
 
@@ -883,8 +887,11 @@ size_t welch_samples(const scn_welch *w, uint32_t n_psd) {
   return ((size_t)n_psd * w->d.segments_per_psd + 1u) * w->hop;
 }
 
-int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd, hipStream_t stream, void *d_work) {
+int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd, hipStream_t stream, void *d_work,
+                  float *d_partial) {
   ScnWelchArgs a;
+  a.partial = d_partial;
+  a.parts = w->parts;
   a.in = d_in;
   a.window = w->d_window;
   a.twiddle = w->d_twiddle;
@@ -944,6 +951,11 @@ int scn_welch_create(const scn_welch_desc *desc, scn_welch **out) {
     if ((e = hipMalloc(&w->d_window, sizeof(float) * d.n)) != hipSuccess) break;
     if ((e = hipMalloc(&w->d_twiddle, sizeof(float) * 2 * d.n)) != hipSuccess) break;
     if ((e = hipMalloc(&w->d_work, sizeof(float) * 2 * (size_t)d.n * d.max_psd * d.segments_per_psd)) != hipSuccess) break;
+    // enough row workgroups for one per CU: 16 tiles x max_psd x parts >= CUs, parts <= 4 and <= K (measured, 8 PSDs per
+    // submit: 68.5 / 75.9 / 73.7 Gsamples/s with 1 / 2 / 4 parts; from 16 PSDs per submit up the split only costs)
+    while (w->parts < 4u && w->parts * 2u <= d.segments_per_psd && 16u * d.max_psd * w->parts < (uint32_t)w->num_cus) w->parts *= 2u;
+    if (const char *env = getenv("SCN_EXP_WELCH_PARTS")) w->parts = std::max(1, std::min(atoi(env), (int)d.segments_per_psd));
+    if (w->parts > 1 && (e = hipMalloc(&w->d_partial, sizeof(float) * (size_t)d.n * d.max_psd * w->parts)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(w->d_window, win.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, w->stream)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(w->d_twiddle, tw.data(), sizeof(float) * 2 * d.n, hipMemcpyHostToDevice, w->stream)) != hipSuccess) break;
     e = hipStreamSynchronize(w->stream);
@@ -971,11 +983,13 @@ int scn_welch_destroy(scn_welch *w) {
     if (s.d_psd) (void)hipFree(s.d_psd);
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.d_work) (void)hipFree(s.d_work);
+    if (s.d_partial) (void)hipFree(s.d_partial);
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   if (w->d_window) (void)hipFree(w->d_window);
   if (w->d_twiddle) (void)hipFree(w->d_twiddle);
   if (w->d_work) (void)hipFree(w->d_work);
+  if (w->d_partial) (void)hipFree(w->d_partial);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
   return SCN_OK;
@@ -1015,6 +1029,7 @@ int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   if (!s.stream) SCN_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
   if (!s.d_work) SCN_HIP(hipMalloc(&s.d_work, sizeof(float) * 2 * (size_t)w->d.n * w->d.max_psd * w->d.segments_per_psd));
+  if (w->parts > 1 && !s.d_partial) SCN_HIP(hipMalloc(&s.d_partial, sizeof(float) * (size_t)w->d.n * w->d.max_psd * w->parts));
   if (!s.graph || s.graph_npsd != n_psd) {
     // capture the slot's inner loop once per batch size: H2D -> columns -> rows -> D2H
     if (s.graph) {
@@ -1025,7 +1040,7 @@ int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
     SCN_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
     hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, welch_samples(w, n_psd) * 8u, hipMemcpyHostToDevice, s.stream);
     int inner = SCN_OK;
-    if (e == hipSuccess) inner = welch_enqueue(w, s.d_in, n_psd, s.d_psd, s.stream, s.d_work);
+    if (e == hipSuccess) inner = welch_enqueue(w, s.d_in, n_psd, s.d_psd, s.stream, s.d_work, s.d_partial);
     if (e == hipSuccess && inner == SCN_OK)
       e = hipMemcpyAsync(s.h_psd, s.d_psd, sizeof(float) * (size_t)w->d.n * n_psd, hipMemcpyDeviceToHost, s.stream);
     hipError_t e2 = hipStreamEndCapture(s.stream, &graph);
@@ -1061,7 +1076,7 @@ int scn_welch_submit_device(scn_welch *w, int slot, const void *d_samples, uint3
     d_psd_db = s.d_psd;
   }
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-  st = welch_enqueue(w, d_samples, n_psd, d_psd_db, w->stream, w->d_work);
+  st = welch_enqueue(w, d_samples, n_psd, d_psd_db, w->stream, w->d_work, w->d_partial);
   if (st) return st;
   SCN_HIP(hipEventRecord(s.done, w->stream));
   s.pending = true;

@@ -81,7 +81,9 @@ struct ScnWelchArgs {
   const scn_v2f *twiddle;  // W_65536^m
   void *work;              // [n_segments][65536] complex: Y[k1][n2] between the two kernels
   float *psd_db;           // [n_psd][65536]
+  float *partial;          // [parts][n_psd][65536] partial |X|^2 sums between the row and the combine kernel
   uint32_t n_segments, hop, k, n_psd;
+  uint32_t parts;          // workgroups that share the K segments of one PSD row tile (1: no combine kernel)
   float inv_k;
 };
 hipError_t scn_launch_welch(const ScnWelchArgs &args, int num_cus, hipStream_t stream);

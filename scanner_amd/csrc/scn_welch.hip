@@ -20,7 +20,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "scn_device.h"
+
+#ifndef SCN_WELCH_AUX_IN
+#define SCN_WELCH_AUX_IN 0  // cache policy of the input stream loads (each sample is read by two overlapping segments)
+#endif
 
 namespace {
 constexpr uint32_t WN = 65536;
@@ -52,15 +58,27 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
   const uint32_t ld_voff = (256u * hi + n2) * 8u;        // + a*16*256*8
   const uint32_t st_voff = (256u * hi + n2) * 8u;        // k1 = hi + 16q: + q*16*256*8
 
+  // the next segment's 16 samples per thread are fetched while this one is transformed (branch-free: a segment past
+  // the end gets a zero-record descriptor)
+  auto in_rsrc = [&](uint32_t seg) {
+    const bool ok = seg < args.n_segments;
+    return make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)(ok ? seg : 0u) * args.hop * 8u, ok ? WN * 8u : 0u);
+  };
+  v2f raw[16];
+  {
+    const __amdgpu_buffer_rsrc_t r0 = in_rsrc(g);
+#pragma unroll
+    for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
+  }
   for (uint32_t seg = g; seg < args.n_segments; seg += G) {
-    __amdgpu_buffer_rsrc_t rin =
-        make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)seg * args.hop * 8u, WN * 8u);
     __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)seg * WN * 8u, WN * 8u);
     cf v[16];
 #pragma unroll
-    for (int a = 0; a < 16; a++) {
-      v2f x = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rin, ld_voff, a * 32768u, 0));
-      v[a] = from_v2f(x) * win[a];
+    for (int a = 0; a < 16; a++) v[a] = from_v2f(raw[a]) * win[a];
+    {
+      const __amdgpu_buffer_rsrc_t rn = in_rsrc(seg + G);
+#pragma unroll
+      for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
     }
     fft16(v);
 #pragma unroll
@@ -84,14 +102,20 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
 }
 
 // ---- kernel B: rows + Welch accumulation -------------------------------------------------
-// grid = 16 row tiles x n_psd; workgroup (i, psd) loops over the K segments of its PSD.
+// grid = 16 row tiles x n_psd x parts; workgroup (i, psd, part) accumulates |X|^2 over ITS share of the PSD's K
+// segments in registers and leaves a partial sum per bin; kernel C adds the parts in order and takes the dB.
+// Why parts: a thread owns 16 bins of one row for the whole PSD, so rows x PSDs fixes the number of waves -- 512 for
+// 8 PSDs, two per CU, each walking its K segments one load round trip at a time (the first version: 30 us at
+// 2.3 TB/s of work-buffer reads, half the CUs empty).  Four parts quadruple the waves, and the next segment's
+// values are fetched while the current one is transformed.
 __global__ __launch_bounds__(256, 3) void scn_welch_rows_kernel(ScnWelchArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
   const uint32_t t = threadIdx.x;
-  const uint32_t i = blockIdx.x & 15u, psd = blockIdx.x >> 4;
+  const uint32_t i = blockIdx.x & 15u, psd = (blockIdx.x >> 4) % args.n_psd, part = (blockIdx.x >> 4) / args.n_psd;
   const uint32_t hi = t >> 4, lo = t & 15u;  // pass 1: (rho, b)   pass 2: (rho, p)
   const uint32_t k1 = 16u * i + hi;
+  const uint32_t s_lo = (args.k * part) / args.parts, s_hi = (args.k * (part + 1u)) / args.parts;  // this part's segments
 
   cf twa[16];
 #pragma unroll
@@ -105,13 +129,25 @@ __global__ __launch_bounds__(256, 3) void scn_welch_rows_kernel(ScnWelchArgs arg
 #pragma unroll
   for (int q = 0; q < 16; q++) acc[q] = 0.0f;
 
-  for (uint32_t s = 0; s < args.k; s++) {
-    const uint32_t seg = psd * args.k + s;
-    __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<const char *>(args.work) + (size_t)seg * WN * 8u, WN * 8u);
+  auto wk_rsrc = [&](uint32_t s) {
+    const bool ok = s < s_hi;
+    return make_rsrc(reinterpret_cast<const char *>(args.work) + (size_t)(psd * args.k + (ok ? s : s_lo)) * WN * 8u, ok ? WN * 8u : 0u);
+  };
+  v2f raw[16];
+  {
+    const __amdgpu_buffer_rsrc_t r0 = wk_rsrc(s_lo);
+#pragma unroll
+    for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 128u, 0));
+  }
+  for (uint32_t s = s_lo; s < s_hi; s++) {
     cf v[16];
 #pragma unroll
-    for (int a = 0; a < 16; a++)
-      v[a] = from_v2f(__builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rwk, ld_voff, a * 128u, 0)));
+    for (int a = 0; a < 16; a++) v[a] = from_v2f(raw[a]);
+    {
+      const __amdgpu_buffer_rsrc_t rn = wk_rsrc(s + 1u);
+#pragma unroll
+      for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 128u, 0));
+    }
     fft16(v);
 #pragma unroll
     for (int p = 0; p < 16; p++) {
@@ -126,19 +162,39 @@ __global__ __launch_bounds__(256, 3) void scn_welch_rows_kernel(ScnWelchArgs arg
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       const cf x = v[OUT16(q)];
-      // |X|^2 exactly as the single-FFT path forms it, summed over segments in order s = 0..K-1
+      // |X|^2 exactly as the single-FFT path forms it, summed over this part's segments in order
       acc[q] += __builtin_fmaf(x.y, x.y, x.x * x.x);
     }
     __syncthreads();
   }
   // bin k = k1 + 256*k2, k2 = p + 16q (p = lo)
-  __amdgpu_buffer_rsrc_t rout = make_rsrc(args.psd_db + (size_t)psd * WN, WN * 4u);
   const uint32_t st_voff = (k1 + 256u * lo) * 4u;
+  if (args.parts == 1u) {  // nothing to combine: finish here
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.psd_db + (size_t)psd * WN, WN * 4u);
 #pragma unroll
-  for (int q = 0; q < 16; q++) {
-    const float mean = acc[q] * args.inv_k;
-    const float d = 1.50514997831990597607f * __builtin_amdgcn_logf(mean);  // 5*log10(mean)
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, q * 16384u, 0);
+    for (int q = 0; q < 16; q++) {
+      const float d = 1.50514997831990597607f * __builtin_amdgcn_logf(acc[q] * args.inv_k);  // 5*log10(mean)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, q * 16384u, 0);
+    }
+  } else {
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.partial + ((size_t)part * args.n_psd + psd) * WN, WN * 4u);
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[q]), rout, st_voff, q * 16384u, 0);
+  }
+}
+
+// ---- kernel C: add the parts (in order: deterministic), mean, dB -------------------------------
+__global__ __launch_bounds__(256) void scn_welch_combine_kernel(ScnWelchArgs args) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const size_t total4 = (size_t)args.n_psd * WN / 4u;
+  for (size_t e = (size_t)blockIdx.x * 256u + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256u) {
+    v4f sum = reinterpret_cast<const v4f *>(args.partial)[e];
+    for (uint32_t part = 1; part < args.parts; part++) sum += reinterpret_cast<const v4f *>(args.partial)[(size_t)part * total4 + e];
+    v4f d;
+#pragma unroll
+    for (int c = 0; c < 4; c++) d[c] = 1.50514997831990597607f * __builtin_amdgcn_logf(sum[c] * args.inv_k);  // 5*log10(mean)
+    reinterpret_cast<v4f *>(args.psd_db)[e] = d;
   }
 }
 
@@ -152,6 +208,9 @@ hipError_t scn_launch_welch(const ScnWelchArgs &a, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(scn_welch_cols_kernel, dim3(16 * G), dim3(256), lds, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(scn_welch_rows_kernel, dim3(16 * a.n_psd), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(scn_welch_rows_kernel, dim3(16 * a.n_psd * a.parts), dim3(256), lds, s, a);
+  e = hipGetLastError();
+  if (e != hipSuccess || a.parts == 1) return e;
+  hipLaunchKernelGGL(scn_welch_combine_kernel, dim3(std::min<uint32_t>(a.n_psd * 64u, 2048u)), dim3(256), 0, s, a);
   return hipGetLastError();
 }

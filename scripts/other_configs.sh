@@ -1,7 +1,7 @@
 #!/bin/bash
 # The other BASELINE configs / wire formats, back to back on one box -> gpurun_out/configs_<tag>.jsonl
 # usage: scripts/other_configs.sh <tag>
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/configs_$TAG.jsonl
 : > $OUT
@@ -15,6 +15,10 @@ run --n 8192 --batch 4096 --kind int16
 run --n 8192 --batch 8192 --kind int16
 run --n 4096 --batch 8192 --kind int16
 run --n 4096 --batch 8192 --kind int8
+run --n 4096 --batch 2048
+run --config c4
+run --n 16384 --batch 2048
+run --n 16384 --batch 2048 --kind int16
 run --welch --welch-psd 32 --steps 100 --warmup 10
 run --welch --welch-psd 8 --welch-pinned --steps 20 --warmup 3
 python3 - <<PY
@@ -23,5 +27,6 @@ for l in open("$OUT"):
     l = l.strip()
     if not l: continue
     d = json.loads(l); r = d.get("roofline") or {}; o = d.get("overlap") or {}
-    print(f'{d["config"]["workload"][:74]:74s} {d["value"]/1e3:7.1f} Gs/s {d["ms_per_step"]*1e3:8.1f} us  frac {r.get("frac")}  overlap {o.get("value", 0)/1e3:7.1f} Gs/s')
+    w = d.get("with_hit_records") or {}
+    print(f'{d["config"]["workload"][:74]:74s} {d["value"]/1e3:7.1f} Gs/s {d["ms_per_step"]*1e3:8.1f} us  frac {r.get("frac")}  overlap {o.get("value", 0)/1e3:7.1f} Gs/s  records {w.get("value", 0)/1e3:7.1f} Gs/s collect {w.get("collect_with_records_us")} us')
 PY

@@ -6,7 +6,7 @@ from scanner_amd import Plan, capi, synth
 dev = torch.device('cuda', 0)
 names = {capi.KIND_FLOAT_COMPLEX: "cfloat", capi.KIND_SHORT_COMPLEX: "int16", capi.KIND_SHORT: "int16 planar", capi.KIND_BYTE_COMPLEX: "int8"}
 print(f"{'n':>5s} {'format':>13s} {'dc':>3s} | spectrum only | spectrum+hits | hits only | time-domain   (us per launch of 33.5 M samples)")
-for n in (1024, 2048, 4096, 8192):
+for n in (1024, 2048, 4096, 8192, 16384):
     nb = 8192 * 4096 // n
     base = [synth.cfloat_batch_torch(n, nb, seed=5 + r, device=dev) for r in range(3)]
     fc = 3e6 + 6e6 * np.arange(nb)

@@ -302,3 +302,29 @@ def test_sample_buffer_through_pinned_staging_slots(host_build, oracle_mod, tmp_
     for f in ("seq_id", "i", "freq_hz"):
         assert np.array_equal(h[f], h_ref[f]), f
     assert np.array_equal(np.concatenate(trig), t_ref)
+
+
+@pytest.mark.gpu
+def test_scan_synth_prints_every_hit_of_a_wideband_burst(host_build, oracle_mod, tmp_path):
+    """A wideband burst makes every buffer it covers report > 1047 hits (process.cpp:62) -- far more than the 64 records
+    per buffer the worker's hit buffer holds.  The reference prints every `freq ... power_db ...` line, so must the
+    batched worker: it walks the rest of the GPU's ordered list with scn_collect_more (no silent truncation)."""
+    from scanner_amd import capi
+
+    _, demo = host_build
+    n, fs, iters = 4096, 8000000, 30
+    dump = tmp_path / "raw.bin"
+    cmd = [demo, "--kind", "short_complex", "--n", str(n), "--start", "100e6", "--stop", "0", "--niterations", str(iters),
+           "--threshold", "2", "--enob", "12", "--sigma", "0.01", "--batch", "4", "--depth", "32", "--burst", "10:14:10",
+           "--dump", str(dump)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "reporting the first" not in out.stderr
+    got = [l for l in out.stdout.splitlines() if l.startswith("freq ")]
+    raw = np.fromfile(dump, np.int16).reshape(-1, 2 * n)[1:]          # generation 0 is the queue's warm-up discard
+    fc = np.full(len(raw), capi.frequency_table(fs, 100e6, 0.0)[1][0])
+    o = oracle_mod.Oracle(n, fs, 2.0, kind=KINDS["short_complex"], enob=12)
+    _, h_ref, t_ref = o.run(raw, fc, np.arange(len(raw), dtype=np.uint64))
+    assert t_ref.sum() == 5 and len(h_ref) > 5 * 1047 > 4 * 64                       # the burst buffers trigger
+    assert len(got) == len(h_ref)
+    assert [l.split()[1] for l in got] == [str(f) for f in h_ref["freq_hz"]]

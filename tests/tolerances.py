@@ -10,6 +10,14 @@ output as 1e-5*|dB| + 1e-4 for every bin at or above the buffer's mean power -- 
 threshold detector can report (a 1e-4 dB step is a 4.6e-5 relative power step; the ~1e-6
 of the buffer's RMS level that two float32 FFTs differ by exceeds that on bins 20 dB down).
 The strict per-bin figure is computed and reported by the tests too.
+
+SAID PLAINLY, because a green suite could be misread otherwise: the 1e-5 of north_star is met in the sense "relative to
+max(bin, buffer mean)".  The dB criterion is only ASSERTED on bins at or above the buffer's mean power; over ALL bins the
+same runs show max dB errors of ~1.3e-3 dB and strict per-bin relative power errors of ~6e-4 (the keys
+max_db_err_all_bins / strict_per_bin_rel_power_max of compare_spectra's result, printed by smoke()): that is the float32
+noise floor on Rayleigh-small bins, present between any two float32 FFTs (the reference's FFTW included), not an
+implementation error -- but it is not "1e-5 per bin" either.  And the oracle these figures are taken against is itself pinned
+by float64 mathematics only, not by the reference's own output (parity unpinned).
 """
 import numpy as np
 

@@ -1,8 +1,9 @@
 """ctypes binding for the CPU oracle (oracle/libscn_oracle.so) + float64 goldens.
 
-TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED for the DSP functions: the reference has no golden
-vectors and its DSP sources cannot be built here (see oracle/scn_oracle.h); the frequency table IS
-pinned against the reference's own frequencyTable.cpp (ref_lib below, oracle/_ref).  Only tests/,
+TEST INFRASTRUCTURE ONLY.  PARITY PARTLY PINNED: the converters (utility.cpp:9-84), the dB map
+(utility.cpp:86-98) and the frequency table are held bit for bit to the reference's own sources compiled into
+oracle/_ref (ref_dsp_lib / ref_lib below); the window, the multiply, the FFT and process_fft are not -- the
+reference has no golden vectors and those sources cannot be built here (see oracle/scn_oracle.h).  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
 the product package scanner_amd never does.
 
@@ -102,6 +103,58 @@ def ref_frequency_walk(sample_rate, start, stop, use_bandwidth, dc_ignore_width,
     ss = np.empty(steps, np.uint8)
     L.ref_frequency_walk(int(sample_rate), start, stop, use_bandwidth, dc_ignore_width, steps, _p(f), _p(it), _p(ss))
     return f, it, ss
+
+
+_REF_DSP_LIB = os.path.join(_HERE, "_ref", "libref_utility.so")
+_ref_dsp = None
+
+
+def ref_dsp_available():
+    return os.path.exists(_REF_DSP_LIB)
+
+
+def ref_dsp_lib():
+    """The reference's own utility.cpp -- the three integer->complex-float converters (utility.cpp:9-84) and the dB map
+    (utility.cpp:86-98) -- compiled from /root/reference by `make -C oracle ref` (see ref_dsp_binding.cpp for how its
+    one foreign include is satisfied from this image).  None where it has not been built."""
+    global _ref_dsp
+    if _ref_dsp is None and os.path.exists(_REF_DSP_LIB):
+        L = C.CDLL(_REF_DSP_LIB)
+        u32, vp, i = C.c_uint32, C.c_void_p, C.c_int
+        L.ref_short_planar_to_float.argtypes = [vp, vp, vp, u32, u32, i]
+        L.ref_short_complex_to_float.argtypes = [vp, vp, u32, u32, i]
+        L.ref_byte_complex_to_float.argtypes = [vp, vp, u32, u32, i]
+        L.ref_complex_to_magnitude.argtypes = [vp, vp, u32]
+        _ref_dsp = L
+    return _ref_dsp
+
+
+def ref_convert(kind, raw, n, enob, correct_dc):
+    """One buffer through the REFERENCE's converter for `kind` (same argument shapes as Oracle.convert)."""
+    L = ref_dsp_lib()
+    assert L is not None, "oracle/_ref/libref_utility.so has not been built (needs /root/reference)"
+    raw = np.ascontiguousarray(raw).copy()  # (the reference takes non-const pointers)
+    out = np.empty(n, np.complex64)
+    if kind == KIND_SHORT_COMPLEX:
+        L.ref_short_complex_to_float(_p(raw), _p(out), n, enob, int(correct_dc))
+    elif kind == KIND_SHORT:
+        flat = raw.reshape(-1)
+        L.ref_short_planar_to_float(_p(flat), C.c_void_p(flat.ctypes.data + 2 * n), _p(out), n, enob, int(correct_dc))
+    elif kind == KIND_BYTE_COMPLEX:
+        L.ref_byte_complex_to_float(_p(raw), _p(out), n, enob, int(correct_dc))
+    else:
+        raise ValueError(kind)
+    return out
+
+
+def ref_magnitude(X):
+    """utility.cpp:86-98 as the reference's own object code computes it."""
+    L = ref_dsp_lib()
+    assert L is not None
+    X = np.ascontiguousarray(X, np.complex64).copy()
+    out = np.empty(X.size, np.float32)
+    L.ref_complex_to_magnitude(_p(X), _p(out), X.size)
+    return out
 
 
 _lib = None

@@ -2,8 +2,9 @@
  * scn_oracle.c -- CPU restatement of wpats/scanner's per-buffer DSP hot path
  * (convert -> window -> FFT -> log magnitude -> fftshift-indexed threshold).
  *
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see scn_oracle.h for why and
- * for what pins it instead.  Each function names the reference lines it
+ * TEST INFRASTRUCTURE ONLY; PARITY PARTLY PINNED -- see scn_oracle.h: the converters, the dB map and the
+ * frequency table are held to the reference's own compiled sources, the window / multiply / FFT / process_fft
+ * (third-party arithmetic, or files that include it) to mathematics only.  Each function names the reference lines it
  * follows (paths relative to /root/reference).  Nothing here is copied: the
  * reference delegates the FFT, the window and the multiply to FFTW / GNU
  * Radio / VOLK, whose published definitions are restated with plain loops.

@@ -6,20 +6,23 @@
  * bench.py's cpu_baseline leg use it, and there only as the checker / the
  * timed CPU baseline.
  *
- * PARITY UNPINNED (see DESIGN.md "Oracle"): the reference holds no test,
- * golden vector or fixture for this path, and it cannot be
- * built in this image -- every hot-path source includes <fftw3.h>
- * (fft.h:3), <volk/volk.h> (process.cpp:8), <gnuradio/fft/window.h>
- * (process.h:5) or <boost/circular_buffer.hpp> (messageQueue.h:6), none of
- * which exist here, and stand-in headers are not allowed.  The oracle is
- * therefore pinned by mathematics instead: float64 DFT / window goldens
- * (numpy/scipy) and hand-derivable known answers under tests/golden/.
- * One function IS pinned against the reference itself: frequencyTable.cpp
- * needs only the standard library, so `make -C oracle ref` compiles it from
- * /root/reference into oracle/_ref/ (ref_binding.cpp) and
- * tests/test_oracle_ref.py holds scn_oracle_frequency_table, the product's
- * scn_frequency_table and the fixture tests/golden/frequency_table_ref.npz
- * (generated from that build) to it.
+ * PARITY PARTLY PINNED (see DESIGN.md "Oracle"): the reference holds no test,
+ * golden vector or fixture for this path, and as a whole it
+ * cannot be built in this image -- process.cpp includes <volk/volk.h> (:8) and
+ * <gnuradio/fft/window.h> (process.h:5), messageQueue.h <boost/circular_buffer.hpp>
+ * (:6), fft.cpp needs a working FFTW; none exist here and stand-in headers are
+ * not allowed.  What DOES compile from /root/reference (`make -C oracle ref`,
+ * into oracle/_ref/) pins the matching functions here, bit for bit:
+ *   frequencyTable.cpp (standard library only; ref_binding.cpp)
+ *       -> scn_oracle_frequency_table            tests/test_oracle_ref.py
+ *   utility.cpp (its one foreign include, <fftw3.h> for the TYPE fftwf_complex,
+ *   is satisfied by this image's hipFFTW header; ref_dsp_binding.cpp)
+ *       -> the three converters (rows a1-a3) and scn_oracle_complex_to_magnitude
+ *          (row a6)                              tests/test_oracle_ref_dsp.py
+ * with the outputs of those builds committed as fixtures under tests/golden/.
+ * The rest -- window, multiply, FFT (third-party arithmetic) and process_fft
+ * (in process.cpp) -- is pinned by mathematics instead: float64 DFT / window
+ * goldens (numpy/scipy) and hand-derivable known answers under tests/golden/.
  *
  * Third-party arithmetic restated here (absent from /root/reference, no
  * version pinned by the reference -- its Makefile:10-11 links -lfftw3f -lvolk

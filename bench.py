@@ -337,8 +337,6 @@ def kernel_name(n, kind, hits=True):
     h = "true" if hits else "false"
     if n == 8192:
         return f"scn_fft8k_kernel<{k}, false, {h}>"
-    if n == 16384:
-        return f"scn_fft16k_kernel<{k}, false, {h}>"
     return f"scn_fft_kernel<{n // 256}, {k}, false, {h}>"
 
 

@@ -235,6 +235,9 @@ hipStream_t list_stream_of(const scn_plan *p, const Slot &s) {
   return (s.own_stream || p->compact_mode == SCN_COMPACT_INLINE) ? s.stream : p->list_stream;
 }
 
+// where work on an already complete list goes (top-up copies, scn_collect_more's windows): a stream with nothing queued
+hipStream_t topup_stream_of(const scn_plan *p, const Slot &s) { return s.own_stream ? s.stream : p->h2d_stream; }
+
 // Scan + compaction of the slot's pending / last submit into d_list, behind everything already queued on the list's
 // stream; with `prefetch`, followed by a DMA of the expected number of records into the pinned h_list (the size of a
 // copy has to be known when it is queued, long before this batch's own total is: the plan predicts it from the last
@@ -260,10 +263,13 @@ int fetch_list(scn_plan *p, Slot &s, uint32_t count) {
   SCN_HIP(hipEventSynchronize(s.list_done[s.gen]));
   count = std::min(count, p->d.max_hits);
   if (count > s.prefetched) {
-    hipStream_t aux = list_stream_of(p, s);
+    // the prediction was short: copy the rest now.  NOT on the list stream: the other slot's list may be queued there
+    // behind a launch that is still running, and this copy would wait for it; the list it reads is complete (the event
+    // above), so any idle stream will do.
+    hipStream_t side = topup_stream_of(p, s);
     SCN_HIP(hipMemcpyAsync(s.h_list + s.prefetched, s.d_list + s.prefetched, sizeof(scn_hit) * (size_t)(count - s.prefetched),
-                           hipMemcpyDeviceToHost, aux));
-    SCN_HIP(hipStreamSynchronize(aux));
+                           hipMemcpyDeviceToHost, side));
+    SCN_HIP(hipStreamSynchronize(side));
     s.prefetched = count;
   }
   return SCN_OK;
@@ -680,10 +686,10 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
       total += c;
       if (trigger) trigger[b] = c > p->d.trigger_count;  // process.cpp:62
     }
-    s.list_valid = true;
   } else if (trigger) {
     memset(trigger, 0, nb);
   }
+  s.list_valid = have_hits;
   if (total > 0x7fffffffu) return fail(SCN_E_INVALID, "%llu hits in one submit: split the batch", (unsigned long long)total);
   s.total_hits = (uint32_t)total;
   if (have_hits) {  // what the automatic mode goes by at the next submit
@@ -734,10 +740,10 @@ int scn_collect_more(scn_plan *p, int slot, uint32_t first, scn_hit *hits, uint3
     SCN_HIP(hipMalloc(&s.d_window, sizeof(scn_hit) * (size_t)want));
     s.d_window_cap = want;
   }
-  hipStream_t aux = list_stream_of(p, s);
-  SCN_HIP(scn_launch_hit_compact(compact_args(p, s, first, want, s.d_window), aux));
-  SCN_HIP(hipMemcpyAsync(hits, s.d_window, sizeof(scn_hit) * want, hipMemcpyDeviceToHost, aux));
-  SCN_HIP(hipStreamSynchronize(aux));
+  hipStream_t side = topup_stream_of(p, s);  // (fetch_list above waited for the scan: the offsets are there)
+  SCN_HIP(scn_launch_hit_compact(compact_args(p, s, first, want, s.d_window), side));
+  SCN_HIP(hipMemcpyAsync(hits, s.d_window, sizeof(scn_hit) * want, hipMemcpyDeviceToHost, side));
+  SCN_HIP(hipStreamSynchronize(side));
   *n_written = want;
   return SCN_OK;
 }
@@ -750,7 +756,7 @@ int scn_hits_view(scn_plan *p, int slot, const scn_hit **hits, uint32_t *n) {
   if (s.pending || !s.list_valid) return fail(SCN_E_STATE, "slot %d: no collected submit whose hit list is still available", slot);
   SCN_HIP(hipSetDevice(p->d.device_id));
   *n = std::min(s.total_hits, p->d.max_hits);
-  if ((st = fetch_list(p, s, *n))) return st;
+  if (*n && (st = fetch_list(p, s, *n))) return st;
   *hits = s.h_list;
   return SCN_OK;
 }

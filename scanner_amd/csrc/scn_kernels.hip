@@ -148,7 +148,8 @@ struct RawLoader<SCN_K_SHORT> {
 }  // namespace
 
 // ------------------------------------------------------------------------------------
-// Fused kernel for N = 256*M points, M in {4, 8, 16, 32} (N = 1024 / 2048 / 4096 / 8192).
+// Fused kernel for N = 256*M points, M in {4, 8, 16, 32, 64} (N = 1024 / 2048 / 4096 / 8192 / 16384; the product uses the
+// wide kernel further down for 8192).
 // One workgroup of T = 16*M threads per buffer, persistent over buffers, 16 points per thread.
 //
 //   n = T*a + M*b + c          k = p + 16q + 256r         a,b,p,q in [0,16), c,r in [0,M)
@@ -159,6 +160,10 @@ struct RawLoader<SCN_K_SHORT> {
 //       M == 32: two lanes (l, l+32) share a butterfly: each does the 16-pt DFT over c = 2c'+e
 //                of its parity e, the odd one applies W_32^{r'}, one cross-half exchange
 //                (radix 2) finishes it; lane half e outputs r = r' + 16e
+//       M == 64: FOUR lanes (l, l+16, l+32, l+48) share a butterfly: lane row e does the 16-pt DFT over
+//                c = 4c'+e, applies W_64^{e r'}, and a radix-4 step made of two lane exchanges
+//                (v_permlane32_swap across the halves, v_permlane16_swap across the rows of a half)
+//                leaves output r = r' + 16 s in the lane with s = 2 (e & 1) + (e >> 1)
 //
 // LDS (complex = 8 B slots, every address = per-thread base + immediate, all four access patterns
 // bank-conflict-free -- checked with SQ_LDS_BANK_CONFLICT and the bank model of the guide):
@@ -238,7 +243,7 @@ struct Geo {
   static constexpr uint32_t P1 = T + (M < 32 ? M : 0);
   static constexpr uint32_t P2 = 256u + (M <= 16 ? 16u / M : 1u);
   static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots
-  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 2u * 4u + 64u * 4u + 8u;
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 2u * 4u + 64u * 4u + 8u + (M == 64 ? 64u * 8u : 0u);
   static constexpr uint32_t WAVES = T >= 64 ? T / 64 : 1;
   // Register prefetch costs a wave per SIMD (4 -> 3).  At 8192 points a workgroup is 8 waves, so
   // 3 waves per SIMD would leave ONE workgroup per CU: no prefetch there, two workgroups instead.
@@ -265,9 +270,10 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
   v2f *lds_tw2 = lds + G::EXCH;                              // [16][M]
-  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T);      // [16] DC-sum scratch (re[8], im[8])
-  int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
+  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T);      // [32] DC-sum scratch (re[16], im[16]: up to 16 waves)
+  int *lds_hits = lds_cnt + 32;                             // [2] hit counters, alternating per buffer
   uint32_t *lds_next = reinterpret_cast<uint32_t *>(lds_hits + 2);  // [1] the buffer this workgroup takes after the next one
+  v2f *lds_w64 = reinterpret_cast<v2f *>(smem_raw + G::LDS_BYTES - 64u * 8u);  // M == 64 only: W_64^m, m < 64
 
 #if SCN_STAMPS
   const uint32_t stamp_entry = (uint32_t)wall_clock64();  // first instruction of the workgroup
@@ -275,8 +281,11 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   const uint32_t t = threadIdx.x;
   const uint32_t p2 = t / M, c2 = t % M;  // pass-2 identity (p, c); also the (q, c) of the table entry below
   const uint32_t lane = t & 63, wave = t >> 6;
-  // pass-3 identity for M == 32: parity e = lane half, butterfly kl
-  const uint32_t e = (t >> 5) & 1u, kl32 = (t & 31u) + 32u * (t >> 6);
+  // pass-3 identity for M == 32: parity e = lane half, butterfly kl;  for M == 64: e = lane row (16 lanes), 16 butterflies per wave
+  const uint32_t e = (M == 64) ? (t >> 4) & 3u : (t >> 5) & 1u;
+  const uint32_t kl32 = (M == 64) ? (t & 15u) + 16u * (t >> 6) : (t & 31u) + 32u * (t >> 6);
+  // the output block this lane ends up holding: r = r' + 16 s
+  const uint32_t s_out = (M == 64) ? 2u * (e & 1u) + (e >> 1) : e;
 
   // the first buffer's samples go out before anything else: their latency then overlaps the
   // ~31 table loads below instead of following them
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t] * args.scale;
   // pass-2 twiddles W_{16M}^(c*q) = W_N^(16 c q), table [q][c] shared by the workgroup
   lds_tw2[t] = args.twiddle[(16 * p2 * c2) & (N - 1)];
+  if (M == 64 && t < 64) lds_w64[t] = args.twiddle[t * (N / 64u)];
   SCN_WORK_QUEUE_SETUP();
   if (t == 0) {
     lds_hits[0] = lds_hits[1] = 0;
@@ -309,18 +319,18 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   v2f *w1 = lds + t;                      // + p*P1
   v2f *r1 = lds + p2 * P1 + c2;           // + b*M
   v2f *w2 = lds + c2 * P2 + p2;           // + 16*q
-  v2f *r3 = (M == 32) ? lds + e * P2 + kl32 : lds + t;  // + 2c'*P2   |   + c*P2 + T*u
+  v2f *r3 = (M >= 32) ? lds + e * P2 + kl32 : lds + t;  // + 2c'*P2 (M = 32), + 4c'*P2 (M = 64)   |   + c*P2 + T*u
   const v2f *tw2 = lds_tw2 + c2;          // + q*M
   // global store offset of output o: voffset (per lane) + scalar part
-  const uint32_t st_voff = (M == 32) ? (kl32 + 4096u * e) * 4u : t * 4u;
+  const uint32_t st_voff = (M >= 32) ? (kl32 + 4096u * s_out) * 4u : t * 4u;
 
   // K5 mask of this thread's 16 output bins (process.cpp:46-52): depends on (t, o) only
-  const uint32_t jbase = (M == 32) ? kl32 + 4096u * e : t;
+  const uint32_t jbase = (M >= 32) ? kl32 + 4096u * s_out : t;
   uint32_t keepmask = 0;
   if (HITS) {
 #pragma unroll
     for (int o = 0; o < 16; o++) {
-      const uint32_t joff = (M == 32) ? 256u * o : T * (o / M) + 256u * (o % M);
+      const uint32_t joff = (M >= 32) ? 256u * o : T * (o / M) + 256u * (o % M);
       const uint32_t j = jbase + joff;
       const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
       const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running (none yet)
 
   // output o of this thread is bin j = jbase + joff(o):  M <= 16: o = u*M + r, j = t + T*u + 256*r;  M == 32: o = r', j = kl + 4096*e + 256*r'
-  auto joff_of = [](int o) -> uint32_t { return (M == 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M); };
+  auto joff_of = [](int o) -> uint32_t { return (M >= 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M); };
 #if SCN_STAMPS
   uint32_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t stamp_prev = (uint32_t)__builtin_readcyclecounter();
@@ -367,14 +377,14 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       si = wave_sum(si);
       if (lane == 0) {
         lds_cnt[wave] = sr;
-        lds_cnt[8 + wave] = si;
+        lds_cnt[16 + wave] = si;
       }
       __syncthreads();
       sr = si = 0;
 #pragma unroll
       for (uint32_t w = 0; w < G::WAVES; w++) {
         sr += lds_cnt[w];
-        si += lds_cnt[8 + w];
+        si += lds_cnt[16 + w];
       }
       dc_re = (int)((uint32_t)sr / N);
       dc_im = (int)((uint32_t)si / N);
@@ -451,7 +461,34 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     if (PF) prefetch(pf_cut[3], pf_cut[4]);
 
     // ---- pass 3: M-point DFT over c ----
-    if constexpr (M == 32) {
+    if constexpr (M == 64) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[4 * c * P2]);
+      fft16(v);
+      // radix 4 across the four rows of the wave: T_e = W_64^(e r') Y_e[r'], then
+      //   halves:  A_e0 = T_e0 + T_(e0+2) (rows 0, 1)     B_e0 = T_e0 - T_(e0+2) (rows 2, 3)
+      //   rows:    X_0 = A_0 + A_1, X_2 = A_0 - A_1 (rows 0, 1)     X_1 = B_0 - i B_1, X_3 = B_0 + i B_1 (rows 2, 3)
+      // Both exchanges use the swap instructions on two copies of the value, which leaves the pair's two values in both
+      // lanes (see M == 32 below); the signs are per-lane constants, so every lane runs the same instructions.
+      const bool upper = (e & 2u) != 0, odd = (e & 1u) != 0;
+      const float sgn_h = upper ? -1.0f : 1.0f, sgn_r = odd ? -1.0f : 1.0f;
+      const v2f *wtab = lds_w64;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        cf y = v[OUT16(r)];
+        if (r) y = cmul(y, from_v2f(wtab[(e * (uint32_t)r) & 63u]));  // W_64^(e r); row 0 multiplies by 1
+        auto hx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.x), false, false);
+        auto hy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y.y), __builtin_bit_cast(unsigned, y.y), false, false);
+        const cf ab = cf{__builtin_fmaf(__builtin_bit_cast(float, (unsigned)hx[1]), sgn_h, __builtin_bit_cast(float, (unsigned)hx[0])),
+                         __builtin_fmaf(__builtin_bit_cast(float, (unsigned)hy[1]), sgn_h, __builtin_bit_cast(float, (unsigned)hy[0]))};
+        auto rx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ab.x), __builtin_bit_cast(unsigned, ab.x), false, false);
+        auto ry = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ab.y), __builtin_bit_cast(unsigned, ab.y), false, false);
+        const cf s0 = cf{__builtin_bit_cast(float, (unsigned)rx[0]), __builtin_bit_cast(float, (unsigned)ry[0])};  // even row of the pair
+        const cf s1 = cf{__builtin_bit_cast(float, (unsigned)rx[1]), __builtin_bit_cast(float, (unsigned)ry[1])};  // odd row
+        const cf tt = upper ? cf{s1.y, -s1.x} : s1;  // -i B_1 in the upper half, A_1 in the lower
+        v[OUT16(r)] = cf{__builtin_fmaf(tt.x, sgn_r, s0.x), __builtin_fmaf(tt.y, sgn_r, s0.y)};
+      }
+    } else if constexpr (M == 32) {
 #pragma unroll
       for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[2 * c * P2]);
       fft16(v);
@@ -537,7 +574,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
             const unsigned long long m = __ballot(hit);
             if (hit) {
               const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-              const uint32_t joff = (M == 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M);
+              const uint32_t joff = (M >= 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M);
               if (pos < args.hit_region) region[pos] = ScnDevHit{(jbase + joff) ^ (N / 2), db[o]};
             }
             base += (uint32_t)__popcll(m);
@@ -589,6 +626,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #ifndef SCN_WIDE_8192
 #define SCN_WIDE_8192 1
 #endif
+// (16384 points run as scn_fft_kernel<64>: 1024 threads x 16 points, four waves per SIMD, lane-quad radix-4 in pass 3.
+// The first form -- 256 threads x 64 points, one wave per SIMD, modelled on the wide kernel below -- was 1.5-1.8x slower:
+// 195 / 191 Gsamples/s against 296 / 344 for cfloat / int16 at batch 2048.)
 namespace {
 struct Geo8k {
   static constexpr uint32_t N = 8192, T = 256, P1 = 512, P2 = 257;
@@ -825,243 +865,6 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
     }
     buf = nxt;
     nxt = after;
-  }
-  if (HITS) {
-    __syncthreads();  // last buffer's recorders done
-    if (t == 0 && prev != 0xffffffffu) {
-      args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
-      if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// 16384 points: ONE workgroup of 256 threads per buffer, 64 points per thread, one workgroup per CU.
-//
-// The reference builds an FFTW plan for whatever --count it is given (fft.cpp:4-11, scan.cpp:85); 16384 is the largest
-// size whose buffer still fits the CU's LDS (128 KiB of complex floats + tables = 137 KiB of 160).  Same
-// decomposition as the other sizes (n = 1024a + 64b + c, k = p + 16q + 256r, passes 16 x 16 x 64): a thread plays
-// FOUR of the 1024 "virtual threads" of passes 1 and 2 (tau = t + 256h) and owns one whole 64-point DFT in pass 3
-// (four in-register 16-point DFTs over c = 4c' + e, the W_64^(e r') twiddles, one radix-4 step).  One wave per SIMD
-// means nothing hides a wave's latencies but its own instruction stream, so the kernel leans on the 512-register
-// budget instead: window taps stay resident, the next buffer's raw samples are prefetched for the integer formats
-// (64 registers; a float buffer would need 128 and is loaded at the top of the loop), and the pass-1 twiddles come
-// from their L2-resident table every buffer (120 registers otherwise).  LDS layouts: P1 = 1024, P2 = 257 -- the
-// same per-instruction bank behaviour as Geo8k (64 lanes = 64 consecutive c in exchange 1, consecutive kl in
-// exchange 2).
-// ------------------------------------------------------------------------------------
-namespace {
-struct Geo16k {
-  static constexpr uint32_t N = 16384, T = 256, M = 64, P1 = 1024, P2 = 257;
-  static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots
-  static constexpr uint32_t LDS_BYTES = EXCH * 8u + 1024u * 8u + 16u * 4u + 2u * 4u + 8u;
-  static constexpr uint32_t WG_PER_CU = 1;
-};
-}  // namespace
-
-template <int KIND, bool DC, bool HITS>
-__global__ __launch_bounds__(256, 1) void scn_fft16k_kernel(ScnFftArgs args) {
-  typedef Geo16k G;
-  constexpr int AUX_LD = SCN_AUX_LD;
-  constexpr int AUX_ST = SCN_AUX_ST;
-  constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
-  constexpr bool PF = KIND != SCN_K_FLOAT_COMPLEX;  // register prefetch of the next buffer
-  typedef RawLoader<KIND> L;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-  v2f *lds_tw2 = lds + G::EXCH;                              // [16][64]: W_1024^(c q) at q*64 + c
-  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + 1024);   // [16] DC-sum scratch (re[8], im[8])
-  int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
-
-  const uint32_t t = threadIdx.x;
-  const uint32_t lane = t & 63, wave = t >> 6;
-  const uint32_t c2 = t & 63u, p2 = t >> 6;  // pass-2 identity of virtual thread t + 256h: (p2 + 4h, c2)
-
-  typename L::raw_t raw[64];
-  auto load_buffer = [&](uint32_t b, bool valid) {
-    const __amdgpu_buffer_rsrc_t r =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)b * L::kBufBytes(N), (valid && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
-#pragma unroll
-    for (int a = 0; a < 64; a++) raw[a] = L::template load<AUX_LD>(r, N, t, T * a);  // x[256 a' + t], a' = 4a + h
-  };
-  if (PF) load_buffer(blockIdx.x, blockIdx.x < args.n_buffers);
-  float win[64];
-#pragma unroll
-  for (int a = 0; a < 64; a++) win[a] = args.window[T * a + t] * args.scale;
-  // pass-2 twiddles W_1024^(c q) = W_N^(16 c q), entry q*64 + c: this thread fills entries t + 256h
-#pragma unroll
-  for (uint32_t h = 0; h < 4; h++) lds_tw2[t + 256u * h] = args.twiddle[(16u * (p2 + 4u * h) * c2) & (N - 1)];
-  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
-  __syncthreads();
-
-  v2f *w1 = lds + t;                       // + p*P1 + 256h
-  v2f *r1 = lds + p2 * P1 + c2;            // + b*64 + 4h*P1
-  v2f *w2 = lds + c2 * P2 + p2;            // + 16*q + 4h
-  v2f *r3 = lds + t;                       // + c*P2
-  const v2f *tw2 = lds_tw2 + c2;           // + q*64
-  const v2f *tw1 = args.tw1_table + t;     // + (p-1)*1024 + 256h
-  const uint32_t st_voff = t * 4u;         // output r of this thread is bin j = t + 256 r
-
-  uint64_t keepmask = 0;  // K5 mask of this thread's 64 bins (process.cpp:46-52)
-  if (HITS) {
-#pragma unroll
-    for (int r = 0; r < 64; r++) {
-      const uint32_t j = t + 256u * r;
-      const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
-      const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
-      keepmask |= keep ? (1ull << r) : 0ull;
-    }
-  }
-  uint32_t par = 0;
-  uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running
-
-  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
-    const uint32_t nxt = buf + gridDim.x;
-    const bool more = nxt < args.n_buffers;
-    if (!PF) load_buffer(buf, true);
-    // ---- K1 + K2 ----
-    int dc_re = 0, dc_im = 0;
-    if (DC) {
-      int sr = 0, si = 0;
-#pragma unroll
-      for (int a = 0; a < 64; a++) {
-        int re, im;
-        L::ints(raw[a], re, im);
-        sr += re;
-        si += im;
-      }
-      sr = wave_sum(sr);
-      si = wave_sum(si);
-      if (lane == 0) {
-        lds_cnt[wave] = sr;
-        lds_cnt[8 + wave] = si;
-      }
-      __syncthreads();
-      sr = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
-      si = lds_cnt[8] + lds_cnt[9] + lds_cnt[10] + lds_cnt[11];
-      dc_re = (int)((uint32_t)sr / N);  // int32 /= uint32, utility.cpp:77-78
-      dc_im = (int)((uint32_t)si / N);
-    }
-    // ---- pass 1: the four virtual threads t + 256h, one after the other (16 values live at a time) ----
-    cf v[4][16];
-#pragma unroll
-    for (int h = 0; h < 4; h++) {
-#pragma unroll
-      for (int a = 0; a < 16; a++) v[0][a] = L::conv(raw[4 * a + h], dc_re, dc_im, 1.0f) * win[4 * a + h];
-      fft16(v[0]);
-#pragma unroll
-      for (int p = 0; p < 16; p++) {
-        cf y = v[0][OUT16(p)];
-        if (p) y = cmul(y, from_v2f(tw1[(p - 1) * 1024 + 256 * h]));
-        w1[p * P1 + 256 * h] = to_v2f(y);
-      }
-    }
-    // the raw registers are free: next buffer of this workgroup, branch-free (zero records past the end)
-    if (PF) load_buffer(more ? nxt : buf, more);
-    __syncthreads();
-    if (HITS) {
-      if (t == 0 && prev != 0xffffffffu) {  // every wave is past the barrier: the previous buffer's recorders are done
-        args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
-        if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
-        lds_hits[par ^ 1] = 0;
-      }
-    }
-
-    // ---- pass 2: virtual threads (p2 + 4h, c2): all four read before anything is written back ----
-#pragma unroll
-    for (int h = 0; h < 4; h++) {
-#pragma unroll
-      for (int b = 0; b < 16; b++) v[h][b] = from_v2f(r1[b * 64 + 4 * h * P1]);
-    }
-#pragma unroll
-    for (int h = 0; h < 4; h++) fft16(v[h]);
-#pragma unroll
-    for (int q = 1; q < 16; q++) {
-      const cf w = from_v2f(tw2[q * 64]);
-#pragma unroll
-      for (int h = 0; h < 4; h++) v[h][OUT16(q)] = cmul(v[h][OUT16(q)], w);
-    }
-    __syncthreads();  // every exchange-1 read done before the area is re-used
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-#pragma unroll
-      for (int h = 0; h < 4; h++) w2[q * 16 + 4 * h] = to_v2f(v[h][OUT16(q)]);
-    }
-    __syncthreads();
-
-    // ---- pass 3: one 64-point DFT over c = 4c' + e per thread (kl = t) ----
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-#pragma unroll
-      for (int c = 0; c < 16; c++) v[e][c] = from_v2f(r3[(4 * c + e) * P2]);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) fft16(v[e]);
-
-    // ---- K4 + K5: X[r' + 16 s] = sum_e W_4^(e s) W_64^(e r') Y_e[r'] ----
-    v32f db_lo, db_hi;  // dB of r = 0..31 and 32..63 (true vectors: the recording path indexes them wave-uniformly)
-    float dmax = -3.40282347e+38f;
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      cf y0 = v[0][OUT16(r)], y1 = v[1][OUT16(r)], y2 = v[2][OUT16(r)], y3 = v[3][OUT16(r)];
-      if (r) {
-        const double ang = 6.283185307179586476925286766559 * r / 64.0;
-        y1 = cmul(y1, cf{(float)__builtin_cos(ang), -(float)__builtin_sin(ang)});
-        y2 = cmul(y2, cf{(float)__builtin_cos(2.0 * ang), -(float)__builtin_sin(2.0 * ang)});
-        y3 = cmul(y3, cf{(float)__builtin_cos(3.0 * ang), -(float)__builtin_sin(3.0 * ang)});
-      }
-      radix4(y0, y1, y2, y3);  // -> X[r], X[r+16], X[r+32], X[r+48]
-      const float d0 = power_db(y0), d1 = power_db(y1), d2 = power_db(y2), d3 = power_db(y3);
-      db_lo[r] = d0;
-      db_lo[r + 16] = d1;
-      db_hi[r] = d2;
-      db_hi[r + 16] = d3;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d0), rout, st_voff, 1024u * r, AUX_ST);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), rout, st_voff, 1024u * (r + 16), AUX_ST);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d2), rout, st_voff, 1024u * (r + 32), AUX_ST);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d3), rout, st_voff, 1024u * (r + 48), AUX_ST);
-      if (HITS) dmax = fmaxf(fmaxf(dmax, fmaxf(d0, d1)), fmaxf(d2, d3));
-    }
-    __syncthreads();  // exchange area free again
-    if (HITS) {
-      if (__ballot(dmax > args.threshold)) {
-        uint32_t hit_lo = 0, hit_hi = 0;
-#pragma unroll
-        for (int r = 0; r < 32; r++) {
-          hit_lo |= (db_lo[r] > args.threshold) ? (1u << r) : 0u;  // strict >, process.cpp:54
-          hit_hi |= (db_hi[r] > args.threshold) ? (1u << r) : 0u;
-        }
-        hit_lo &= (uint32_t)keepmask;
-        hit_hi &= (uint32_t)(keepmask >> 32);
-        const uint32_t total = wave_add_u32((uint32_t)__popc(hit_lo) + (uint32_t)__popc(hit_hi));
-        if (total) {
-          uint32_t base = 0;
-          if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
-          base = __builtin_amdgcn_readfirstlane(base);
-          ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-#pragma unroll
-          for (int half = 0; half < 2; half++) {
-            const uint32_t mine = half ? hit_hi : hit_lo;
-            uint32_t wm = wave_or_u32(mine);
-            while (wm) {
-              const int r = __builtin_ctz(wm);  // wave-uniform
-              wm &= wm - 1u;
-              const bool hit = (mine >> r) & 1u;
-              const unsigned long long m = __ballot(hit);
-              if (hit) {
-                const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                const uint32_t j = t + 256u * (uint32_t)(r + 32 * half);
-                if (pos < args.hit_region) region[pos] = ScnDevHit{j ^ (N / 2), half ? db_hi[r] : db_lo[r]};
-              }
-              base += (uint32_t)__popcll(m);
-            }
-          }
-        }
-      }
-      prev = buf;
-      par ^= 1;
-    }
   }
   if (HITS) {
     __syncthreads();  // last buffer's recorders done
@@ -1374,31 +1177,6 @@ static hipError_t launch_8k(int kind, bool dc, bool hits, const ScnFftArgs &args
   }
 }
 
-template <int KIND>
-static hipError_t launch_16k_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
-  typedef Geo16k G;
-  void (*k)(ScnFftArgs) = nullptr;
-  if (dc && hits) k = scn_fft16k_kernel<KIND, true, true>;
-  else if (dc) k = scn_fft16k_kernel<KIND, true, false>;
-  else if (hits) k = scn_fft16k_kernel<KIND, false, true>;
-  else k = scn_fft16k_kernel<KIND, false, false>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  int grid = num_cus * (int)G::WG_PER_CU;
-  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), G::LDS_BYTES, s, a);
-  return hipGetLastError();
-}
-static hipError_t launch_16k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream) {
-  switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_16k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream);
-    case SCN_K_SHORT_COMPLEX: return launch_16k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream);
-    case SCN_K_SHORT: return launch_16k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream);
-    case SCN_K_BYTE_COMPLEX: return launch_16k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream);
-    default: return hipErrorInvalidValue;
-  }
-}
-
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus,
                           hipStream_t stream) {
   if (args.n_buffers == 0) return hipSuccess;
@@ -1411,7 +1189,7 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFft
 #else
     case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream);  // the 512-thread form (variant build)
 #endif
-    case 16384: return launch_16k(kind, dc, hits, args, num_cus, stream);
+    case 16384: return launch_size<64>(kind, dc, hits, args, num_cus, stream);
     default: return hipErrorInvalidValue;
   }
 }

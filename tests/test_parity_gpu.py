@@ -434,6 +434,43 @@ def test_hit_capacity_truncation(torch_cuda, oracle_mod):
         assert plan.last_n_hits == 0 and len(h) == 0 and len(plan.hits_view(0)) == 0
 
 
+def test_hit_list_eager_prefetch_and_top_up(torch_cuda, oracle_mod):
+    """A caller that asks for records gets the list built beside the next launch and a DMA of the PREDICTED number of
+    records (last total + 25 %); when a batch holds many more than predicted the rest is copied at collect time, and a
+    counts-only collect in between switches the eager build off again.  Every list must equal the oracle's whatever path
+    it took: quiet, loud (top-up), quiet (over-prediction), counts-only, then records again (built on demand)."""
+    n, nb = 4096, 48
+    quiet = synth.cfloat_batch(n, nb, seed=31, sigma=0.02, max_tones=1)
+    loud = synth.cfloat_batch(n, nb, seed=32, sigma=0.3, max_tones=4)
+    fc = 400e6 + 6e6 * np.arange(nb)
+    o = oracle_mod.Oracle(n, FS, 9.0)
+    refs = {id(quiet): o.run(quiet, fc)[1], id(loud): o.run(loud, fc)[1]}
+    assert len(refs[id(loud)]) > 4 * len(refs[id(quiet)]) > 0
+    dq, dl = _to_dev(torch_cuda, quiet), _to_dev(torch_cuda, loud)
+    with Plan(n, FS, 9.0, max_batch=nb, max_hits=nb * n, flags=capi.OUT_HITS) as plan:
+        seq = [(quiet, dq, True), (quiet, dq, True), (loud, dl, True), (loud, dl, True), (quiet, dq, True), (quiet, dq, False),
+               (loud, dl, False), (loud, dl, True), (quiet, dq, True)]
+        pend = []
+        for k, (x, d, want) in enumerate(seq):
+            if len(pend) == 2:
+                k0, x0, want0 = pend.pop(0)
+                _, h, t = plan.collect(k0 & 1, want_power=False, want_hits=want0)
+                if want0:
+                    _assert_hits_equal(h, refs[id(x0)])
+                else:
+                    assert plan.last_n_hits == len(refs[id(x0)])
+            plan.submit_device(k & 1, d, nb, fc)
+            pend.append((k, x, want))
+        for k0, x0, want0 in pend:
+            _, h, t = plan.collect(k0 & 1, want_power=False, want_hits=want0)
+            if want0:
+                _assert_hits_equal(h, refs[id(x0)])
+        # an empty submit is a valid sweep result: no hits, an empty view
+        plan.submit_device(0, dq, 0, [])
+        _, h, t = plan.collect(0, want_power=False)
+        assert len(h) == 0 and len(t) == 0 and len(plan.hits_view(0)) == 0
+
+
 def test_negative_frequency_cast_follows_x86(torch_cuda, oracle_mod):
     """A sweep that starts at 0 Hz has start_frequency = 3 MHz - 4 MHz < 0 for its first centre; process.cpp:57 casts the
     (negative) double of the lowest evaluated bins to uint64, which on the reference's x86-64 build wraps -- the

@@ -128,6 +128,7 @@ struct scn_plan {
   // kernel stores each count to pinned host memory as well (one 4-byte PCIe write per buffer; costs a 4096-point launch
   // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
   bool direct_counts = false;
+  int stop_event_in_packet = -1;  // -1: by launch size (see submit_common); 0 / 1: experiment knob SCN_EXP_STOP_EVENT
   int fft_cus = 0;  // CUs the FFT launch is sized for (num_cus unless SCN_EXP_RESERVE_CUS leaves some to the side stream)
   hipStream_t stream = nullptr;      // compute
   hipStream_t h2d_stream = nullptr;  // staging copies of scn_submit (overlap the other slot's kernel)
@@ -336,31 +337,40 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.host_hits = (hits && p->direct_counts) ? s.h_buf_hits : nullptr;
   a.work_counter = s.d_work_counter;
   for (uint32_t x = 0; x < 8; x++) a.work_base[x] = s.work_base[x];
-  SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->fft_cus, s.stream));
+  // What follows the kernel: the counts (a DMA on the d2h stream: needs no CU -- or nothing, when the kernel stores them to
+  // pinned memory itself) and, when the caller is known to want records, the ordered list (two small kernels + a DMA on
+  // the list stream, beside the next launch).  With overlapped slots both follow the kernel on the slot's own stream --
+  // its next kernel is two submits away, and fewer streams keep both compute streams on hardware queues of their own
+  // (HIP maps streams onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one).
+  const bool eager = hits && nb && (p->compact_mode == SCN_COMPACT_INLINE || p->compact_mode == SCN_COMPACT_SIDE ||
+                                    (p->compact_mode == SCN_COMPACT_AUTO && p->records_wanted));
+  hipStream_t cnt = (s.own_stream || p->direct_counts) ? s.stream : p->d2h_stream;
+  hipStream_t lst = list_stream_of(p, s);
+  const bool fork_list = eager && lst != s.stream;
+  // ONE event marks the kernel's end for whoever waits for it: the host (`done`, when nothing else follows on the compute
+  // stream: counts stored by the kernel) or the side streams (`kernel_done`).  For LARGE launches it is completed by the
+  // kernel's own dispatch packet (hipExtLaunchKernel's stopEvent), otherwise by a marker packet behind the kernel.
+  // Measured (scripts/stop_event_check.sh, profiles/r02_stop_event.txt), us per step marker -> in-packet: 33.5 M-sample
+  // launches 75.6 -> 73.1 (4096-pt cfloat), 77 -> 74.5 (2048-pt), 60.2 -> 59.3 (int16); 67 M samples 144.5 -> 140.8; but
+  // 16.8 M samples 44 -> 46..58 and 8.4 M 31 -> 29..56 (erratic: short kernels that carry an event get serialised).
+  const bool after_is_done = cnt == s.stream && !s.own_stream;  // direct counts on the plan's stream
+  hipEvent_t after = (!nb || s.own_stream) ? nullptr : !hits ? s.done : after_is_done ? s.done : s.kernel_done;
+  const bool in_packet = after && (p->stop_event_in_packet < 0 ? (uint64_t)nb * n >= (1u << 25) : p->stop_event_in_packet != 0);
+  SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->fft_cus, s.stream, in_packet ? after : nullptr));
   if (scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
   if (hits && nb) {
-    // two independent branches behind the kernel: the counts (a DMA on the d2h stream: needs no CU) and, when the
-    // caller is known to want records, the ordered list (two small kernels + a DMA on the list stream, beside the next
-    // launch).  With overlapped slots both follow the kernel on the slot's own stream -- its next kernel is two
-    // submits away, and fewer streams keep both compute streams on hardware queues of their own (HIP maps streams
-    // onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one).
-    const bool eager = p->compact_mode == SCN_COMPACT_INLINE || p->compact_mode == SCN_COMPACT_SIDE ||
-                       (p->compact_mode == SCN_COMPACT_AUTO && p->records_wanted);
-    hipStream_t cnt = (s.own_stream || p->direct_counts) ? s.stream : p->d2h_stream;
-    hipStream_t lst = list_stream_of(p, s);
-    const bool fork_list = eager && lst != s.stream;
-    if (cnt != s.stream || fork_list) SCN_HIP(hipEventRecord(s.kernel_done, s.stream));
-    if (cnt != s.stream) SCN_HIP(hipStreamWaitEvent(cnt, s.kernel_done, 0));
-    if (fork_list) SCN_HIP(hipStreamWaitEvent(lst, s.kernel_done, 0));
+    if (after && !in_packet) SCN_HIP(hipEventRecord(after, s.stream));
+    if (cnt != s.stream) SCN_HIP(hipStreamWaitEvent(cnt, after, 0));
+    if (fork_list) SCN_HIP(hipStreamWaitEvent(lst, after, 0));
     if (!p->direct_counts)
       SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits[s.gen], sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, cnt));
-    SCN_HIP(hipEventRecord(s.done, cnt));
+    if (!(after_is_done && after)) SCN_HIP(hipEventRecord(s.done, cnt));
     if (eager) {
       int st2 = build_list(p, s, true);
       if (st2) return st2;
     }
-  } else {
+  } else if (!(after && in_packet)) {  // spectrum-only plans: `done` follows the kernel on its stream
     SCN_HIP(hipEventRecord(s.done, s.stream));
   }
   s.pending = true;
@@ -494,6 +504,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     if (const char *e = getenv("SCN_EXP_RESERVE_CUS")) p->fft_cus = std::max(1, p->num_cus - atoi(e));
     p->direct_counts = d.n >= 8192;
     if (const char *e = getenv("SCN_EXP_DIRECT_COUNTS")) p->direct_counts = atoi(e) != 0;
+    if (const char *e = getenv("SCN_EXP_STOP_EVENT")) p->stop_event_in_packet = atoi(e) != 0 ? 1 : 0;
     SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->h2d_stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->d2h_stream, hipStreamNonBlocking));

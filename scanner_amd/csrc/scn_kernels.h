@@ -110,5 +110,5 @@ hipError_t scn_launch_convert(int kind, bool correct_dc, const void *raw, scn_v2
                               float scale, hipStream_t stream);
 
 hipError_t scn_launch_fft(uint32_t n, int kind, bool correct_dc, bool hits, const ScnFftArgs &args,
-                          int num_cus, hipStream_t stream);
+                          int num_cus, hipStream_t stream, hipEvent_t stop = nullptr);
 bool scn_fft_size_supported(uint32_t n);

@@ -22,6 +22,7 @@
 // Workgroups are persistent over buffers (grid-stride), so the pass-1 twiddles and the
 // window coefficients a thread needs live in registers for the whole launch.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1119,8 +1120,17 @@ hipError_t scn_launch_convert(int kind, bool dc, const void *raw, scn_v2f *out, 
 // ------------------------------------------------------------------------------------
 // host-side launcher
 // ------------------------------------------------------------------------------------
+// `stop` (may be null): an event completed by the kernel's own dispatch packet (hipExtLaunchKernel) instead of a marker
+// packet of its own behind the kernel.
+template <typename K>
+static hipError_t launch_with_stop(K k, int grid, uint32_t threads, uint32_t lds, hipStream_t s, hipEvent_t stop, const ScnFftArgs &a) {
+  if (stop) hipExtLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, nullptr, stop, 0, a);
+  else hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a);
+  return hipGetLastError();
+}
+
 template <int M, int KIND>
-static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
+static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s, hipEvent_t stop) {
   typedef Geo<M> G;
   void (*k)(ScnFftArgs) = nullptr;
   if (dc && hits) k = scn_fft_kernel<M, KIND, true, true>;
@@ -1136,23 +1146,22 @@ static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, int num_c
   }
   int grid = num_cus * (int)G::WG_PER_CU;  // one resident wave of persistent workgroups
   if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), G::LDS_BYTES, s, a);
-  return hipGetLastError();
+  return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
 }
 
 template <int M>
-static hipError_t launch_size(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream) {
+static hipError_t launch_size(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_kind<M, SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream);
-    case SCN_K_SHORT_COMPLEX: return launch_kind<M, SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream);
-    case SCN_K_SHORT: return launch_kind<M, SCN_K_SHORT>(args, dc, hits, num_cus, stream);
-    case SCN_K_BYTE_COMPLEX: return launch_kind<M, SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream);
+    case SCN_K_FLOAT_COMPLEX: return launch_kind<M, SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_kind<M, SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_kind<M, SCN_K_SHORT>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_kind<M, SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }
 
 template <int KIND>
-static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s) {
+static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s, hipEvent_t stop) {
   typedef Geo8k G;
   void (*k)(ScnFftArgs) = nullptr;
   if (dc && hits) k = scn_fft8k_kernel<KIND, true, true>;
@@ -1164,32 +1173,31 @@ static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, int nu
   if (e != hipSuccess) return e;
   int grid = num_cus * (int)G::WG_PER_CU;
   if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), G::LDS_BYTES, s, a);
-  return hipGetLastError();
+  return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
 }
-static hipError_t launch_8k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream) {
+static hipError_t launch_8k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_8k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream);
-    case SCN_K_SHORT_COMPLEX: return launch_8k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream);
-    case SCN_K_SHORT: return launch_8k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream);
-    case SCN_K_BYTE_COMPLEX: return launch_8k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream);
+    case SCN_K_FLOAT_COMPLEX: return launch_8k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_8k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_8k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_8k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus,
-                          hipStream_t stream) {
-  if (args.n_buffers == 0) return hipSuccess;
+                          hipStream_t stream, hipEvent_t stop) {
+  if (args.n_buffers == 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
   switch (n) {
-    case 1024: return launch_size<4>(kind, dc, hits, args, num_cus, stream);
-    case 2048: return launch_size<8>(kind, dc, hits, args, num_cus, stream);
-    case 4096: return launch_size<16>(kind, dc, hits, args, num_cus, stream);
+    case 1024: return launch_size<4>(kind, dc, hits, args, num_cus, stream, stop);
+    case 2048: return launch_size<8>(kind, dc, hits, args, num_cus, stream, stop);
+    case 4096: return launch_size<16>(kind, dc, hits, args, num_cus, stream, stop);
 #if SCN_WIDE_8192
-    case 8192: return launch_8k(kind, dc, hits, args, num_cus, stream);
+    case 8192: return launch_8k(kind, dc, hits, args, num_cus, stream, stop);
 #else
-    case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream);  // the 512-thread form (variant build)
+    case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream, stop);  // the 512-thread form (variant build)
 #endif
-    case 16384: return launch_size<64>(kind, dc, hits, args, num_cus, stream);
+    case 16384: return launch_size<64>(kind, dc, hits, args, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }

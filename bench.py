@@ -426,7 +426,7 @@ def main():
     plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank)
     ext = torch.cuda.ExternalStream(plan.stream_handle, device=dev)
 
-    def make_loop(pl, want_records):
+    def make_loop(pl, want_records, zero_copy=False):
         """step(k): one pass over this rank's batch = len(chunks) launches, double-buffered over the plan's two slots; the
         results of a slot are collected right before it is reused (counts + trigger flags; the ordered records too if asked)"""
         pending = [False, False]
@@ -435,7 +435,11 @@ def main():
 
         def collect(s):
             tc0 = time.perf_counter()
-            _, h, _ = pl.collect(s, want_power=False, want_hits=want_records, hits_out=rec_buf)
+            if zero_copy:  # counts + trigger flags from scn_collect, the records read in place (scn_hits_view)
+                pl.collect(s, want_power=False, want_hits=False)
+                h = pl.hits_view(s)
+            else:
+                _, h, _ = pl.collect(s, want_power=False, want_hits=want_records, hits_out=rec_buf)
             state["collect_s"] = state.get("collect_s", 0.0) + time.perf_counter() - tc0
             state["collects"] = state.get("collects", 0) + 1
             if want_records:
@@ -499,8 +503,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = tt.tolist()
 
-    def timed_leg(pl, want_records, warm):
-        st, dr, state = make_loop(pl, want_records)
+    def timed_leg(pl, want_records, warm, zero_copy=False):
+        st, dr, state = make_loop(pl, want_records, zero_copy)
         for k in range(warm):
             st(k)
         dr()
@@ -530,6 +534,7 @@ def main():
     if not args.no_records_leg:
         el3, st3 = timed_leg(plan, True, min(args.warmup, 20))
         nh = st3["hits"]
+        el4, st4 = timed_leg(plan, True, min(args.warmup, 20), zero_copy=True)
         plan.submit_device(0, raws[0][chunks[0][0]:chunks[0][1]], chunks[0][1] - chunks[0][0], fc[:chunks[0][1]], seq[:chunks[0][1]],
                            sync_producer=False)
         plan.wait(0)
@@ -542,6 +547,9 @@ def main():
                    "ms_per_step": round(el3 / args.steps * 1e3, 5), "hits_per_step": round(nh / max(args.steps, 1), 1),
                    "collect_with_records_us": round(collect_us, 1), "collect_hits": int(len(h1)),
                    "collect_call_avg_us_in_loop": round(st3["collect_s"] / max(st3["collects"], 1) * 1e6, 1),
+                   "zero_copy_view": {"value": round(world * shard * n * args.steps / el4 / 1e6, 1), "ms_per_step": round(el4 / args.steps * 1e3, 5),
+                                      "collect_plus_view_avg_us_in_loop": round(st4["collect_s"] / max(st4["collects"], 1) * 1e6, 1),
+                                      "note": "the same loop reading the records in place through scn_hits_view (no copy into a caller buffer)"},
                    "note": "same steps, scn_collect returns the ordered, completed scn_hit records (built on the GPU) every step; "
                            "collect_with_records_us = one such call on an idle plan whose list is already complete (event wait + "
                            "top-up DMA if the prefetch was short + one memcpy out of pinned memory into the caller's buffer)"}

@@ -767,6 +767,7 @@ int scn_hits_view(scn_plan *p, int slot, const scn_hit **hits, uint32_t *n) {
   if (s.pending || !s.list_valid) return fail(SCN_E_STATE, "slot %d: no collected submit whose hit list is still available", slot);
   SCN_HIP(hipSetDevice(p->d.device_id));
   *n = std::min(s.total_hits, p->d.max_hits);
+  p->records_wanted = true;  // (a caller that reads the list through the view wants it built eagerly too)
   if (*n && (st = fetch_list(p, s, *n))) return st;
   *hits = s.h_list;
   return SCN_OK;

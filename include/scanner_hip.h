@@ -84,7 +84,8 @@ typedef struct scn_hit {
  * constant where one exists. */
 typedef struct scn_plan_desc {
   uint32_t struct_size;
-  uint32_t n;              /* sampleCount = FFT size (scan.cpp:85); a power of two, 1024 ... 16384 */
+  uint32_t n;              /* sampleCount = FFT size (scan.cpp:85): a power of two from 16 to 65536.  1024 ... 16384 run in
+                              the fused LDS kernels; the others through a staged (slower) path with identical results */
   uint32_t sample_rate;    /* Hz (scan.cpp:92) */
   uint32_t sample_kind;    /* SCN_KIND_* */
   uint32_t enob;           /* effective bits (scan.cpp:138,183) */

@@ -58,6 +58,7 @@ namespace {
   } while (0)
 
 struct Slot {
+  scn_v2f *d_gen_work[2] = {nullptr, nullptr};  // generic sizes only: [max_batch][n] complex ping-pong between the stages
   void *h_raw = nullptr;            // pinned staging, max_batch raw buffers
   void *d_raw = nullptr;            // device copy of the staging slot
   float *d_power = nullptr;         // [max_batch][N] dB spectra (plan-owned destination)
@@ -127,6 +128,7 @@ struct scn_plan {
   // host learned the counts late and submitted the launch after next ~10 us late, every other launch).  true: the FFT
   // kernel stores each count to pinned host memory as well (one 4-byte PCIe write per buffer; costs a 4096-point launch
   // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
+  bool generic = false;  // no fused kernel for this size: the staged path of scn_generic.hip
   bool direct_counts = false;
   int stop_event_in_packet = -1;  // -1: by launch size (see submit_common); 0 / 1: experiment knob SCN_EXP_STOP_EVENT
   int fft_cus = 0;  // CUs the FFT launch is sized for (num_cus unless SCN_EXP_RESERVE_CUS leaves some to the side stream)
@@ -355,8 +357,34 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   // 16.8 M samples 44 -> 46..58 and 8.4 M 31 -> 29..56 (erratic: short kernels that carry an event get serialised).
   const bool after_is_done = cnt == s.stream && !s.own_stream;  // direct counts on the plan's stream
   hipEvent_t after = (!nb || s.own_stream) ? nullptr : !hits ? s.done : after_is_done ? s.done : s.kernel_done;
-  const bool in_packet = after && (p->stop_event_in_packet < 0 ? (uint64_t)nb * n >= (1u << 25) : p->stop_event_in_packet != 0);
-  SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->fft_cus, s.stream, in_packet ? after : nullptr));
+  const bool in_packet = after && !p->generic &&
+                         (p->stop_event_in_packet < 0 ? (uint64_t)nb * n >= (1u << 25) : p->stop_event_in_packet != 0);
+  if (p->generic) {
+    for (int g = 0; g < 2 && nb; g++)
+      if (!s.d_gen_work[g]) SCN_HIP(hipMalloc(&s.d_gen_work[g], sizeof(scn_v2f) * (size_t)n * p->d.max_batch));
+    ScnGenericArgs ga;
+    ga.raw = d_raw;
+    ga.window = p->d_window;
+    ga.twiddle = p->d_twiddle;
+    ga.work0 = s.d_gen_work[0];
+    ga.work1 = s.d_gen_work[1];
+    ga.power_db = d_power;
+    ga.n = n;
+    ga.log2n = 0;
+    while ((1u << ga.log2n) < n) ga.log2n++;
+    ga.n_buffers = nb;
+    ga.scale = p->scale;
+    ga.threshold = p->d.threshold;
+    ga.dc_ignore = p->d.dc_ignore_bins;
+    ga.i_lo = p->i_lo;
+    ga.i_hi = p->i_hi;
+    ga.hits = a.hits;
+    ga.hit_region = p->hit_region;
+    ga.per_buffer_hits = a.per_buffer_hits;
+    SCN_HIP(scn_launch_generic((int)p->d.sample_kind, p->d.correct_dc != 0, hits, ga, p->num_cus, s.stream));
+  } else {
+    SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->fft_cus, s.stream, in_packet ? after : nullptr));
+  }
   if (scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
   if (hits && nb) {
@@ -378,6 +406,8 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
 }
 
 void free_slot(Slot &s) {
+  for (int g = 0; g < 2; g++)
+    if (s.d_gen_work[g]) (void)hipFree(s.d_gen_work[g]);
   if (s.h_raw) (void)hipHostFree(s.h_raw);
   if (s.d_raw) (void)hipFree(s.d_raw);
   if (s.d_power) (void)hipFree(s.d_power);
@@ -460,8 +490,8 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
   if (d.mode != SCN_MODE_FREQUENCY_DOMAIN && d.mode != SCN_MODE_TIME_DOMAIN)
     return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
-  if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n))
-    return fail(SCN_E_INVALID, "unsupported FFT size %u (1024, 2048, 4096, 8192, 16384)", d.n);
+  if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !scn_generic_size_supported(d.n))
+    return fail(SCN_E_INVALID, "unsupported FFT size %u (powers of two from 16 to 65536; fused kernels for 1024 ... 16384)", d.n);
   if (d.n == 0 || d.n > (1u << 24)) return fail(SCN_E_INVALID, "bad sample count %u", d.n);
   if (d.sample_rate == 0) return fail(SCN_E_INVALID, "sample_rate must be > 0");
 
@@ -502,7 +532,8 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     p->fft_cus = p->num_cus;
     if (const char *e = getenv("SCN_EXP_COMPACT")) p->compact_mode = atoi(e);
     if (const char *e = getenv("SCN_EXP_RESERVE_CUS")) p->fft_cus = std::max(1, p->num_cus - atoi(e));
-    p->direct_counts = d.n >= 8192;
+    p->generic = d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n);
+    p->direct_counts = d.n >= 8192 && !p->generic;
     if (const char *e = getenv("SCN_EXP_DIRECT_COUNTS")) p->direct_counts = atoi(e) != 0;
     if (const char *e = getenv("SCN_EXP_STOP_EVENT")) p->stop_event_in_packet = atoi(e) != 0 ? 1 : 0;
     SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -533,7 +564,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     SCN_TRY(hipMemcpyAsync(p->d_window, p->h_window.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, p->stream));
     SCN_TRY(hipMemcpyAsync(p->d_twiddle, tw.data(), sizeof(float) * 2 * d.n, hipMemcpyHostToDevice, p->stream));
     // the same values, regrouped per thread of the fused kernel: entry (p-1, t) = W_n^(t p), t < n/16
-    const uint32_t nthreads = d.n / 16;
+    const uint32_t nthreads = std::max<uint32_t>(d.n / 16, 1u);
     std::vector<float> tw1(2 * (size_t)15 * nthreads);
     for (uint32_t pp = 1; pp < 16; pp++)
       for (uint32_t t = 0; t < nthreads; t++) {

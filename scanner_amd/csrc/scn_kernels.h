@@ -105,6 +105,23 @@ struct ScnCompactArgs {
 hipError_t scn_launch_hit_scan(const ScnCompactArgs &args, hipStream_t stream);
 hipError_t scn_launch_hit_compact(const ScnCompactArgs &args, hipStream_t stream);
 
+// The same path for the power-of-two sizes without a fused kernel (scn_generic.hip): through HBM, stage by stage
+struct ScnGenericArgs {
+  const void *raw;            // n_buffers raw buffers back to back
+  const float *window;        // [n]
+  const scn_v2f *twiddle;     // W_n^m, m in [0, n)
+  scn_v2f *work0, *work1;     // [n_buffers][n] complex each: ping-pong between the stages
+  float *power_db;            // [n_buffers][n] or nullptr
+  uint32_t n, log2n, n_buffers;
+  float scale, threshold;
+  uint32_t dc_ignore, i_lo, i_hi;
+  ScnDevHit *hits;            // [n_buffers][hit_region]
+  uint32_t hit_region;
+  uint32_t *per_buffer_hits;  // [n_buffers], zeroed by the launcher
+};
+hipError_t scn_launch_generic(int kind, bool correct_dc, bool hits, const ScnGenericArgs &args, int num_cus, hipStream_t stream);
+bool scn_generic_size_supported(uint32_t n);
+
 // K1 alone (capture path)
 hipError_t scn_launch_convert(int kind, bool correct_dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers,
                               float scale, hipStream_t stream);

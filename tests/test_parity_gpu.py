@@ -279,6 +279,48 @@ def test_sizes_integer_kinds(torch_cuda, oracle_mod, n, kind, enob, dc):
     assert np.array_equal(t, t_ref)
 
 
+@pytest.mark.parametrize("n,kind,enob,dc", [
+    (16, capi.KIND_FLOAT_COMPLEX, 12, False), (64, capi.KIND_SHORT_COMPLEX, 12, True), (256, capi.KIND_FLOAT_COMPLEX, 12, False),
+    (512, capi.KIND_BYTE_COMPLEX, 8, True), (512, capi.KIND_SHORT, 12, False), (32768, capi.KIND_FLOAT_COMPLEX, 12, False),
+    (32768, capi.KIND_SHORT_COMPLEX, 12, True), (65536, capi.KIND_FLOAT_COMPLEX, 12, False), (65536, capi.KIND_BYTE_COMPLEX, 8, False),
+])
+def test_generic_sizes_vs_oracle(torch_cuda, oracle_mod, n, kind, enob, dc):
+    """The reference plans any --count (fft.cpp:4-11).  Powers of two without a fused kernel (16 ... 512, 32768, 65536) run
+    through the staged path of scn_generic.hip: same spectra (to the bar), same hit lists, same trigger flags."""
+    nb = {16: 200, 64: 150, 256: 90, 512: 75, 32768: 9, 65536: 5}[n]
+    x = synth.cfloat_batch(n, nb, seed=70 + n % 1000, sigma=0.1)
+    raw = synth.quantize(x, kind) if kind != capi.KIND_FLOAT_COMPLEX else x
+    if dc:  # a DC offset to remove -- clipped, not wrapped: a wrapped int8 buffer is dominated by its jumps, the threshold below
+        info = np.iinfo(raw.dtype)  # would then sit far under the buffer mean, where two float32 FFTs may disagree on a bin
+        raw = np.clip(raw.astype(np.int32) + 9, info.min, info.max).astype(raw.dtype)
+    fc = 2.4e9 + 6e6 * np.arange(nb)
+    p_ref, _, _ = oracle_mod.Oracle(n, FS, 1e9, kind=kind, enob=enob, correct_dc=dc).run(raw, threads=4)
+    ev = tol.evaluated_mask(n)
+    thr = tol.pick_threshold(p_ref, n, start=float(np.quantile(p_ref[:, ev], 0.97))) if ev.any() else 0.0
+    (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, kind, raw, fc, None, thr, enob, dc, max_hits=nb * n)
+    print(n, tol.compare_spectra(p, p_ref))
+    assert len(h_ref) > 0 or not ev.any()
+    _assert_hits_equal(h, h_ref)
+    assert np.array_equal(t, t_ref)
+
+
+def test_generic_size_double_buffered_and_windows(torch_cuda, oracle_mod):
+    """Both slots in flight at a generic size, every evaluated bin a hit (the region / compaction capacity at 65536 points:
+    49 145 evaluated bins per buffer, a 2048-word bitmap per wave), the list walked in windows."""
+    n, nb = 65536, 3
+    xs = [synth.cfloat_batch(n, nb, seed=90 + s, sigma=0.1) for s in range(2)]
+    fc = np.array([1e9, 2e9, 3e9])
+    with Plan(n, FS, -200.0, max_batch=nb, max_hits=4096, flags=capi.OUT_HITS) as plan:
+        for s in range(2):
+            plan.submit_device(s, _to_dev(torch_cuda, xs[s]), nb, fc)
+        for s in range(2):
+            _, h_ref, t_ref = oracle_mod.Oracle(n, FS, -200.0).run(xs[s], fc, threads=4)
+            _, h, t = plan.collect(s, want_power=False)
+            assert len(h_ref) == nb * tol.evaluated_mask(n).sum() == len(h)
+            _assert_hits_equal(h, h_ref)
+            assert np.array_equal(t, t_ref) and t.all()
+
+
 @pytest.mark.parametrize("n", [1024, 8192, 16384])
 def test_sizes_all_bins_hit_mask(torch_cuda, oracle_mod, n):
     """mask edges (DC window, use-band) and the i <-> j mapping at the other sizes"""

@@ -253,7 +253,7 @@ class Oracle:
         out = np.empty(self.n, np.complex64)
         L = lib()
         f = L.scn_oracle_fft_create(self.n)
-        assert f, "oracle FFT needs a power-of-two n"
+        assert f, "oracle FFT needs n >= 2"
         L.scn_oracle_fft_process(f, _p(out), _p(x))
         L.scn_oracle_fft_destroy(f)
         return out

@@ -140,6 +140,7 @@ void scn_oracle_window_apply(float *s, const float *w, uint32_t n) {
  * same definition (sign -1, unnormalised, natural order). */
 struct scn_oracle_fft {
   uint32_t n, log2n;
+  int direct;      /* n is not a power of two: the DFT sum itself, in double (FFTW plans any n, fft.cpp:4-11) */
   float *in, *out; /* fftwIn / fftwOut of fft.h:14-15 */
   float *tw;       /* n/2 complex twiddles */
   double *twd;     /* the same in double, and a double work array, for the accurate mode */
@@ -160,11 +161,25 @@ void scn_oracle_set_fft_mode(int accurate) { g_fft_accurate = accurate ? 1 : 0; 
 int scn_oracle_get_fft_mode(void) { return g_fft_accurate; }
 
 scn_oracle_fft *scn_oracle_fft_create(uint32_t n) {
-  if (n < 2 || (n & (n - 1)) != 0) return NULL;
+  if (n < 2) return NULL;
   scn_oracle_fft *f = (scn_oracle_fft *)calloc(1, sizeof(*f));
   if (!f) return NULL;
   f->n = n;
   while ((1u << f->log2n) < n) f->log2n++;
+  if ((n & (n - 1)) != 0) { /* any other length: Y[k] = sum_j X[j] exp(-2 pi i j k / n) evaluated as written, O(n^2), in
+                               double with one rounding to float -- small sizes in the tests only */
+    f->direct = 1;
+    f->in = (float *)malloc(sizeof(float) * 2 * n);
+    f->out = (float *)malloc(sizeof(float) * 2 * n);
+    f->twd = (double *)malloc(sizeof(double) * 2 * n);
+    const double pi_ = 3.14159265358979323846;
+    for (uint32_t k = 0; k < n; k++) {
+      double a = -2.0 * pi_ * (double)k / (double)n;
+      f->twd[2 * k] = cos(a);
+      f->twd[2 * k + 1] = sin(a);
+    }
+    return f;
+  }
   f->in = (float *)aligned_alloc(64, sizeof(float) * 2 * n);
   f->out = (float *)aligned_alloc(64, sizeof(float) * 2 * n);
   f->tw = (float *)aligned_alloc(64, sizeof(float) * n);
@@ -226,7 +241,29 @@ static void fft_execute_accurate(scn_oracle_fft *f) {
   for (uint32_t i = 0; i < 2 * n; i++) f->out[i] = (float)o[i];
 }
 
+static void fft_execute_direct(scn_oracle_fft *f) {
+  const uint32_t n = f->n;
+  for (uint32_t k = 0; k < n; k++) {
+    double sr = 0.0, si = 0.0;
+    uint32_t idx = 0; /* (j * k) mod n, stepped */
+    for (uint32_t j = 0; j < n; j++) {
+      const double wr = f->twd[2 * idx], wi = f->twd[2 * idx + 1];
+      const double xr = (double)f->in[2 * j], xi = (double)f->in[2 * j + 1];
+      sr += xr * wr - xi * wi;
+      si += xr * wi + xi * wr;
+      idx += k;
+      if (idx >= n) idx -= n;
+    }
+    f->out[2 * k] = (float)sr;
+    f->out[2 * k + 1] = (float)si;
+  }
+}
+
 static void fft_execute(scn_oracle_fft *f) {
+  if (f->direct) {
+    fft_execute_direct(f);
+    return;
+  }
   if (g_fft_accurate) {
     fft_execute_accurate(f);
     return;

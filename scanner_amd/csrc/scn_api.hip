@@ -129,6 +129,9 @@ struct scn_plan {
   // kernel stores each count to pinned host memory as well (one 4-byte PCIe write per buffer; costs a 4096-point launch
   // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
   bool generic = false;  // no fused kernel for this size: the staged path of scn_generic.hip
+  uint32_t fft_m = 0, log2m = 0;     // ... and its transform length: n for a power of two, >= 2n - 1 for Bluestein
+  scn_v2f *d_chirp = nullptr;        // Bluestein: w[i] = exp(-i pi i^2 / n)
+  scn_v2f *d_bfilter = nullptr;      // Bluestein: FFT_m of the chirp filter / m
   bool direct_counts = false;
   int stop_event_in_packet = -1;  // -1: by launch size (see submit_common); 0 / 1: experiment knob SCN_EXP_STOP_EVENT
   int fft_cus = 0;  // CUs the FFT launch is sized for (num_cus unless SCN_EXP_RESERVE_CUS leaves some to the side stream)
@@ -183,6 +186,34 @@ void build_window(uint32_t type, uint32_t n, std::vector<float> &w) {
     double x = (double)i / m;
     w[i] = (float)(0.35875 - 0.48829 * std::cos(2.0 * pi * x) + 0.14128 * std::cos(4.0 * pi * x) -
                    0.01168 * std::cos(6.0 * pi * x));
+  }
+}
+
+// In-place forward DFT of a power-of-two length in double (plan creation only: the Bluestein filter's transform).
+void host_fft(std::vector<double> &re, std::vector<double> &im) {
+  const size_t n = re.size();
+  for (size_t i = 1, j = 0; i < n; i++) {  // bit reversal
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      std::swap(re[i], re[j]);
+      std::swap(im[i], im[j]);
+    }
+  }
+  const double pi = 3.14159265358979323846;
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t k = 0; k < len / 2; k++) {
+      const double a = -2.0 * pi * (double)k / (double)len, wr = std::cos(a), wi = std::sin(a);
+      for (size_t i = k; i < n; i += len) {
+        const size_t j = i + len / 2;
+        const double xr = re[j] * wr - im[j] * wi, xi = re[j] * wi + im[j] * wr;
+        re[j] = re[i] - xr;
+        im[j] = im[i] - xi;
+        re[i] += xr;
+        im[i] += xi;
+      }
+    }
   }
 }
 
@@ -361,7 +392,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
                          (p->stop_event_in_packet < 0 ? (uint64_t)nb * n >= (1u << 25) : p->stop_event_in_packet != 0);
   if (p->generic) {
     for (int g = 0; g < 2 && nb; g++)
-      if (!s.d_gen_work[g]) SCN_HIP(hipMalloc(&s.d_gen_work[g], sizeof(scn_v2f) * (size_t)n * p->d.max_batch));
+      if (!s.d_gen_work[g]) SCN_HIP(hipMalloc(&s.d_gen_work[g], sizeof(scn_v2f) * (size_t)p->fft_m * p->d.max_batch));
     ScnGenericArgs ga;
     ga.raw = d_raw;
     ga.window = p->d_window;
@@ -370,8 +401,10 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     ga.work1 = s.d_gen_work[1];
     ga.power_db = d_power;
     ga.n = n;
-    ga.log2n = 0;
-    while ((1u << ga.log2n) < n) ga.log2n++;
+    ga.m = p->fft_m;
+    ga.log2m = p->log2m;
+    ga.chirp = p->d_chirp;
+    ga.bfilter = p->d_bfilter;
     ga.n_buffers = nb;
     ga.scale = p->scale;
     ga.threshold = p->d.threshold;
@@ -490,8 +523,10 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
   if (d.mode != SCN_MODE_FREQUENCY_DOMAIN && d.mode != SCN_MODE_TIME_DOMAIN)
     return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
-  if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !scn_generic_size_supported(d.n))
-    return fail(SCN_E_INVALID, "unsupported FFT size %u (powers of two from 16 to 65536; fused kernels for 1024 ... 16384)", d.n);
+  if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !scn_generic_size_supported(d.n) &&
+      !scn_bluestein_size_supported(d.n))
+    return fail(SCN_E_INVALID, "unsupported FFT size %u (16 to 65536 for powers of two, 16 to 32768 otherwise; fused kernels for "
+                "1024 ... 16384)", d.n);
   if (d.n == 0 || d.n > (1u << 24)) return fail(SCN_E_INVALID, "bad sample count %u", d.n);
   if (d.sample_rate == 0) return fail(SCN_E_INVALID, "sample_rate must be > 0");
 
@@ -552,23 +587,61 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
         sl.own_stream = true;
       }
     }
+    // the transform length: the buffer length, except for sizes that are not powers of two (Bluestein, scn_generic.hip)
+    const bool blue = p->generic && (d.n & (d.n - 1u)) != 0u;
+    uint32_t tn = d.n;
+    if (blue)
+      for (tn = 1; tn < 2u * d.n - 1u; tn <<= 1) {
+      }
+    p->fft_m = tn;
+    for (p->log2m = 0; (1u << p->log2m) < tn; p->log2m++) {
+    }
     SCN_TRY(hipMalloc(&p->d_window, sizeof(float) * d.n));
-    SCN_TRY(hipMalloc(&p->d_twiddle, sizeof(scn_v2f) * d.n));
-    std::vector<float> tw(2 * (size_t)d.n);
+    SCN_TRY(hipMalloc(&p->d_twiddle, sizeof(scn_v2f) * tn));
+    std::vector<float> tw(2 * (size_t)tn);
     const double pi = 3.14159265358979323846;
-    for (uint32_t m = 0; m < d.n; m++) {
-      double a = -2.0 * pi * (double)m / (double)d.n;
+    for (uint32_t m = 0; m < tn; m++) {
+      double a = -2.0 * pi * (double)m / (double)tn;
       tw[2 * m] = (float)std::cos(a);
       tw[2 * m + 1] = (float)std::sin(a);
     }
     SCN_TRY(hipMemcpyAsync(p->d_window, p->h_window.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, p->stream));
-    SCN_TRY(hipMemcpyAsync(p->d_twiddle, tw.data(), sizeof(float) * 2 * d.n, hipMemcpyHostToDevice, p->stream));
+    SCN_TRY(hipMemcpyAsync(p->d_twiddle, tw.data(), sizeof(float) * 2 * tn, hipMemcpyHostToDevice, p->stream));
+    std::vector<float> chirp, bfilter;
+    if (blue) {
+      // w[i] = exp(-i pi i^2 / n) with i^2 reduced mod 2n in integers; the filter b[k] = conj(w[|k|]) laid out cyclically over
+      // tn points, transformed here in double (tn <= 65536) and scaled by 1/tn (the second device transform is an inverse
+      // one up to conjugations, which needs that factor)
+      chirp.resize(2 * (size_t)d.n);
+      std::vector<double> br(tn, 0.0), bi(tn, 0.0);
+      for (uint32_t i = 0; i < d.n; i++) {
+        const double a = -pi * (double)(((uint64_t)i * i) % (2ull * d.n)) / (double)d.n;
+        chirp[2 * i] = (float)std::cos(a);
+        chirp[2 * i + 1] = (float)std::sin(a);
+        br[i] = std::cos(a);
+        bi[i] = -std::sin(a);
+        if (i) {
+          br[tn - i] = br[i];
+          bi[tn - i] = bi[i];
+        }
+      }
+      host_fft(br, bi);
+      bfilter.resize(2 * (size_t)tn);
+      for (uint32_t k = 0; k < tn; k++) {
+        bfilter[2 * k] = (float)(br[k] / (double)tn);
+        bfilter[2 * k + 1] = (float)(bi[k] / (double)tn);
+      }
+      SCN_TRY(hipMalloc(&p->d_chirp, sizeof(float) * chirp.size()));
+      SCN_TRY(hipMalloc(&p->d_bfilter, sizeof(float) * bfilter.size()));
+      SCN_TRY(hipMemcpyAsync(p->d_chirp, chirp.data(), sizeof(float) * chirp.size(), hipMemcpyHostToDevice, p->stream));
+      SCN_TRY(hipMemcpyAsync(p->d_bfilter, bfilter.data(), sizeof(float) * bfilter.size(), hipMemcpyHostToDevice, p->stream));
+    }
     // the same values, regrouped per thread of the fused kernel: entry (p-1, t) = W_n^(t p), t < n/16
-    const uint32_t nthreads = std::max<uint32_t>(d.n / 16, 1u);
+    const uint32_t nthreads = p->generic ? 1u : d.n / 16;  // (only the fused kernels read it)
     std::vector<float> tw1(2 * (size_t)15 * nthreads);
     for (uint32_t pp = 1; pp < 16; pp++)
       for (uint32_t t = 0; t < nthreads; t++) {
-        const uint32_t m = (t * pp) & (d.n - 1);
+        const uint32_t m = (t * pp) & (tn - 1);
         tw1[2 * ((size_t)(pp - 1) * nthreads + t)] = tw[2 * m];
         tw1[2 * ((size_t)(pp - 1) * nthreads + t) + 1] = tw[2 * m + 1];
       }
@@ -599,6 +672,8 @@ int scn_plan_destroy(scn_plan *p) {
   for (int i = 0; i < SCN_NUM_SLOTS; i++) free_slot(p->slot[i]);
   if (p->d_window) (void)hipFree(p->d_window);
   if (p->d_twiddle) (void)hipFree(p->d_twiddle);
+  if (p->d_chirp) (void)hipFree(p->d_chirp);
+  if (p->d_bfilter) (void)hipFree(p->d_bfilter);
   if (p->d_tw1_table) (void)hipFree(p->d_tw1_table);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   if (p->h2d_stream) (void)hipStreamDestroy(p->h2d_stream);

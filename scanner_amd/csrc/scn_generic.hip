@@ -10,12 +10,20 @@
 //   scn_gen_finish_kernel   K4 + K5: dB (utility.cpp:86-98), fftshift-indexed mask, strict > threshold, hit records into the
 //                           buffer's region (process.cpp:46-62)
 //
+// Sizes that are NOT powers of two (16 <= N <= 32768) use the same kernels around Bluestein's identity
+//   X[k] = w[k] * sum_n (x[n] w[n]) conj(w)[k - n],   w[n] = exp(-i pi n^2 / N):
+// a cyclic convolution of length M = the power of two >= 2N - 1, i.e. load (x window w, zero-padded to M) -> FFT_M ->
+// multiply by the precomputed FFT_M of the chirp filter (scaled by 1/M) and conjugate -> FFT_M again (an inverse transform
+// up to a conjugation) -> finish.  The final w[k] and the conjugation have modulus one and never reach the dB value.
+//
 // Same arithmetic and the same outputs as the fused path (spectrum, per-buffer counts, unordered regions that
 // scn_hits.hip orders), at 2 + log_4 N passes over the data instead of one: a correctness path for unusual sizes, not a
 // fast one -- each kernel is a plain streaming kernel (coalesced reads; the stage writes are strided by the sub-transform
 // length).  Twiddles come from the plan's W_N table.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <utility>
 
 #include "scn_device.h"
 #include "scn_kernels.h"
@@ -102,9 +110,26 @@ __global__ __launch_bounds__(256) void scn_gen_load_kernel(ScnGenericArgs a) {
       dc_re = (int)((uint32_t)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) / n);  // int32 /= uint32, utility.cpp:77-78
       dc_im = (int)((uint32_t)(s_sum[4] + s_sum[5] + s_sum[6] + s_sum[7]) / n);
     }
-    v2f *out = a.work0 + (size_t)b * n;
+    v2f *out = a.work0 + (size_t)b * a.m;
     // float(s - dc)*onebymax*w and float(s - dc)*(onebymax*w) round identically (onebymax is +-2^-k), as in the fused kernels
-    for (uint32_t i = t; i < n; i += 256u) out[i] = to_v2f(L::conv(buf, n, i, dc_re, dc_im, 1.0f) * (a.window[i] * a.scale));
+    if (a.chirp) {  // Bluestein: times the chirp, zero-padded to the convolution length
+      for (uint32_t i = t; i < a.m; i += 256u) {
+        cf v = cf{0.0f, 0.0f};
+        if (i < n) v = cmul(L::conv(buf, n, i, dc_re, dc_im, 1.0f) * (a.window[i] * a.scale), from_v2f(a.chirp[i]));
+        out[i] = to_v2f(v);
+      }
+    } else {
+      for (uint32_t i = t; i < n; i += 256u) out[i] = to_v2f(L::conv(buf, n, i, dc_re, dc_im, 1.0f) * (a.window[i] * a.scale));
+    }
+  }
+}
+
+// Bluestein, between the two transforms: y = conj(x * B'), B' = FFT_M(chirp filter) / M
+__global__ __launch_bounds__(256) void scn_gen_pointwise_kernel(ScnGenericArgs a, v2f *__restrict__ x) {
+  const size_t total = (size_t)a.n_buffers << a.log2m;
+  for (size_t g = (size_t)blockIdx.x * 256u + threadIdx.x; g < total; g += (size_t)gridDim.x * 256u) {
+    const cf y = cmul(from_v2f(x[g]), from_v2f(a.bfilter[(uint32_t)g & (a.m - 1u)]));
+    x[g] = v2f{y.x, -y.y};
   }
 }
 
@@ -118,7 +143,7 @@ __global__ __launch_bounds__(256) void scn_gen_stage_kernel(ScnGenericArgs a, co
   // every quantity is a power of two: shifts and masks, no integer division (the first version divided: 10 ms per
   // 512 x 65536-point batch instead of ~2)
   constexpr uint32_t LR = R == 4 ? 2u : 1u;
-  const uint32_t n = a.n, log2n = a.log2n, log2per = log2n - LR, per = 1u << log2per, ns = 1u << log2ns;
+  const uint32_t n = a.m, log2n = a.log2m, log2per = log2n - LR, per = 1u << log2per, ns = 1u << log2ns;  // the transform length
   const size_t total = (size_t)a.n_buffers << log2per;
   for (size_t g = (size_t)blockIdx.x * 256u + threadIdx.x; g < total; g += (size_t)gridDim.x * 256u) {
     const uint32_t b = (uint32_t)(g >> log2per), j = (uint32_t)g & (per - 1u);
@@ -148,19 +173,26 @@ __global__ __launch_bounds__(256) void scn_gen_stage_kernel(ScnGenericArgs a, co
   }
 }
 
-template <bool HITS>
+template <bool HITS, bool POW2>
 __global__ __launch_bounds__(256) void scn_gen_finish_kernel(ScnGenericArgs a, const v2f *__restrict__ spec) {
   const uint32_t n = a.n;
-  const size_t total = (size_t)a.n_buffers << a.log2n;
+  const size_t total = (size_t)a.n_buffers * n;
   for (size_t g = (size_t)blockIdx.x * 256u + threadIdx.x; g < total; g += (size_t)gridDim.x * 256u) {
-    const uint32_t b = (uint32_t)(g >> a.log2n), j = (uint32_t)g & (n - 1u);
-    const float d = power_db(from_v2f(spec[g]));
+    uint32_t b, j;
+    if (POW2) {
+      b = (uint32_t)(g >> a.log2m);
+      j = (uint32_t)g & (n - 1u);
+    } else {
+      b = (uint32_t)(g / n);
+      j = (uint32_t)(g - (size_t)b * n);
+    }
+    const float d = power_db(from_v2f(spec[((size_t)b << a.log2m) + j]));  // rows are m long (= n for the powers of two)
     if (a.power_db) a.power_db[g] = d;
     if (HITS) {
-      const uint32_t i = (j + n / 2u) & (n - 1u);  // the i with (i + N/2) % N == j, process.cpp:47
+      const uint32_t i = POW2 ? (j + n / 2u) & (n - 1u) : (j + n - n / 2u) % n;  // the i with (i + N/2) % N == j, process.cpp:47
       const bool keep = !(j < a.dc_ignore || (n - j) < a.dc_ignore) && !(i < a.i_lo || i > a.i_hi);
       const bool hit = keep && d > a.threshold;  // strict >, process.cpp:54
-      if (n >= 64u) {
+      if (POW2 && n >= 64u) {
         // a wave's 64 consecutive bins belong to one buffer: ONE atomic per wave hands out its slots (a noisy 65536-point
         // batch has ~20 k hits per buffer; one atomic per hit on 512 counters took 7 of the step's 10 ms)
         const unsigned long long m = __ballot(hit);
@@ -192,6 +224,7 @@ hipError_t launch_load(bool dc, const ScnGenericArgs &a, int grid, hipStream_t s
 }  // namespace
 
 bool scn_generic_size_supported(uint32_t n) { return n >= 16u && n <= 65536u && (n & (n - 1u)) == 0u; }
+bool scn_bluestein_size_supported(uint32_t n) { return n >= 16u && n <= 32768u && (n & (n - 1u)) != 0u; }
 
 hipError_t scn_launch_generic(int kind, bool dc, bool hits, const ScnGenericArgs &a, int num_cus, hipStream_t s) {
   if (a.n_buffers == 0) return hipSuccess;
@@ -210,34 +243,40 @@ hipError_t scn_launch_generic(int kind, bool dc, bool hits, const ScnGenericArgs
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  // stages: one radix-2 first when log2 N is odd, radix 4 from there on
-  const v2f *src = a.work0;
-  v2f *dst = a.work1;
-  uint32_t log2ns = 0;
-  const uint32_t log2n = a.log2n;
   auto blocks_for = [&](size_t items) {
     size_t b = (items + 255u) / 256u;
     const size_t cap = (size_t)resident * 4u;
     return (int)(b < cap ? b : cap);
   };
-  if (log2n & 1u) {
-    hipLaunchKernelGGL((scn_gen_stage_kernel<2>), dim3(blocks_for((size_t)a.n / 2 * a.n_buffers)), dim3(256), 0, s, a, src, dst, log2ns);
+  // forward transform of length m from `from`, ping-ponging with the other work buffer; returns where the result is:
+  // one radix-2 stage first when log2 m is odd, radix 4 from there on
+  auto transform = [&](v2f *from, v2f *other) -> v2f * {
+    v2f *src = from, *dst = other;
+    uint32_t log2ns = 0;
+    if (a.log2m & 1u) {
+      hipLaunchKernelGGL((scn_gen_stage_kernel<2>), dim3(blocks_for((size_t)a.m / 2 * a.n_buffers)), dim3(256), 0, s, a, src, dst, log2ns);
+      log2ns += 1;
+      std::swap(src, dst);
+    }
+    while (log2ns < a.log2m) {
+      hipLaunchKernelGGL((scn_gen_stage_kernel<4>), dim3(blocks_for((size_t)a.m / 4 * a.n_buffers)), dim3(256), 0, s, a, src, dst, log2ns);
+      log2ns += 2;
+      std::swap(src, dst);
+    }
+    return src;
+  };
+  v2f *spec = transform(a.work0, a.work1);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (a.chirp) {  // Bluestein: multiply by the filter's transform, conjugate, transform again
+    hipLaunchKernelGGL(scn_gen_pointwise_kernel, dim3(blocks_for((size_t)a.m * a.n_buffers)), dim3(256), 0, s, a, spec);
+    spec = transform(spec, spec == a.work0 ? a.work1 : a.work0);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    log2ns += 1;
-    const v2f *t = dst;
-    dst = const_cast<v2f *>(src);
-    src = t;
-  }
-  while (log2ns < log2n) {
-    hipLaunchKernelGGL((scn_gen_stage_kernel<4>), dim3(blocks_for((size_t)a.n / 4 * a.n_buffers)), dim3(256), 0, s, a, src, dst, log2ns);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    log2ns += 2;
-    const v2f *t = dst;
-    dst = const_cast<v2f *>(src);
-    src = t;
   }
   const int fin = blocks_for((size_t)a.n * a.n_buffers);
-  if (hits) hipLaunchKernelGGL((scn_gen_finish_kernel<true>), dim3(fin), dim3(256), 0, s, a, src);
-  else hipLaunchKernelGGL((scn_gen_finish_kernel<false>), dim3(fin), dim3(256), 0, s, a, src);
+  const bool pow2 = a.chirp == nullptr;
+  if (hits && pow2) hipLaunchKernelGGL((scn_gen_finish_kernel<true, true>), dim3(fin), dim3(256), 0, s, a, spec);
+  else if (hits) hipLaunchKernelGGL((scn_gen_finish_kernel<true, false>), dim3(fin), dim3(256), 0, s, a, spec);
+  else if (pow2) hipLaunchKernelGGL((scn_gen_finish_kernel<false, true>), dim3(fin), dim3(256), 0, s, a, spec);
+  else hipLaunchKernelGGL((scn_gen_finish_kernel<false, false>), dim3(fin), dim3(256), 0, s, a, spec);
   return hipGetLastError();
 }

@@ -109,10 +109,13 @@ hipError_t scn_launch_hit_compact(const ScnCompactArgs &args, hipStream_t stream
 struct ScnGenericArgs {
   const void *raw;            // n_buffers raw buffers back to back
   const float *window;        // [n]
-  const scn_v2f *twiddle;     // W_n^m, m in [0, n)
-  scn_v2f *work0, *work1;     // [n_buffers][n] complex each: ping-pong between the stages
+  const scn_v2f *twiddle;     // W_m^k, k in [0, m): the table of the TRANSFORM length
+  scn_v2f *work0, *work1;     // [n_buffers][m] complex each: ping-pong between the stages
   float *power_db;            // [n_buffers][n] or nullptr
-  uint32_t n, log2n, n_buffers;
+  uint32_t n, n_buffers;      // buffer length (samples, bins)
+  uint32_t m, log2m;          // transform length: n for a power of two, the power of two >= 2n - 1 for Bluestein
+  const scn_v2f *chirp;       // Bluestein only: w[i] = exp(-i pi i^2 / n), i < n;  nullptr for the powers of two
+  const scn_v2f *bfilter;     // Bluestein only: FFT_m of the chirp filter, scaled by 1/m
   float scale, threshold;
   uint32_t dc_ignore, i_lo, i_hi;
   ScnDevHit *hits;            // [n_buffers][hit_region]
@@ -120,7 +123,8 @@ struct ScnGenericArgs {
   uint32_t *per_buffer_hits;  // [n_buffers], zeroed by the launcher
 };
 hipError_t scn_launch_generic(int kind, bool correct_dc, bool hits, const ScnGenericArgs &args, int num_cus, hipStream_t stream);
-bool scn_generic_size_supported(uint32_t n);
+bool scn_generic_size_supported(uint32_t n);    // powers of two, 16 ... 65536
+bool scn_bluestein_size_supported(uint32_t n);  // everything else from 16 to 32768
 
 // K1 alone (capture path)
 hipError_t scn_launch_convert(int kind, bool correct_dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers,

@@ -64,14 +64,14 @@ def run(budget, seed):
     cases = launches = 0
     near_misses.clear()
     while time.time() < t_end:
-        n = int(rng.choice([1024, 2048, 4096, 8192, 16384, 512, 32768]))   # the last two: the staged path for sizes without a fused kernel
+        n = int(rng.choice([1024, 2048, 4096, 8192, 16384, 512, 32768, 1000]))   # the last three: the staged path (1000: Bluestein)
         kind = int(rng.choice(kinds))
         enob = 8 if kind == capi.KIND_BYTE_COMPLEX else int(rng.choice([12, 12, 14, 16, 10]))
         dc = bool(rng.integers(0, 2)) and kind != capi.KIND_FLOAT_COMPLEX
         thr = float(rng.choice([6.0, 9.5, 12.0, 20.0, -5.0]))
         out_flags = int(rng.choice([3, 3, 1, 2]))
         flags = out_flags | (capi.PLAN_OVERLAP_SLOTS if rng.integers(0, 2) else 0)
-        max_nb = int(rng.choice([3, 64, 700, 1300, 2600])) if n <= 4096 else int(rng.choice([3, 64, 600, 1100])) if n == 8192 else int(rng.choice([3, 64, 300, 520])) if n == 16384 else int(rng.choice([3, 40, 130])) if n == 32768 else int(rng.choice([3, 64, 700, 2600]))
+        max_nb = int(rng.choice([3, 40, 150])) if n == 1000 else int(rng.choice([3, 64, 700, 1300, 2600])) if n <= 4096 else int(rng.choice([3, 64, 600, 1100])) if n == 8192 else int(rng.choice([3, 64, 300, 520])) if n == 16384 else int(rng.choice([3, 40, 130])) if n == 32768 else int(rng.choice([3, 64, 700, 2600]))
         if rng.random() < 0.15:   # time-domain mode (process.cpp:203-237): a few small launches against the oracle
             time_domain_case(rng, n, kind, enob, dc)
             cases += 1

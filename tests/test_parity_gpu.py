@@ -304,6 +304,32 @@ def test_generic_sizes_vs_oracle(torch_cuda, oracle_mod, n, kind, enob, dc):
     assert np.array_equal(t, t_ref)
 
 
+@pytest.mark.parametrize("n,kind,enob,dc", [
+    (30, capi.KIND_FLOAT_COMPLEX, 12, False), (1000, capi.KIND_SHORT_COMPLEX, 12, True), (1023, capi.KIND_FLOAT_COMPLEX, 12, False),
+    (3000, capi.KIND_BYTE_COMPLEX, 8, False), (4097, capi.KIND_SHORT, 12, True), (6000, capi.KIND_FLOAT_COMPLEX, 12, False),
+])
+def test_non_power_of_two_sizes_vs_oracle(torch_cuda, oracle_mod, n, kind, enob, dc):
+    """--count is any integer in the reference (FFTW plans it, fft.cpp:4-11).  Sizes that are not powers of two run
+    Bluestein's algorithm over the staged path; the oracle evaluates the DFT sum itself in double for them.  Odd sizes
+    exercise the general form of the mask: j = (i + N/2) % N with an integer N/2 (process.cpp:45-47)."""
+    nb = 24
+    x = synth.cfloat_batch(n, nb, seed=80 + n % 1000, sigma=0.1)
+    raw = synth.quantize(x, kind) if kind != capi.KIND_FLOAT_COMPLEX else x
+    if dc:
+        info = np.iinfo(raw.dtype)
+        raw = np.clip(raw.astype(np.int32) + 21, info.min, info.max).astype(raw.dtype)   # (a positive mean: the negative-sum quirk
+        # turns a buffer into one huge constant plus cancellation residue -- test_dc_quirk_negative_mean covers it where it belongs)
+    fc = 915e6 + 6e6 * np.arange(nb)
+    p_ref, _, _ = oracle_mod.Oracle(n, FS, 1e9, kind=kind, enob=enob, correct_dc=dc).run(raw, threads=4)
+    ev = tol.evaluated_mask(n)
+    thr = tol.pick_threshold(p_ref, n, start=float(np.quantile(p_ref[:, ev][np.isfinite(p_ref[:, ev])], 0.97)))
+    (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, kind, raw, fc, None, thr, enob, dc, max_hits=nb * n)
+    print(n, tol.compare_spectra(p, p_ref))
+    assert len(h_ref) > 0
+    _assert_hits_equal(h, h_ref)
+    assert np.array_equal(t, t_ref)
+
+
 def test_generic_size_double_buffered_and_windows(torch_cuda, oracle_mod):
     """Both slots in flight at a generic size, every evaluated bin a hit (the region / compaction capacity at 65536 points:
     49 145 evaluated bins per buffer, a 2048-word bitmap per wave), the list walked in windows."""

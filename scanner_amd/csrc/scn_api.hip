@@ -58,7 +58,7 @@ namespace {
   } while (0)
 
 struct Slot {
-  scn_v2f *d_gen_work[2] = {nullptr, nullptr};  // generic sizes only: [max_batch][n] complex ping-pong between the stages
+  void *d_gen_work[2] = {nullptr, nullptr};  // staged sizes only: double[max_batch][fft_m][2], ping-pong between the stages
   void *h_raw = nullptr;            // pinned staging, max_batch raw buffers
   void *d_raw = nullptr;            // device copy of the staging slot
   float *d_power = nullptr;         // [max_batch][N] dB spectra (plan-owned destination)
@@ -130,8 +130,9 @@ struct scn_plan {
   // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
   bool generic = false;  // no fused kernel for this size: the staged path of scn_generic.hip
   uint32_t fft_m = 0, log2m = 0;     // ... and its transform length: n for a power of two, >= 2n - 1 for Bluestein
-  scn_v2f *d_chirp = nullptr;        // Bluestein: w[i] = exp(-i pi i^2 / n)
-  scn_v2f *d_bfilter = nullptr;      // Bluestein: FFT_m of the chirp filter / m
+  double *d_twiddle64 = nullptr;     // [fft_m][2]: W_m^k in double (the staged path applies its tables in double)
+  double *d_chirp = nullptr;         // Bluestein: [n][2], w[i] = exp(-i pi i^2 / n)
+  double *d_bfilter = nullptr;       // Bluestein: [fft_m][2], FFT_m of the chirp filter / m
   bool direct_counts = false;
   int stop_event_in_packet = -1;  // -1: by launch size (see submit_common); 0 / 1: experiment knob SCN_EXP_STOP_EVENT
   int fft_cus = 0;  // CUs the FFT launch is sized for (num_cus unless SCN_EXP_RESERVE_CUS leaves some to the side stream)
@@ -392,11 +393,11 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
                          (p->stop_event_in_packet < 0 ? (uint64_t)nb * n >= (1u << 25) : p->stop_event_in_packet != 0);
   if (p->generic) {
     for (int g = 0; g < 2 && nb; g++)
-      if (!s.d_gen_work[g]) SCN_HIP(hipMalloc(&s.d_gen_work[g], sizeof(scn_v2f) * (size_t)p->fft_m * p->d.max_batch));
+      if (!s.d_gen_work[g]) SCN_HIP(hipMalloc(&s.d_gen_work[g], 2u * sizeof(double) * (size_t)p->fft_m * p->d.max_batch));
     ScnGenericArgs ga;
     ga.raw = d_raw;
     ga.window = p->d_window;
-    ga.twiddle = p->d_twiddle;
+    ga.twiddle = p->d_twiddle64;
     ga.work0 = s.d_gen_work[0];
     ga.work1 = s.d_gen_work[1];
     ga.power_db = d_power;
@@ -607,7 +608,17 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     }
     SCN_TRY(hipMemcpyAsync(p->d_window, p->h_window.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, p->stream));
     SCN_TRY(hipMemcpyAsync(p->d_twiddle, tw.data(), sizeof(float) * 2 * tn, hipMemcpyHostToDevice, p->stream));
-    std::vector<float> chirp, bfilter;
+    if (p->generic) {
+      std::vector<double> tw64(2 * (size_t)tn);
+      for (uint32_t m = 0; m < tn; m++) {
+        const double a = -2.0 * pi * (double)m / (double)tn;
+        tw64[2 * m] = std::cos(a);
+        tw64[2 * m + 1] = std::sin(a);
+      }
+      SCN_TRY(hipMalloc(&p->d_twiddle64, sizeof(double) * tw64.size()));
+      SCN_TRY(hipMemcpy(p->d_twiddle64, tw64.data(), sizeof(double) * tw64.size(), hipMemcpyHostToDevice));
+    }
+    std::vector<double> chirp, bfilter;
     if (blue) {
       // w[i] = exp(-i pi i^2 / n) with i^2 reduced mod 2n in integers; the filter b[k] = conj(w[|k|]) laid out cyclically over
       // tn points, transformed here in double (tn <= 65536) and scaled by 1/tn (the second device transform is an inverse
@@ -616,8 +627,8 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
       std::vector<double> br(tn, 0.0), bi(tn, 0.0);
       for (uint32_t i = 0; i < d.n; i++) {
         const double a = -pi * (double)(((uint64_t)i * i) % (2ull * d.n)) / (double)d.n;
-        chirp[2 * i] = (float)std::cos(a);
-        chirp[2 * i + 1] = (float)std::sin(a);
+        chirp[2 * i] = std::cos(a);
+        chirp[2 * i + 1] = std::sin(a);
         br[i] = std::cos(a);
         bi[i] = -std::sin(a);
         if (i) {
@@ -628,13 +639,13 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
       host_fft(br, bi);
       bfilter.resize(2 * (size_t)tn);
       for (uint32_t k = 0; k < tn; k++) {
-        bfilter[2 * k] = (float)(br[k] / (double)tn);
-        bfilter[2 * k + 1] = (float)(bi[k] / (double)tn);
+        bfilter[2 * k] = br[k] / (double)tn;
+        bfilter[2 * k + 1] = bi[k] / (double)tn;
       }
-      SCN_TRY(hipMalloc(&p->d_chirp, sizeof(float) * chirp.size()));
-      SCN_TRY(hipMalloc(&p->d_bfilter, sizeof(float) * bfilter.size()));
-      SCN_TRY(hipMemcpyAsync(p->d_chirp, chirp.data(), sizeof(float) * chirp.size(), hipMemcpyHostToDevice, p->stream));
-      SCN_TRY(hipMemcpyAsync(p->d_bfilter, bfilter.data(), sizeof(float) * bfilter.size(), hipMemcpyHostToDevice, p->stream));
+      SCN_TRY(hipMalloc(&p->d_chirp, sizeof(double) * chirp.size()));
+      SCN_TRY(hipMalloc(&p->d_bfilter, sizeof(double) * bfilter.size()));
+      SCN_TRY(hipMemcpy(p->d_chirp, chirp.data(), sizeof(double) * chirp.size(), hipMemcpyHostToDevice));
+      SCN_TRY(hipMemcpy(p->d_bfilter, bfilter.data(), sizeof(double) * bfilter.size(), hipMemcpyHostToDevice));
     }
     // the same values, regrouped per thread of the fused kernel: entry (p-1, t) = W_n^(t p), t < n/16
     const uint32_t nthreads = p->generic ? 1u : d.n / 16;  // (only the fused kernels read it)
@@ -672,6 +683,7 @@ int scn_plan_destroy(scn_plan *p) {
   for (int i = 0; i < SCN_NUM_SLOTS; i++) free_slot(p->slot[i]);
   if (p->d_window) (void)hipFree(p->d_window);
   if (p->d_twiddle) (void)hipFree(p->d_twiddle);
+  if (p->d_twiddle64) (void)hipFree(p->d_twiddle64);
   if (p->d_chirp) (void)hipFree(p->d_chirp);
   if (p->d_bfilter) (void)hipFree(p->d_bfilter);
   if (p->d_tw1_table) (void)hipFree(p->d_tw1_table);

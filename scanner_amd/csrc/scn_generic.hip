@@ -16,10 +16,10 @@
 // multiply by the precomputed FFT_M of the chirp filter (scaled by 1/M) and conjugate -> FFT_M again (an inverse transform
 // up to a conjugation) -> finish.  The final w[k] and the conjugation have modulus one and never reach the dB value.
 //
-// Same arithmetic and the same outputs as the fused path (spectrum, per-buffer counts, unordered regions that
-// scn_hits.hip orders), at 2 + log_4 N passes over the data instead of one: a correctness path for unusual sizes, not a
-// fast one -- each kernel is a plain streaming kernel (coalesced reads; the stage writes are strided by the sub-transform
-// length).  Twiddles come from the plan's W_N table.
+// The same outputs as the fused path (spectrum, per-buffer counts, unordered regions that scn_hits.hip orders), at
+// 2 + log_4 N passes over the data instead of one, in double between input and spectrum: a correctness path for unusual
+// sizes, not a fast one -- each kernel is a plain streaming kernel (coalesced reads; the stage writes are strided by the
+// sub-transform length).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,6 +29,30 @@
 #include "scn_kernels.h"
 
 namespace {
+
+// Everything between the windowed input and the final spectrum is DOUBLE: the work buffers, the twiddle / chirp / filter
+// tables and the butterflies; the spectrum is rounded to float once, in the finish kernel -- the accuracy class of the
+// oracle's default mode (and of FFTW's float transform, which it stands in for).  The first version kept float work
+// buffers: eight stages then round a strong tone's partial sums to float eight times (the fused kernels: three), and a
+// buffer with peak/mean power 8e3 at 32768 points read 1.0e-5 .. 1.2e-5 on bins near the mean -- AT the parity bar.  This
+// is the correctness path for unusual sizes; it is bound by its HBM passes, and it pays for the wider ones.
+typedef double scn_v2d __attribute__((ext_vector_type(2)));
+struct cd {
+  double x, y;
+};
+__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd from_v2d(scn_v2d v) { return cd{v.x, v.y}; }
+__device__ __forceinline__ scn_v2d to_v2d(cd c) { return scn_v2d{c.x, c.y}; }
+__device__ __forceinline__ cd cmul_d(cd a, scn_v2d w) { return cd{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+// DFT4 with W4 = -i, results left in (x0, x1, x2, x3) = (X0, X1, X2, X3)
+__device__ __forceinline__ void radix4_d(cd &x0, cd &x1, cd &x2, cd &x3) {
+  const cd t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = x1 - x3;
+  x0 = t0 + t2;
+  x2 = t0 - t2;
+  x1 = cd{t1.x + t3.y, t1.y - t3.x};  // t1 - i*t3
+  x3 = cd{t1.x - t3.y, t1.y + t3.x};  // t1 + i*t3
+}
 
 template <int KIND>
 struct GenRaw;
@@ -110,26 +134,33 @@ __global__ __launch_bounds__(256) void scn_gen_load_kernel(ScnGenericArgs a) {
       dc_re = (int)((uint32_t)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) / n);  // int32 /= uint32, utility.cpp:77-78
       dc_im = (int)((uint32_t)(s_sum[4] + s_sum[5] + s_sum[6] + s_sum[7]) / n);
     }
-    v2f *out = a.work0 + (size_t)b * a.m;
-    // float(s - dc)*onebymax*w and float(s - dc)*(onebymax*w) round identically (onebymax is +-2^-k), as in the fused kernels
+    scn_v2d *out = static_cast<scn_v2d *>(a.work0) + (size_t)b * a.m;
+    // the windowed sample is a FLOAT product, as in the reference (process.cpp:28-34 multiplies floats) and in the fused
+    // kernels: float(s - dc)*onebymax*w and float(s - dc)*(onebymax*w) round identically (onebymax is +-2^-k)
     if (a.chirp) {  // Bluestein: times the chirp, zero-padded to the convolution length
       for (uint32_t i = t; i < a.m; i += 256u) {
-        cf v = cf{0.0f, 0.0f};
-        if (i < n) v = cmul(L::conv(buf, n, i, dc_re, dc_im, 1.0f) * (a.window[i] * a.scale), from_v2f(a.chirp[i]));
-        out[i] = to_v2f(v);
+        cd v = cd{0.0, 0.0};
+        if (i < n) {
+          const cf x = L::conv(buf, n, i, dc_re, dc_im, 1.0f) * (a.window[i] * a.scale);
+          v = cmul_d(cd{(double)x.x, (double)x.y}, static_cast<const scn_v2d *>(a.chirp)[i]);
+        }
+        out[i] = to_v2d(v);
       }
     } else {
-      for (uint32_t i = t; i < n; i += 256u) out[i] = to_v2f(L::conv(buf, n, i, dc_re, dc_im, 1.0f) * (a.window[i] * a.scale));
+      for (uint32_t i = t; i < n; i += 256u) {
+        const cf x = L::conv(buf, n, i, dc_re, dc_im, 1.0f) * (a.window[i] * a.scale);
+        out[i] = scn_v2d{(double)x.x, (double)x.y};
+      }
     }
   }
 }
 
 // Bluestein, between the two transforms: y = conj(x * B'), B' = FFT_M(chirp filter) / M
-__global__ __launch_bounds__(256) void scn_gen_pointwise_kernel(ScnGenericArgs a, v2f *__restrict__ x) {
+__global__ __launch_bounds__(256) void scn_gen_pointwise_kernel(ScnGenericArgs a, scn_v2d *__restrict__ x) {
   const size_t total = (size_t)a.n_buffers << a.log2m;
   for (size_t g = (size_t)blockIdx.x * 256u + threadIdx.x; g < total; g += (size_t)gridDim.x * 256u) {
-    const cf y = cmul(from_v2f(x[g]), from_v2f(a.bfilter[(uint32_t)g & (a.m - 1u)]));
-    x[g] = v2f{y.x, -y.y};
+    const cd y = cmul_d(from_v2d(x[g]), static_cast<const scn_v2d *>(a.bfilter)[(uint32_t)g & (a.m - 1u)]);
+    x[g] = scn_v2d{y.x, -y.y};
   }
 }
 
@@ -138,7 +169,7 @@ __global__ __launch_bounds__(256) void scn_gen_pointwise_kernel(ScnGenericArgs a
 // does the R-point DFT and writes y[(j / Ns) R Ns + (j mod Ns) + r Ns].  Ns = 1, R, R^2, ... : natural order in, natural
 // order out after the last stage.
 template <int R>
-__global__ __launch_bounds__(256) void scn_gen_stage_kernel(ScnGenericArgs a, const v2f *__restrict__ src, v2f *__restrict__ dst,
+__global__ __launch_bounds__(256) void scn_gen_stage_kernel(ScnGenericArgs a, const scn_v2d *__restrict__ src, scn_v2d *__restrict__ dst,
                                                             uint32_t log2ns) {
   // every quantity is a power of two: shifts and masks, no integer division (the first version divided: 10 ms per
   // 512 x 65536-point batch instead of ~2)
@@ -147,34 +178,35 @@ __global__ __launch_bounds__(256) void scn_gen_stage_kernel(ScnGenericArgs a, co
   const size_t total = (size_t)a.n_buffers << log2per;
   for (size_t g = (size_t)blockIdx.x * 256u + threadIdx.x; g < total; g += (size_t)gridDim.x * 256u) {
     const uint32_t b = (uint32_t)(g >> log2per), j = (uint32_t)g & (per - 1u);
-    const v2f *x = src + ((size_t)b << log2n);
-    v2f *y = dst + ((size_t)b << log2n);
+    const scn_v2d *x = src + ((size_t)b << log2n);
+    scn_v2d *y = dst + ((size_t)b << log2n);
     const uint32_t k = j & (ns - 1u);
     const uint32_t step = n >> (LR + log2ns);  // twiddle index stride in the W_N table
     const uint32_t j0 = ((j >> log2ns) << (log2ns + LR)) + k;
     if (R == 4) {
-      cf v0 = from_v2f(x[j]), v1 = from_v2f(x[j + per]), v2 = from_v2f(x[j + 2 * per]), v3 = from_v2f(x[j + 3 * per]);
+      cd v0 = from_v2d(x[j]), v1 = from_v2d(x[j + per]), v2 = from_v2d(x[j + 2 * per]), v3 = from_v2d(x[j + 3 * per]);
       if (k) {
-        v1 = cmul(v1, from_v2f(a.twiddle[k * step]));
-        v2 = cmul(v2, from_v2f(a.twiddle[2 * k * step]));
-        v3 = cmul(v3, from_v2f(a.twiddle[3 * k * step]));
+        const scn_v2d *tw = static_cast<const scn_v2d *>(a.twiddle);
+        v1 = cmul_d(v1, tw[k * step]);
+        v2 = cmul_d(v2, tw[2 * k * step]);
+        v3 = cmul_d(v3, tw[3 * k * step]);
       }
-      radix4(v0, v1, v2, v3);
-      y[j0] = to_v2f(v0);
-      y[j0 + ns] = to_v2f(v1);
-      y[j0 + 2 * ns] = to_v2f(v2);
-      y[j0 + 3 * ns] = to_v2f(v3);
+      radix4_d(v0, v1, v2, v3);
+      y[j0] = to_v2d(v0);
+      y[j0 + ns] = to_v2d(v1);
+      y[j0 + 2 * ns] = to_v2d(v2);
+      y[j0 + 3 * ns] = to_v2d(v3);
     } else {
-      cf v0 = from_v2f(x[j]), v1 = from_v2f(x[j + per]);
-      if (k) v1 = cmul(v1, from_v2f(a.twiddle[k * step]));
-      y[j0] = to_v2f(v0 + v1);
-      y[j0 + ns] = to_v2f(v0 - v1);
+      cd v0 = from_v2d(x[j]), v1 = from_v2d(x[j + per]);
+      if (k) v1 = cmul_d(v1, static_cast<const scn_v2d *>(a.twiddle)[k * step]);
+      y[j0] = to_v2d(v0 + v1);
+      y[j0 + ns] = to_v2d(v0 - v1);
     }
   }
 }
 
 template <bool HITS, bool POW2>
-__global__ __launch_bounds__(256) void scn_gen_finish_kernel(ScnGenericArgs a, const v2f *__restrict__ spec) {
+__global__ __launch_bounds__(256) void scn_gen_finish_kernel(ScnGenericArgs a, const scn_v2d *__restrict__ spec) {
   const uint32_t n = a.n;
   const size_t total = (size_t)a.n_buffers * n;
   for (size_t g = (size_t)blockIdx.x * 256u + threadIdx.x; g < total; g += (size_t)gridDim.x * 256u) {
@@ -186,7 +218,8 @@ __global__ __launch_bounds__(256) void scn_gen_finish_kernel(ScnGenericArgs a, c
       b = (uint32_t)(g / n);
       j = (uint32_t)(g - (size_t)b * n);
     }
-    const float d = power_db(from_v2f(spec[((size_t)b << a.log2m) + j]));  // rows are m long (= n for the powers of two)
+    const scn_v2d X = spec[((size_t)b << a.log2m) + j];  // rows are m long (= n for the powers of two)
+    const float d = power_db(cf{(float)X.x, (float)X.y});  // the spectrum in float (fft.cpp:20-25 delivers floats), then utility.cpp:86-98
     if (a.power_db) a.power_db[g] = d;
     if (HITS) {
       const uint32_t i = POW2 ? (j + n / 2u) & (n - 1u) : (j + n - n / 2u) % n;  // the i with (i + N/2) % N == j, process.cpp:47
@@ -250,8 +283,8 @@ hipError_t scn_launch_generic(int kind, bool dc, bool hits, const ScnGenericArgs
   };
   // forward transform of length m from `from`, ping-ponging with the other work buffer; returns where the result is:
   // one radix-2 stage first when log2 m is odd, radix 4 from there on
-  auto transform = [&](v2f *from, v2f *other) -> v2f * {
-    v2f *src = from, *dst = other;
+  auto transform = [&](scn_v2d *from, scn_v2d *other) -> scn_v2d * {
+    scn_v2d *src = from, *dst = other;
     uint32_t log2ns = 0;
     if (a.log2m & 1u) {
       hipLaunchKernelGGL((scn_gen_stage_kernel<2>), dim3(blocks_for((size_t)a.m / 2 * a.n_buffers)), dim3(256), 0, s, a, src, dst, log2ns);
@@ -265,11 +298,12 @@ hipError_t scn_launch_generic(int kind, bool dc, bool hits, const ScnGenericArgs
     }
     return src;
   };
-  v2f *spec = transform(a.work0, a.work1);
+  scn_v2d *const w0 = static_cast<scn_v2d *>(a.work0), *const w1 = static_cast<scn_v2d *>(a.work1);
+  scn_v2d *spec = transform(w0, w1);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (a.chirp) {  // Bluestein: multiply by the filter's transform, conjugate, transform again
     hipLaunchKernelGGL(scn_gen_pointwise_kernel, dim3(blocks_for((size_t)a.m * a.n_buffers)), dim3(256), 0, s, a, spec);
-    spec = transform(spec, spec == a.work0 ? a.work1 : a.work0);
+    spec = transform(spec, spec == w0 ? w1 : w0);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   const int fin = blocks_for((size_t)a.n * a.n_buffers);

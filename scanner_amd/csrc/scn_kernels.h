@@ -109,13 +109,13 @@ hipError_t scn_launch_hit_compact(const ScnCompactArgs &args, hipStream_t stream
 struct ScnGenericArgs {
   const void *raw;            // n_buffers raw buffers back to back
   const float *window;        // [n]
-  const scn_v2f *twiddle;     // W_m^k, k in [0, m): the table of the TRANSFORM length
-  scn_v2f *work0, *work1;     // [n_buffers][m] complex each: ping-pong between the stages
+  const void *twiddle;        // double[m][2]: W_m^k, k in [0, m): the table of the TRANSFORM length, in double
+  void *work0, *work1;        // double[n_buffers][m][2] each: ping-pong between the stages
   float *power_db;            // [n_buffers][n] or nullptr
   uint32_t n, n_buffers;      // buffer length (samples, bins)
   uint32_t m, log2m;          // transform length: n for a power of two, the power of two >= 2n - 1 for Bluestein
-  const scn_v2f *chirp;       // Bluestein only: w[i] = exp(-i pi i^2 / n), i < n;  nullptr for the powers of two
-  const scn_v2f *bfilter;     // Bluestein only: FFT_m of the chirp filter, scaled by 1/m
+  const void *chirp;          // Bluestein only: double[n][2], w[i] = exp(-i pi i^2 / n);  nullptr for the powers of two
+  const void *bfilter;        // Bluestein only: double[m][2], FFT_m of the chirp filter, scaled by 1/m
   float scale, threshold;
   uint32_t dc_ignore, i_lo, i_hi;
   ScnDevHit *hits;            // [n_buffers][hit_region]

@@ -230,6 +230,9 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
+GATHER_DEADLINE_S = 120
+
+
 def emit(obj):
     line = (json.dumps(obj) + "\n").encode()
     if _RESULT_FD is None:
@@ -581,18 +584,39 @@ def main():
     hits = np.concatenate(parts) if len(parts) > 1 else parts[0]
     gather_info = {"transport": "none (1 rank)"}
     all_hits, per_rank = hits, np.array([len(hits)])
+    stuck = False
     if use_dist:
-        try:
-            with sweep.HitGather(dev) as g:
-                all_hits, per_rank = g.gather(hits)
-            gather_info = {"transport": "scn_gather_hits (RCCL: ncclAllGather counts + grouped ncclSend/ncclRecv to rank 0)"}
-        except Exception as e:  # the line must survive a transport problem: say so and use the launcher's process group
-            from scanner_amd.sweep import HitGather
+        # The gather runs on a helper thread with a deadline: this is the one place where ranks exchange data through a
+        # library the launcher did not set up, and a rank that never arrives must cost the line one field, not the run.
+        import threading
 
-            fb = HitGather(None)
+        res = {}
+
+        def gather_job():
+            try:
+                with sweep.HitGather(dev) as g:
+                    res["hits"], res["per_rank"] = g.gather(hits)
+                res["info"] = {"transport": "scn_gather_hits (RCCL: ncclAllGather counts + grouped ncclSend/ncclRecv to rank 0)"}
+            except Exception as e:
+                res["error"] = str(e)[:300]
+
+        th = threading.Thread(target=gather_job, daemon=True)
+        th.start()
+        th.join(GATHER_DEADLINE_S)
+        stuck = th.is_alive()
+        # every rank takes the same branch: the fallback is a collective too
+        flag = torch.tensor([0 if (stuck or "error" in res) else 1], dtype=torch.int32, device=dev)
+        if not stuck:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if stuck:
+            gather_info = {"transport": f"scn_gather_hits did not return within {GATHER_DEADLINE_S} s on rank {rank}; local hits only"}
+        elif int(flag.item()) == 1:
+            all_hits, per_rank, gather_info = res["hits"], res["per_rank"], res["info"]
+        else:  # say so and use the launcher's process group
+            fb = sweep.HitGather(None)
             fb.device = dev
             all_hits, per_rank = fb._gather_torch(np.ascontiguousarray(hits, dtype=capi.HIT_DTYPE), 0)
-            gather_info = {"transport": "torch.distributed fallback", "scn_gather_hits_error": str(e)[:300]}
+            gather_info = {"transport": "torch.distributed fallback", "scn_gather_hits_error": res.get("error", "failed on another rank")}
     gather_ms = (time.perf_counter() - tg0) * 1e3
     if rank == 0:
         sid = all_hits["seq_id"].astype(np.int64)
@@ -680,6 +704,9 @@ def main():
         emit(out)
     else:
         rc = 0
+    if stuck:  # a thread is still inside the collective: the line is out, leave without the teardown that would wait for it
+        sys.stdout.flush()
+        os._exit(rc or 4)
     plan.close()
     if use_dist:
         dist.barrier()

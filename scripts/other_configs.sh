@@ -19,6 +19,9 @@ run --n 4096 --batch 2048
 run --config c4
 run --n 16384 --batch 2048
 run --n 16384 --batch 2048 --kind int16
+run --n 512 --batch 16384 --steps 20 --warmup 3     # the staged path: a power of two without a fused kernel
+run --n 32768 --batch 256 --steps 20 --warmup 3
+run --n 1000 --batch 4096 --steps 20 --warmup 3      # Bluestein
 run --welch --welch-psd 32 --steps 100 --warmup 10
 run --welch --welch-psd 8 --welch-pinned --steps 20 --warmup 3
 python3 - <<PY

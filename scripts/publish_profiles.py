@@ -1,0 +1,34 @@
+"""Copy one round's profiling evidence from gpurun_out/ (scratch) into profiles/ (tracked):
+   python scripts/publish_profiles.py r02
+summary.txt -> profiles/<tag>_<shape>_rocprofv3_summary.txt, kernel_stats.csv beside it, and the per-shape PMC
+traffic / kernel averages into profiles/measured_shapes.json (what bench.py reads for roofline.traffic)."""
+import json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+shapes_path = os.path.join(ROOT, "profiles", "measured_shapes.json")
+shapes = json.load(open(shapes_path)) if os.path.exists(shapes_path) else {}
+for shape in ("c2", "c3", "c4shape", "c5"):
+    d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{shape}")
+    if not os.path.exists(os.path.join(d, "summary.txt")):
+        print("missing", d)
+        continue
+    shutil.copy(os.path.join(d, "summary.txt"), os.path.join(ROOT, "profiles", f"{tag}_{shape}_rocprofv3_summary.txt"))
+    shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_{shape}_kernel_stats.csv"))
+    t = json.load(open(os.path.join(d, "pmc_traffic.json")))
+    welch = t.get("segments_per_psd") is not None
+    key = (f"welch/{t['n']}/{t['segments_per_psd']}/{t['psd_per_submit']}" if welch
+           else f"{t['n']}/{t['sample_kind']}/{t['buffers_per_launch']}")
+    entry = {("hbm_bytes_per_step" if welch else "hbm_bytes_per_launch"): int(round(t["hbm_bytes_per_launch"])),
+             "read_bytes": int(round(t["read_bytes"])), "write_bytes": int(round(t["write_bytes"])),
+             "kernel_avg_us": round(t["kernel_avg_us"], 3), "kernels": t["kernels"],
+             "source": f"profiles/{tag}_{shape}_rocprofv3_summary.txt",
+             "method": t["method"] + ("; summed over the kernels of one step" if welch else "")}
+    shapes[key] = entry
+    print(key, entry["kernel_avg_us"], "us")
+json.dump(shapes, open(shapes_path, "w"), indent=1)
+for src, dst in ((f"configs_{tag}.jsonl", f"{tag}_other_configs.jsonl"), (f"other_{tag}.txt", f"{tag}_other_configs.txt"),
+                 (f"bench_{tag}_final.json", f"{tag}_bench_line.json")):
+    p = os.path.join(ROOT, "gpurun_out", src)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(ROOT, "profiles", dst))

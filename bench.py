@@ -425,7 +425,9 @@ def main():
     raw = raws[0]
     torch.cuda.synchronize()
 
-    hit_cap = nb * max(64, n // 64)  # records the plan keeps per slot / the caller's buffer: ample for this input
+    # records the plan keeps per slot / the caller's buffer: ample for this input.  The threshold is an absolute dB figure and
+    # the noise floor of a bin grows with N, so beyond the fused sizes a tenth of the bins cross 10 dB
+    hit_cap = nb * (max(64, n // 64) if n <= 16384 else n // 8)
     plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank)
     ext = torch.cuda.ExternalStream(plan.stream_handle, device=dev)
 

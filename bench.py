@@ -205,9 +205,10 @@ def welch_main(args):
                                    f"independent stream per GPU (replicas)",
                        "n": N, "segments_per_psd": K, "psd_per_submit": npsd, "pinned": bool(args.welch_pinned)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("hbm_bytes_per_step"),
                          "kernel": "scn_welch_cols_kernel + scn_welch_rows_kernel (two-pass four-step FFT: the work "
                                    "buffer round trip and the 50% overlap re-read are NOT algorithmic bytes)",
+                         "kernels_avg_us_rocprof": prof.get("kernels"), "traffic_source": prof.get("source"),
                          "algorithmic_bytes_per_launch": algo},
         })
     plan.close()

@@ -14,9 +14,9 @@
 //   kernel B (rows):    one workgroup per tile of 16 rows k1: 16 x 256-pt FFTs over n2, |X|^2
 //                       accumulated in registers over the K segments of one PSD, dB, store
 // Both kernels keep the 4096-pt kernel's shape (256 threads x 16 points, buffer descriptors,
-// conflict-free padded LDS layouts, base + immediate addressing).  Global accesses are 128-byte
-// segments (16 consecutive complex) on both sides of the work buffer, which lives in L2 /
-// Infinity Cache between the two kernels (8 MiB per 16 segments).
+// conflict-free padded LDS layouts, base + immediate addressing).  The work buffer between them is tiled
+// (16 x 16 blocks of 2 KiB) so that both sides move whole blocks; the input stream is read in 128-byte
+// segments (16 consecutive complex).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -26,6 +26,26 @@
 
 #ifndef SCN_WELCH_AUX_IN
 #define SCN_WELCH_AUX_IN 0  // cache policy of the input stream loads (each sample is read by two overlapping segments)
+#endif
+
+#ifndef SCN_EXP_WELCH_NO_ST
+#define SCN_EXP_WELCH_NO_ST 0  // timing experiments only: zero-record descriptors drop the column kernel's stores / loads
+#endif
+#ifndef SCN_EXP_WELCH_NO_LD
+#define SCN_EXP_WELCH_NO_LD 0
+#endif
+#ifndef SCN_WELCH_PF_CUT
+#define SCN_WELCH_PF_CUT 8  // how many of the next segment's 16 loads the column kernel issues before pass 1 (the rest after the barrier)
+#endif
+#ifndef SCN_WELCH_ROWS_WPS
+#define SCN_WELCH_ROWS_WPS 3  // waves per SIMD the row kernel is compiled for
+#endif
+#ifndef SCN_WELCH_AUX_WK_ST
+#define SCN_WELCH_AUX_WK_ST 0  // cache policy of the work-buffer stores (columns) ...
+#endif
+#ifndef SCN_WELCH_AUX_WK_LD
+#define SCN_WELCH_AUX_WK_LD 2  // ... and loads (rows): read once, non-temporal (measured 152 -> 140 us per 32-PSD step; the store policy and
+                               // the input-stream policy change nothing: scripts/welch_variants.sh)
 #endif
 
 namespace {
@@ -56,13 +76,18 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
   v2f *w1 = lds + t;                // + p*WP           (row p, column b*16+c = t)
   v2f *r1 = lds + hi * WP + lo;     // + b*16
   const uint32_t ld_voff = (256u * hi + n2) * 8u;        // + a*16*256*8
-  const uint32_t st_voff = (256u * hi + n2) * 8u;        // k1 = hi + 16q: + q*16*256*8
+  // The work buffer is private to this file, so it is laid out for both of its users: per segment
+  // [row tile i = k1/16][column tile j = n2/16][16 k1][16 n2].  This workgroup's 256 outputs for a fixed q are exactly
+  // block (i = q, j) -- 2 KiB contiguous, thread t at slot t -- and the row kernel reads block (i, j = a) the same
+  // way: every wave instruction on either side moves 512 contiguous bytes (the row-major layout gave 128-byte pieces
+  // 2 KiB apart).
+  const uint32_t st_voff = t * 8u;                        // + (16 q + j) * 2048
 
   // the next segment's 16 samples per thread are fetched while this one is transformed (branch-free: a segment past
   // the end gets a zero-record descriptor)
   auto in_rsrc = [&](uint32_t seg) {
     const bool ok = seg < args.n_segments;
-    return make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)(ok ? seg : 0u) * args.hop * 8u, ok ? WN * 8u : 0u);
+    return make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)(ok ? seg : 0u) * args.hop * 8u, (ok && !SCN_EXP_WELCH_NO_LD) ? WN * 8u : 0u);
   };
   v2f raw[16];
   {
@@ -71,15 +96,15 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
     for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
   }
   for (uint32_t seg = g; seg < args.n_segments; seg += G) {
-    __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)seg * WN * 8u, WN * 8u);
+    __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)seg * WN * 8u + j * 2048u, SCN_EXP_WELCH_NO_ST ? 0u : WN * 8u - j * 2048u);
     cf v[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) v[a] = from_v2f(raw[a]) * win[a];
-    {
-      const __amdgpu_buffer_rsrc_t rn = in_rsrc(seg + G);
+    // the next segment's loads go out in two groups, one per barrier-separated phase (a burst of 16 stalls the wave at
+    // issue when the memory pipeline is backed up: profiles/r01_floors.md)
+    const __amdgpu_buffer_rsrc_t rn = in_rsrc(seg + G);
 #pragma unroll
-      for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
-    }
+    for (int a = 0; a < SCN_WELCH_PF_CUT; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
     fft16(v);
 #pragma unroll
     for (int p = 0; p < 16; p++) {
@@ -90,12 +115,14 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 16]);
+#pragma unroll
+    for (int a = SCN_WELCH_PF_CUT; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
     fft16(v);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       cf y = cmul(v[OUT16(q)], twb[q]);
       typedef unsigned u2 __attribute__((__vector_size__(8)));
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, to_v2f(y)), rwk, st_voff, q * 32768u, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, to_v2f(y)), rwk, st_voff, q * 32768u, SCN_WELCH_AUX_WK_ST);
     }
     __syncthreads();
   }
@@ -108,7 +135,7 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
 // 8 PSDs, two per CU, each walking its K segments one load round trip at a time (the first version: 30 us at
 // 2.3 TB/s of work-buffer reads, half the CUs empty).  Four parts quadruple the waves, and the next segment's
 // values are fetched while the current one is transformed.
-__global__ __launch_bounds__(256, 3) void scn_welch_rows_kernel(ScnWelchArgs args) {
+__global__ __launch_bounds__(256, SCN_WELCH_ROWS_WPS) void scn_welch_rows_kernel(ScnWelchArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
   const uint32_t t = threadIdx.x;
@@ -123,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void scn_welch_rows_kernel(ScnWelchArgs arg
 
   v2f *w1 = lds + hi * WP + lo * 17u;  // + p        (row rho, slot b*17 + p)
   v2f *r1 = lds + hi * WP + lo;        // + b*17
-  const uint32_t ld_voff = (k1 * 256u + lo) * 8u;  // n2 = 16a + b: + a*128
+  const uint32_t ld_voff = t * 8u;  // block (i, j = a) of the tiled work buffer: + (16 i + a) * 2048
 
   float acc[16];
 #pragma unroll
@@ -131,13 +158,14 @@ __global__ __launch_bounds__(256, 3) void scn_welch_rows_kernel(ScnWelchArgs arg
 
   auto wk_rsrc = [&](uint32_t s) {
     const bool ok = s < s_hi;
-    return make_rsrc(reinterpret_cast<const char *>(args.work) + (size_t)(psd * args.k + (ok ? s : s_lo)) * WN * 8u, ok ? WN * 8u : 0u);
+    return make_rsrc(reinterpret_cast<const char *>(args.work) + (size_t)(psd * args.k + (ok ? s : s_lo)) * WN * 8u + i * 32768u,
+                     ok ? WN * 8u - i * 32768u : 0u);
   };
   v2f raw[16];
   {
     const __amdgpu_buffer_rsrc_t r0 = wk_rsrc(s_lo);
 #pragma unroll
-    for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 128u, 0));
+    for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 2048u, SCN_WELCH_AUX_WK_LD));
   }
   for (uint32_t s = s_lo; s < s_hi; s++) {
     cf v[16];
@@ -146,7 +174,7 @@ __global__ __launch_bounds__(256, 3) void scn_welch_rows_kernel(ScnWelchArgs arg
     {
       const __amdgpu_buffer_rsrc_t rn = wk_rsrc(s + 1u);
 #pragma unroll
-      for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 128u, 0));
+      for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 2048u, SCN_WELCH_AUX_WK_LD));
     }
     fft16(v);
 #pragma unroll

@@ -128,12 +128,12 @@ struct scn_plan {
   // host learned the counts late and submitted the launch after next ~10 us late, every other launch).  true: the FFT
   // kernel stores each count to pinned host memory as well (one 4-byte PCIe write per buffer; costs a 4096-point launch
   // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
+  bool direct_counts = false;
   bool generic = false;  // no fused kernel for this size: the staged path of scn_generic.hip
   uint32_t fft_m = 0, log2m = 0;     // ... and its transform length: n for a power of two, >= 2n - 1 for Bluestein
   double *d_twiddle64 = nullptr;     // [fft_m][2]: W_m^k in double (the staged path applies its tables in double)
   double *d_chirp = nullptr;         // Bluestein: [n][2], w[i] = exp(-i pi i^2 / n)
   double *d_bfilter = nullptr;       // Bluestein: [fft_m][2], FFT_m of the chirp filter / m
-  bool direct_counts = false;
   int stop_event_in_packet = -1;  // -1: by launch size (see submit_common); 0 / 1: experiment knob SCN_EXP_STOP_EVENT
   int fft_cus = 0;  // CUs the FFT launch is sized for (num_cus unless SCN_EXP_RESERVE_CUS leaves some to the side stream)
   hipStream_t stream = nullptr;      // compute

@@ -63,6 +63,11 @@ namespace {
                        // input (-> 3 waves per SIMD), 16 for the integer formats; worth 3-4 % on C2.
                        // (A "touch-ahead" of the next buffer into L2/Infinity Cache was measured too: -5 %.)
 #endif
+#ifndef SCN_PF32_INT
+#define SCN_PF32_INT 0  // experiment: register prefetch in the 512-thread 8192-point form for the 4-byte and 2-byte formats (16 registers;
+                       // 13 VGPRs spill at the 128 of four waves per SIMD).  C3 shape, us per step: wide kernel 65.8, 512-thread form 73.9,
+                       // with this prefetch 77.8 (scripts/narrow8k_check.sh)
+#endif
 #ifndef SCN_WAVES_PER_SIMD_PF
 #define SCN_WAVES_PER_SIMD_PF 3  // VGPR budget 168 with the prefetch registers
 #endif
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   typedef Geo<M> G;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
-  constexpr bool PF = G::PREFETCH;
+  constexpr bool PF = G::PREFETCH || (SCN_PF32_INT != 0 && M == 32 && KIND != SCN_K_FLOAT_COMPLEX);
   constexpr bool DYN = scn_uses_queue(KIND, G::N);
   constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
   typedef RawLoader<KIND> L;

@@ -67,6 +67,8 @@ def parse():
                          "per centre, emitters planted at known absolute frequencies, a step = one sweep of the rank's shard, "
                          "the gathered hit list is compared with the computed expectation on rank 0")
     ap.add_argument("--centres", type=int, default=16384, help="c4: number of centre frequencies in the table")
+    ap.add_argument("--no-hits-only-leg", action="store_true", help="skip the extra leg on a plan without SCN_OUT_SPECTRUM")
+    ap.add_argument("--no-copy-ref", action="store_true", help="skip the device-to-device copy measured beside the roofline")
     ap.add_argument("--no-records-leg", action="store_true",
                     help="skip the extra leg that times the same steps with the ordered hit records fetched every step")
     ap.add_argument("--dry-run", action="store_true",
@@ -432,7 +434,7 @@ def main():
     plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank)
     ext = torch.cuda.ExternalStream(plan.stream_handle, device=dev)
 
-    def make_loop(pl, want_records, zero_copy=False):
+    def make_loop(pl, want_records, zero_copy=False, spectrum=True):
         """step(k): one pass over this rank's batch = len(chunks) launches, double-buffered over the plan's two slots; the
         results of a slot are collected right before it is reused (counts + trigger flags; the ordered records too if asked)"""
         pending = [False, False]
@@ -459,7 +461,7 @@ def main():
                 if pending[s]:
                     collect(s)
                 pl.submit_device(s, raws[k % R][lo:hi], hi - lo, fc[lo:hi], seq[lo:hi], sync_producer=False,
-                                 d_power_db=outs[k % R][lo:hi])
+                                 d_power_db=outs[k % R][lo:hi] if spectrum else None)
                 pending[s] = True
 
         def drain():
@@ -509,8 +511,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = tt.tolist()
 
-    def timed_leg(pl, want_records, warm, zero_copy=False):
-        st, dr, state = make_loop(pl, want_records, zero_copy)
+    def timed_leg(pl, want_records, warm, zero_copy=False, spectrum=True):
+        st, dr, state = make_loop(pl, want_records, zero_copy, spectrum)
         for k in range(warm):
             st(k)
         dr()
@@ -576,6 +578,38 @@ def main():
                    "plan_flags": "SCN_OUT_SPECTRUM|SCN_OUT_HITS|SCN_PLAN_OVERLAP_SLOTS",
                    "note": "same steps, slots on two streams so consecutive launches overlap; not used for value/roofline"}
         plan2.close()
+
+    # Hits-only output mode (reported separately, never mixed with spectrum mode): the same steps on a plan
+    # without SCN_OUT_SPECTRUM -- no dB spectrum is written, the algorithmic bytes are the raw samples alone.
+    hits_only = None
+    if not args.no_hits_only_leg:
+        plan3 = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank,
+                     flags=capi.OUT_HITS)
+        el5, _ = timed_leg(plan3, False, min(args.warmup, 20), spectrum=False)
+        in_bytes = algo_bytes_per_sample - 4
+        hits_only = {"value": round(world * shard * n * args.steps / el5 / 1e6, 1), "unit": "Msamples/s",
+                     "ms_per_step": round(el5 / args.steps * 1e3, 5), "algorithmic_bytes_per_sample": in_bytes,
+                     "frac_of_hbm_peak_wall": round(shard * n * in_bytes * args.steps / el5 / 1e9 / HBM_PEAK_GBS, 4),
+                     "plan_flags": "SCN_OUT_HITS", "note": "wall clock over the same steps; not used for value/roofline"}
+        plan3.close()
+
+    # What a plain device-to-device copy reaches on this box in this run: torch's copy kernel over buffers no
+    # cache can hold, read + write bytes counted.
+    copy_gbs = None
+    if rank == 0 and not args.no_copy_ref:
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * nbytes * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
 
     # final sweep's hit list: collected with records, gathered to rank 0 by the C-ABI's scn_gather_hits
     # (RCCL: count all-gather + grouped send/recv), not timed above
@@ -676,6 +710,8 @@ def main():
                 # the same bytes over three clocks, side by side: HIP events launch-to-launch on the plan's stream (what
                 # `achieved` uses), host wall time per launch, and the kernel's own begin-to-end time under rocprofv3
                 # (a separate run: profiles/measured_shapes.json, null if this shape was not profiled)
+                "measured_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),  # torch tensor copy, 1 GiB, read + write bytes
+                "frac_of_measured_copy": None if copy_gbs is None else round(achieved / copy_gbs, 4),
                 "frac_event": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_wall": round(algo_bytes_per_launch / (wall_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "frac_kernel_rocprof": (round(algo_bytes_per_launch / (prof["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
@@ -695,6 +731,7 @@ def main():
             rc = 0 if ok else 3
         out["with_hit_records"] = records
         out["overlap"] = overlap
+        out["hits_only"] = hits_only
         if not args.no_cpu_baseline and world == 1:
             host = raw[: min(shard, 4096)].cpu().numpy()
             okind = {"cfloat": 4, "int16": 3, "int8": 1}[args.kind]

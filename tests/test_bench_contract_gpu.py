@@ -56,6 +56,9 @@ def test_bench_line_single_process():
     assert r["value"] > 0 and r["collect_hits"] > 0 and r["collect_with_records_us"] > 0
     assert d["roofline"]["kernel"].startswith("scn_fft_kernel<16, SCN_K_FLOAT_COMPLEX")
     assert d["roofline"]["frac_wall"] <= d["roofline"]["frac_event"] * 1.05
+    h = d["hits_only"]                                   # hits-only mode is reported separately, on its own byte count
+    assert h["value"] > 0 and h["algorithmic_bytes_per_sample"] == 8 and h["plan_flags"] == "SCN_OUT_HITS"
+    assert d["roofline"]["measured_copy_GBs"] > 500      # a device-to-device copy measured in the same run
 
 
 def test_bench_line_through_torch_distributed_one_rank():

@@ -14,11 +14,12 @@
 //                           (process.cpp:38-39,55-57: uint32 bin_step, uint32 i*bin_step, double sum, cast to uint64).
 //
 // Both are byte work on a few KB..MB (L2-latency bound, no roofline of their own): the C2 batch has ~69 k hits
-// = 0.5 MB of records in, 1.6 MB out.  The list goes straight into pinned HOST memory (a buffer's records are
-// contiguous there; alone on the GPU the kernel takes ~4.5 us for a C2 batch, beside a running FFT launch ~30 us,
-// in its shadow either way), so a collect call is an event wait plus a copy out of host memory.  The output window
-// [first, first + out_cap) lets a caller with a small buffer walk an arbitrarily long list (scn_collect_more) --
-// nothing is ever dropped on the device.
+// = 0.5 MB of records in, 1.6 MB out.  The list is written to DEVICE memory (writing it straight into pinned host
+// memory stalled the FFT launch running beside it: 76 -> 100 us) and a DMA of the predicted size follows it on the same
+// stream (scn_api.hip, build_list / fetch_list); alone on the GPU the kernel takes ~4.5 us for a C2 batch, beside a
+// running FFT launch ~30 us, in its shadow either way, so a collect call is an event wait plus a copy out of pinned
+// memory.  The output window [first, first + out_cap) lets a caller with a small buffer walk an arbitrarily long list
+// (scn_collect_more) -- nothing is ever dropped on the device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -4,6 +4,7 @@
 //
 //   scan_synth --kind short_complex --n 4096 --fs 8000000 --start 88e6 --stop 108e6
 //              --niterations 3 --threshold 10 --emitter 98.5e6:0.2 --emitter 101.1e6:0.05 [--dump raw.bin]
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,7 +22,7 @@ int main(int argc, char **argv) {
   std::string kindName = "short_complex", dump, outFile;
   uint32_t pre = 0, post = 0;
   unsigned long burstFirst = 1, burstLast = 0;
-  uint32_t sweepBlocks = 0, scanOffset = 0;
+  uint32_t sweepBlocks = 0, scanOffset = 0, replay = 0;
   double burstGain = 1.0;
   std::vector<SyntheticSource::Emitter> emitters;
   for (int i = 1; i < argc; i++) {
@@ -54,6 +55,7 @@ int main(int argc, char **argv) {
     else if (a == "--post") post = (uint32_t)atol(val());
     else if (a == "--sweep-blocks") sweepBlocks = (uint32_t)atol(val());
     else if (a == "--scan-offset") scanOffset = (uint32_t)atof(val());
+    else if (a == "--replay") replay = (uint32_t)atol(val());
     else if (a == "--burst") {  // first:last:gain
       const char *v = val();
       if (sscanf(v, "%lu:%lu:%lf", &burstFirst, &burstLast, &burstGain) != 3) { fprintf(stderr, "--burst wants first:last:gain\n"); return 2; }
@@ -79,6 +81,7 @@ int main(int argc, char **argv) {
   if (!dump.empty() && !source.SetDumpFile(dump)) return 1;
   source.SetBurst(burstFirst, burstLast, burstGain);
   if (sweepBlocks) source.SetSweepFraming(sweepBlocks, scanOffset);  // HackRF sweep-mode transfers
+  if (replay) source.SetReplay(replay);  // throughput runs: the generator hands out its first `replay` buffers again and again
 
   // scan.cpp:211-223
   ProcessSamples process(n, fs, enob, threshold, gr::fft::window::WIN_BLACKMAN_HARRIS, timeDomain ? ProcessSamples::TimeDomain : ProcessSamples::FrequencyDomain,
@@ -87,6 +90,7 @@ int main(int argc, char **argv) {
   SampleQueue sampleQueue(kind, enob, n, depth, correctDC, outFile != "");  // scan.cpp:223
 
   // scan.cpp:234-238 (the source delivers numIterations+1 sweeps: the first one is the queue's warm-up discard)
+  const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   if (!source.Start() || !source.StartStreaming(iterations + 1, sampleQueue)) {
     sampleQueue.SetIsDone();
     return 1;
@@ -94,6 +98,9 @@ int main(int argc, char **argv) {
   const bool ok = process.StartProcessing(sampleQueue);
   source.StopStreaming();
   if (!ok) fprintf(stderr, "scan_synth: %s\n", process.GetLastError().c_str());
+  const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   fprintf(stderr, "buffers %lu hits %lu\n", (unsigned long)process.GetBufferCount(), (unsigned long)process.GetHitCount());
+  // (the clock starts before the discarded warm-up sweep and includes plan creation: a lower bound on the pipeline's rate)
+  fprintf(stderr, "seconds %.3f Msamples/s %.1f\n", seconds, (double)process.GetBufferCount() * n / seconds / 1e6);
   return ok ? 0 : 1;
 }

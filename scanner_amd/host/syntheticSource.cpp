@@ -142,12 +142,18 @@ void SyntheticSource::ThreadWorker() {
     SweepWorker();
     return;
   }
-  std::vector<unsigned char> raw(m_bufferBytes);
+  std::vector<unsigned char> scratch(m_bufferBytes);
+  if (m_replay) m_replayCache.resize(m_replay);
   Retune(GetCurrentFrequency());
   while (!GetIsDone() && !m_finished) {
     double centerFrequency = GetCurrentFrequency();
     bool isScanStart = GetIsScanStart();
-    Generate(centerFrequency, m_bufferIndex++, raw.data());
+    std::vector<unsigned char> &raw = m_replay ? m_replayCache[m_bufferIndex % m_replay] : scratch;
+    if (raw.empty() || !m_replay) {
+      raw.resize(m_bufferBytes);
+      Generate(centerFrequency, m_bufferIndex, raw.data());
+    }
+    m_bufferIndex++;
     // a deterministic stand-in for time(NULL): one "second" per sweep, never 0
     time_t startTime = (time_t)(86400 + GetIterationCount());
     double next = GetNextFrequency();

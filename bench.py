@@ -67,6 +67,8 @@ def parse():
                          "per centre, emitters planted at known absolute frequencies, a step = one sweep of the rank's shard, "
                          "the gathered hit list is compared with the computed expectation on rank 0")
     ap.add_argument("--centres", type=int, default=16384, help="c4: number of centre frequencies in the table")
+    ap.add_argument("--sweeps-per-launch", type=int, default=0,
+                    help="c4: sweeps of the rank's shard batched into one launch (0: as many as fit 8192 buffers; 1: a launch per sweep)")
     ap.add_argument("--no-hits-only-leg", action="store_true", help="skip the extra leg on a plan without SCN_OUT_SPECTRUM")
     ap.add_argument("--no-copy-ref", action="store_true", help="skip the device-to-device copy measured beside the roofline")
     ap.add_argument("--no-records-leg", action="store_true",
@@ -396,19 +398,29 @@ def main():
         _, fc_all = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0)
         first, fc = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
         shard = len(fc)                      # buffers this rank sweeps per step
-        nb = min(shard, 8192)                # buffers per launch
+        # A launch is a batch of whatever is queued, not a sweep (the ProcessSamples worker drains up to max_batch messages
+        # whatever sweep they belong to): a shard smaller than the C2 batch is launched S sweeps at a time, so the per-launch
+        # fixed costs that a 2048-buffer launch cannot hide are paid once per 8192 buffers at every N.
+        sweeps_per_launch = max(1, 8192 // shard) if args.sweeps_per_launch == 0 else args.sweeps_per_launch
+        nb = min(shard, 8192) if sweeps_per_launch == 1 else shard * sweeps_per_launch  # buffers per launch
     else:
         nb = args.batch
         first, fc = capi.frequency_table(FS, 0.0, world * nb * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
         assert len(fc) == nb and first == rank * nb
         shard = nb
+        sweeps_per_launch = 1
+    S = sweeps_per_launch
     seq = np.arange(first, first + shard, dtype=np.uint64)
-    chunks = [(lo, min(lo + nb, shard)) for lo in range(0, shard, nb)]  # launches of one step
+    chunks = [(lo, min(lo + nb, shard)) for lo in range(0, shard, nb)]  # launches of one step (S == 1)
+    if S > 1:  # headers of a launch of S consecutive sweeps: the same centres, sequence ids running on (messageQueue.h:86)
+        fc_launch = np.tile(fc, S)
+        seq_launch = np.concatenate([seq + np.uint64(j * (n_centres if c4 else shard)) for j in range(S)])
 
     # synthetic IQ generated in HBM (seeded per rank and per rotation slot); quantised on device for
     # the int kinds.  R batches in, R spectra out: footprint >= 1.5 GiB >> 256 MiB Infinity Cache.
     step_bytes = shard * n * algo_bytes_per_sample
     R = args.rotate or max(2, -(-(3 << 29) // step_bytes))
+    R = -(-R // S) * S  # whole launches
     raws, outs = [], []
     if c4:
         centres, i0 = synth.c4_emitters(n_centres, n)
@@ -425,6 +437,14 @@ def main():
             raws.append(x)
         del x
         outs.append(torch.empty((shard, n), dtype=torch.float32, device=dev))
+    graws, gouts = [], []
+    if S > 1:  # S consecutive rotation slots back to back in memory = one launch; raws / outs become views of them
+        for g in range(R // S):
+            graws.append(torch.cat(raws[g * S:(g + 1) * S], dim=0).contiguous())
+            gouts.append(torch.empty((S * shard, n), dtype=torch.float32, device=dev))
+            for j in range(S):
+                raws[g * S + j] = graws[g][j * shard:(j + 1) * shard]
+                outs[g * S + j] = gouts[g][j * shard:(j + 1) * shard]
     raw = raws[0]
     torch.cuda.synchronize()
 
@@ -438,7 +458,7 @@ def main():
         """step(k): one pass over this rank's batch = len(chunks) launches, double-buffered over the plan's two slots; the
         results of a slot are collected right before it is reused (counts + trigger flags; the ordered records too if asked)"""
         pending = [False, False]
-        state = {"launch": 0, "hits": 0}
+        state = {"launch": 0, "hits": 0, "acc": 0, "group": 0}
         rec_buf = np.zeros(hit_cap, capi.HIT_DTYPE) if want_records else None  # the caller's record buffer, reused
 
         def collect(s):
@@ -454,7 +474,29 @@ def main():
                 state["hits"] += len(h)
             pending[s] = False
 
+        def flush():  # S > 1: launch the sweeps accumulated so far (a whole group, or what is left at the end)
+            a = state["acc"]
+            if not a:
+                return
+            g = state["group"] % len(graws)
+            state["group"] += 1
+            s = state["launch"] & 1
+            state["launch"] += 1
+            if pending[s]:
+                collect(s)
+            pl.submit_device(s, graws[g][:a * shard], a * shard, fc_launch[:a * shard], seq_launch[:a * shard], sync_producer=False,
+                             d_power_db=gouts[g][:a * shard] if spectrum else None)
+            pending[s] = True
+            state["acc"] = 0
+
+        state["flush"] = flush
+
         def step(k):
+            if S > 1:
+                state["acc"] += 1
+                if state["acc"] == S:
+                    flush()
+                return
             for lo, hi in chunks:
                 s = state["launch"] & 1
                 state["launch"] += 1
@@ -465,13 +507,14 @@ def main():
                 pending[s] = True
 
         def drain():
+            flush()
             for s in ((state["launch"] & 1), ((state["launch"] + 1) & 1)):  # older slot first
                 if pending[s]:
                     collect(s)
 
         return step, drain, state
 
-    step, drain, _ = make_loop(plan, False)
+    step, drain, main_state = make_loop(plan, False)
 
     # settle: the same steps, untimed and reported, until the GPU is out of its idle power state
     settle_steps = 0
@@ -492,10 +535,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    launch0 = main_state["launch"]
     with torch.cuda.stream(ext):
         ev0.record(ext)
     for k in range(args.steps):
         step(k)
+    main_state["flush"]()
     with torch.cuda.stream(ext):
         ev1.record(ext)
     drain()
@@ -503,7 +548,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    launches = args.steps * len(chunks)
+    launches = main_state["launch"] - launch0
     kernel_ms = ev0.elapsed_time(ev1) / launches  # average launch-to-launch duration on the plan's stream
 
     if world > 1:
@@ -691,7 +736,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": (f"{config_tag}: full frequency table of {n_centres} centres x {n}-pt FFT+power+threshold, "
-                             f"{shard} cfloat buffers per GPU per sweep in launches of {nb}, emitters planted on {len(centres)} centres, "
+                             f"{shard} cfloat buffers per GPU per sweep in launches of {nb}" + (f" (= {S} consecutive sweeps)" if S > 1 else "") +
+                             f", emitters planted on {len(centres)} centres, "
                              if c4 else
                              f"{config_tag}: {n}-pt FFT+power+threshold, batch {nb} {args.kind} buffers per GPU resident in HBM, ") +
                             f"Blackman-Harris, fs={FS} Hz, threshold {args.threshold} dB; frequency table range-sharded over "

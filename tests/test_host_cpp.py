@@ -197,6 +197,28 @@ def test_scan_synth_hackrf_sweep_framing(host_build, oracle_mod, tmp_path, n, bl
 
 
 @pytest.mark.gpu
+def test_scan_synth_replay_mode_repeats_its_first_buffers(host_build, tmp_path):
+    """--replay R (the throughput runs of scripts/host_path_rate.sh): buffer k of the stream is buffer k % R, so with one centre
+    frequency and R = 2 the hit lines of sweep j + 2 repeat those of sweep j exactly, and the run reports its rate."""
+    _, demo = host_build
+    r = subprocess.run([demo, "--kind", "short_complex", "--n", "4096", "--start", "433e6", "--stop", "0", "--niterations", "6",
+                        "--threshold", "11", "--sigma", "0.02", "--batch", "2", "--depth", "4", "--emitter", "433.92e6:0.3",
+                        "--replay", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"seconds [\d.]+ Msamples/s [\d.]+", r.stderr)
+    sweeps, cur = [], None
+    for l in r.stdout.splitlines():
+        if l.startswith("Start scan"):
+            cur = []
+            sweeps.append(cur)
+        elif l.startswith("freq ") and cur is not None:
+            cur.append(l)
+    assert len(sweeps) == 6 and len(sweeps[0]) > 3
+    # the generator's buffer 0 is the discarded warm-up sweep, so processed sweep j carries generated buffer (j + 1) % 2
+    assert sweeps[0] == sweeps[2] == sweeps[4] and sweeps[1] == sweeps[3] == sweeps[5] and sweeps[0] != sweeps[1]
+
+
+@pytest.mark.gpu
 def test_scan_synth_two_consumer_threads_and_time_domain(host_build, tmp_path):
     """scan.cpp:217 runs 2 consumer threads: two plans on their own streams share the queue.  Line
     order across threads is nondeterministic (as in the reference), the multiset of lines is not."""

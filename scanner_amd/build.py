@@ -40,7 +40,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     objs = []
     tag = "" if not out else "." + os.path.basename(out).replace(".so", "")
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
+        obj = os.path.join(os.path.dirname(out) if out else CSRC, src.replace(".hip", tag + ".o"))  # variants keep their objects beside them
         # -fno-slp-vectorize: keep the FFT butterflies as scalar f32 ops.  On gfx950 a packed
         # v_pk_*_f32 issues in the same 4 cycles as two scalar ops, and the SLP-packed stream
         # needs ~180 extra v_mov/v_pk_mov per FFT to pair registers (measured: 801 vs 668 VALU

@@ -206,7 +206,9 @@ struct RawLoader<SCN_K_SHORT> {
 // starts more workgroups than buffers, so workgroup g takes buffer g statically (shard g % 8, j = g / 8) and
 // head x hands out j = j0, j0 + 1, ... with j0 = the number of workgroups in shard x.  Heads are never reset:
 // work_base[x] is head x's value before the launch (host-tracked; a launch adds exactly the number of buffers of
-// shard x, because every workgroup stops at its first index past the end).
+// shard x, because every workgroup stops at its first index past the end).  (The one take whose answer is needed at
+// once is the prologue's; giving every workgroup a second static buffer instead, so that no take is ever waited for,
+// was built and measured: C3 shape 66.4 -> 67.2 us, 4096-pt int16 58.8 -> 58.4 -- nothing, so the simpler form stays.)
 // Measured per wire format (one box, single stream, us per launch static -> queue): int16 4096-pt 64.1 -> 61.2,
 // int8 63.9 -> 59.4, 8192-pt int16 98.5 -> 89.9, float 4096-pt 76.1 -> 77.0, 8192-pt float 83.8 -> 85.8: the
 // queue is compiled in for the integer formats from 4096 points up (scn_uses_queue, scn_kernels.h).
@@ -660,6 +662,9 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
   uint32_t *lds_next = reinterpret_cast<uint32_t *>(lds_hits + 2);  // [1] the buffer this workgroup takes after the next one
 
+#if SCN_STAMPS
+  const uint32_t stamp_entry = (uint32_t)wall_clock64();
+#endif
   const uint32_t t = threadIdx.x;
   const uint32_t lane = t & 63, wave = t >> 6;
   const uint32_t c2 = t & 31u, p2 = t >> 5;  // pass-2 identity of virtual thread t: (p2, c2); of t + 256: (p2 + 8, c2)
@@ -712,9 +717,17 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   uint32_t par = 0;
   uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running
 
+#if SCN_STAMPS
+  uint32_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t stamp_prev = (uint32_t)__builtin_readcyclecounter();
+  const uint32_t stamp_t0 = (uint32_t)wall_clock64();  // 100 MHz
+  uint32_t stamp_hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(stamp_hw));
+#endif
   uint32_t buf = blockIdx.x;
   uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
   while (buf < args.n_buffers) {
+    SCN_STAMP(0);  // previous buffer's hit recording + loop back
     const bool more = nxt < args.n_buffers;
     // ---- K1 + K2 ----
     int dc_re = 0, dc_im = 0;
@@ -745,6 +758,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       va[a] = L::conv(raw[2 * a], dc_re, dc_im, 1.0f) * win[2 * a];
       vb[a] = L::conv(raw[2 * a + 1], dc_re, dc_im, 1.0f) * win[2 * a + 1];
     }
+    SCN_STAMP(1);  // wait for this buffer's samples (+ convert, window)
     // take the buffer after the next one (behind the convert, see scn_fft_kernel); needed at the end of the iteration
     uint32_t taken = 0;
     if (DYN && t == 0 && more) taken = wq_take();
@@ -758,6 +772,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
         if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(rn, N, t, T * a);
     };
     prefetch(0, 11);
+    SCN_STAMP(2);  // issue of the first group of the next buffer's loads
 
     // ---- pass 1: virtual threads t and t + 256 ----
     fft16(va);
@@ -774,7 +789,9 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       if (p) y = cmul(y, tw1b[p]);
       w1[p * P1 + 256] = to_v2f(y);
     }
+    SCN_STAMP(3);  // pass 1 + exchange-1 writes
     __syncthreads();
+    SCN_STAMP(4);  // barrier 1
     if (HITS) {
       if (t == 0 && prev != 0xffffffffu) {  // every wave is past the barrier: the previous buffer's recorders are done
         args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
@@ -798,14 +815,18 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       va[OUT16(q)] = cmul(va[OUT16(q)], w);
       vb[OUT16(q)] = cmul(vb[OUT16(q)], w);
     }
+    SCN_STAMP(5);  // exchange-1 reads + pass 2 + twiddles (+ second load group)
     __syncthreads();  // every exchange-1 read done before the area is re-used
+    SCN_STAMP(6);  // barrier 2
     prefetch(22, 32);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       w2[q * 16] = to_v2f(va[OUT16(q)]);
       w2[q * 16 + 8] = to_v2f(vb[OUT16(q)]);
     }
+    SCN_STAMP(7);  // exchange-2 writes (+ third load group)
     __syncthreads();
+    SCN_STAMP(8);  // barrier 3
 
     // ---- pass 3: one 32-point DFT over c per thread (kl = t): even c -> va, odd c -> vb ----
 #pragma unroll
@@ -836,8 +857,13 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), rout, st_voff, 1024u * (r + 16), AUX_ST);
       if (HITS) dmax = fmaxf(dmax, fmaxf(d0, d1));
     }
+    SCN_STAMP(9);  // exchange-2 reads + pass 3 + dB + stores issued
     if (t == 0) lds_next[0] = !more ? 0xffffffffu : DYN ? wq_buffer(taken) : nxt + gridDim.x;
     __syncthreads();  // exchange area free again; lds_next visible
+    SCN_STAMP(10);  // barrier 4
+#if SCN_STAMPS
+    stamp_acc[11] += 1;
+#endif
     const uint32_t after = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
     if (HITS) {
       if (__ballot(dmax > args.threshold)) {
@@ -872,6 +898,18 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
     buf = nxt;
     nxt = after;
   }
+#if SCN_STAMPS
+  if (t == 0 && blockIdx.x < args.n_buffers && args.power_db) {
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int i = 0; i < 12; i++) args.power_db[(size_t)blockIdx.x * N + i] = (float)stamp_acc[i];
+    args.power_db[(size_t)blockIdx.x * N + 12] = (float)(stamp_t0 & 0xffffffu);
+    args.power_db[(size_t)blockIdx.x * N + 13] = (float)((uint32_t)wall_clock64() & 0xffffffu);
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    args.power_db[(size_t)blockIdx.x * N + 14] = (float)(((xcc & 0xfu) << 8) | ((stamp_hw >> 8) & 0xffu));
+    args.power_db[(size_t)blockIdx.x * N + 15] = (float)(stamp_entry & 0xffffffu);
+  }
+#endif
   if (HITS) {
     __syncthreads();  // last buffer's recorders done
     if (t == 0 && prev != 0xffffffffu) {

@@ -85,6 +85,14 @@ struct RawLoader<SCN_K_FLOAT_COMPLEX> {
     // (the builtin returns a GCC-style vector; bit_cast, never assign it to an ext_vector)
     return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, t * 8u, idx0 * 8u, AUX));
   }
+  // two consecutive samples idx0 + 2t, idx0 + 2t + 1 in one 16-byte load (the wide 8192-point kernel's lane pairs)
+  template <int AUX>
+  static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    const v4f_t v = __builtin_bit_cast(v4f_t, __builtin_amdgcn_raw_buffer_load_b128(r, t * 16u, idx0 * 8u, AUX));
+    r0 = v2f{v.x, v.y};
+    r1 = v2f{v.z, v.w};
+  }
   static __device__ __forceinline__ void ints(raw_t, int &re, int &im) { re = im = 0; }
   static __device__ __forceinline__ cf conv(raw_t r, int, int, float) { return from_v2f(r); }
 };
@@ -97,6 +105,13 @@ struct RawLoader<SCN_K_SHORT_COMPLEX> {
   template <int AUX>
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
     return __builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, idx0 * 4u, AUX);
+  }
+  template <int AUX>
+  static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    const v2i_t v = __builtin_bit_cast(v2i_t, __builtin_amdgcn_raw_buffer_load_b64(r, t * 8u, idx0 * 4u, AUX));
+    r0 = v.x;
+    r1 = v.y;
   }
   static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
     re = (int)(short)(r & 0xffff);
@@ -120,6 +135,12 @@ struct RawLoader<SCN_K_BYTE_COMPLEX> {
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
     return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, AUX);
   }
+  template <int AUX>
+  static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {
+    const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, idx0 * 2u, AUX);
+    r0 = (int)(v & 0xffffu);
+    r1 = (int)(v >> 16);
+  }
   static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
     re = (int)(signed char)(r & 0xff);
     im = (int)(signed char)((r >> 8) & 0xff);
@@ -142,6 +163,13 @@ struct RawLoader<SCN_K_SHORT> {
     int re = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, AUX);
     int im = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, (n + idx0) * 2u, AUX);
     return (re & 0xffff) | (im << 16);
+  }
+  template <int AUX>
+  static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t n, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {
+    const uint32_t re = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, idx0 * 2u, AUX);        // I[2t], I[2t+1]
+    const uint32_t im = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, (n + idx0) * 2u, AUX);  // Q[2t], Q[2t+1]
+    r0 = (int)((re & 0xffffu) | (im << 16));
+    r1 = (int)((re >> 16) | (im & 0xffff0000u));
   }
   static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
     RawLoader<SCN_K_SHORT_COMPLEX>::ints(r, re, im);
@@ -634,6 +662,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #ifndef SCN_WIDE_8192
 #define SCN_WIDE_8192 1
 #endif
+#ifndef SCN_8K_PAIR
+#define SCN_8K_PAIR 1  // the wide kernel's threads play neighbouring virtual threads (two-sample loads, 16-byte exchange-1 writes)
+#endif
 // (16384 points run as scn_fft_kernel<64>: 1024 threads x 16 points, four waves per SIMD, lane-quad radix-4 in pass 3.
 // The first form -- 256 threads x 64 points, one wave per SIMD, modelled on the wide kernel below -- was 1.5-1.8x slower:
 // 195 / 191 Gsamples/s against 296 / 344 for cfloat / int16 at batch 2048.)
@@ -652,7 +683,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   typedef Geo8k G;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
-  constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
+  constexpr uint32_t N = G::N, P1 = G::P1, P2 = G::P2;
   constexpr bool DYN = scn_uses_queue(KIND, N);
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -668,25 +699,45 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   const uint32_t t = threadIdx.x;
   const uint32_t lane = t & 63, wave = t >> 6;
   const uint32_t c2 = t & 31u, p2 = t >> 5;  // pass-2 identity of virtual thread t: (p2, c2); of t + 256: (p2 + 8, c2)
+  // Which two of the 512 pass-1 virtual threads this thread plays.  PAIR (product): tau = 2t and 2t + 1 -- their inputs
+  // 512a + 2t (+1) are neighbours in memory and their exchange-1 slots neighbours in LDS, so a buffer is fetched in 16
+  // loads of two samples instead of 32 of one (16 / 8 / 4 bytes per lane) and exchange 1 is written in 16 ds_write_b128
+  // instead of 32 ds_write_b64.  !PAIR: tau = t and t + 256 (the first form).
+  constexpr bool PAIR = SCN_8K_PAIR != 0;
+  const uint32_t tau0 = PAIR ? 2u * t : t, tau1 = PAIR ? 2u * t + 1u : t + 256u;
 
-  // first buffer's samples first: x[256 a' + t], a' = 2a + h  <->  virtual thread t + 256 h, input a
+  // first buffer's samples first: raw[2a + h] = x[512 a + tau_h]
   typename L::raw_t raw[32];
+  auto load_group = [&](const __amdgpu_buffer_rsrc_t &r, int a_lo, int a_hi) {  // inputs a_lo .. a_hi - 1 of both virtual threads
+#pragma unroll
+    for (int a = 0; a < 16; a++)
+      if (a >= a_lo && a < a_hi) {
+        if (PAIR) {
+          L::template load2<AUX_LD>(r, N, t, 512u * a, raw[2 * a], raw[2 * a + 1]);
+        } else {
+          raw[2 * a] = L::template load<AUX_LD>(r, N, t, 512u * a);
+          raw[2 * a + 1] = L::template load<AUX_LD>(r, N, t, 512u * a + 256u);
+        }
+      }
+  };
   if (blockIdx.x < args.n_buffers) {
     __amdgpu_buffer_rsrc_t r0 =
         make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
-#pragma unroll
-    for (int a = 0; a < 32; a++) raw[a] = L::template load<AUX_LD>(r0, N, t, T * a);
+    load_group(r0, 0, 16);
   }
-  // persistent constants: pass-1 twiddles of both virtual threads (coalesced table rows of 512), window taps
+  // persistent constants: pass-1 twiddles of both virtual threads (table rows of 512), window taps
   cf tw1a[16], tw1b[16];
 #pragma unroll
   for (int p = 1; p < 16; p++) {
-    tw1a[p] = from_v2f(args.tw1_table[(p - 1) * 512 + t]);
-    tw1b[p] = from_v2f(args.tw1_table[(p - 1) * 512 + 256 + t]);
+    tw1a[p] = from_v2f(args.tw1_table[(p - 1) * 512 + tau0]);
+    tw1b[p] = from_v2f(args.tw1_table[(p - 1) * 512 + tau1]);
   }
   float win[32];
 #pragma unroll
-  for (int a = 0; a < 32; a++) win[a] = args.window[T * a + t] * args.scale;
+  for (int a = 0; a < 16; a++) {
+    win[2 * a] = args.window[512 * a + tau0] * args.scale;
+    win[2 * a + 1] = args.window[512 * a + tau1] * args.scale;
+  }
   // pass-2 twiddles W_512^(c q) = W_N^(16 c q), entry q*32 + c: this thread fills entries t and t + 256
   lds_tw2[t] = args.twiddle[(16u * p2 * c2) & (N - 1)];
   lds_tw2[t + 256] = args.twiddle[(16u * (p2 + 8u) * c2) & (N - 1)];
@@ -697,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   }
   __syncthreads();
 
-  v2f *w1 = lds + t;                       // + p*P1 (+256 for the second virtual thread)
+  v2f *w1 = lds + tau0;                    // + p*P1 (the second virtual thread: + (tau1 - tau0))
   v2f *r1 = lds + p2 * P1 + c2;            // + b*32 (+ 8*P1 for the second)
   v2f *w2 = lds + c2 * P2 + p2;            // + 16*q (+ 8 for the second)
   v2f *r3 = lds + t;                       // + c*P2
@@ -766,28 +817,39 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
     const __amdgpu_buffer_rsrc_t rn =
         make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N),
                   (more && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
-    auto prefetch = [&](int a_lo, int a_hi) {
-#pragma unroll
-      for (int a = 0; a < 32; a++)
-        if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(rn, N, t, T * a);
-    };
-    prefetch(0, 11);
+    auto prefetch = [&](int a_lo, int a_hi) { load_group(rn, a_lo, a_hi); };  // groups of inputs a: two samples each
+    prefetch(0, 6);
     SCN_STAMP(2);  // issue of the first group of the next buffer's loads
 
     // ---- pass 1: virtual threads t and t + 256 ----
-    fft16(va);
+    if (PAIR) {
+      fft16(va);
+      fft16(vb);
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-      cf y = va[OUT16(p)];
-      if (p) y = cmul(y, tw1a[p]);
-      w1[p * P1] = to_v2f(y);
-    }
-    fft16(vb);
+      for (int p = 0; p < 16; p++) {
+        cf ya = va[OUT16(p)], yb = vb[OUT16(p)];
+        if (p) {
+          ya = cmul(ya, tw1a[p]);
+          yb = cmul(yb, tw1b[p]);
+        }
+        typedef float v4f_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<v4f_t *>(w1 + p * P1) = v4f_t{ya.x, ya.y, yb.x, yb.y};  // slots tau0, tau0 + 1: 16-byte aligned (P1 even)
+      }
+    } else {
+      fft16(va);
 #pragma unroll
-    for (int p = 0; p < 16; p++) {
-      cf y = vb[OUT16(p)];
-      if (p) y = cmul(y, tw1b[p]);
-      w1[p * P1 + 256] = to_v2f(y);
+      for (int p = 0; p < 16; p++) {
+        cf y = va[OUT16(p)];
+        if (p) y = cmul(y, tw1a[p]);
+        w1[p * P1] = to_v2f(y);
+      }
+      fft16(vb);
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        cf y = vb[OUT16(p)];
+        if (p) y = cmul(y, tw1b[p]);
+        w1[p * P1 + 256] = to_v2f(y);
+      }
     }
     SCN_STAMP(3);  // pass 1 + exchange-1 writes
     __syncthreads();
@@ -799,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
         lds_hits[par ^ 1] = 0;
       }
     }
-    prefetch(11, 22);
+    prefetch(6, 11);
 
     // ---- pass 2: virtual threads (p2, c2) and (p2 + 8, c2) ----
 #pragma unroll
@@ -818,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
     SCN_STAMP(5);  // exchange-1 reads + pass 2 + twiddles (+ second load group)
     __syncthreads();  // every exchange-1 read done before the area is re-used
     SCN_STAMP(6);  // barrier 2
-    prefetch(22, 32);
+    prefetch(11, 16);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       w2[q * 16] = to_v2f(va[OUT16(q)]);

@@ -325,6 +325,11 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 
   // the first buffer's samples go out before anything else: their latency then overlaps the
   // ~31 table loads below instead of following them
+  // (Sizes without the register prefetch load at the top of the iteration.  Letting the next buffer's loads leave behind this
+  // buffer's stores, before the end-of-buffer barrier and the hit recording -- free in registers, and at 16384 points, one
+  // workgroup per CU, everything after the stores is dead time for the memory system: 5.9 k cycles at barrier 4 + 2 k of
+  // recording per 30 k-cycle buffer -- was measured twice and is worse both times: 8192 points, 512-thread form, 85.9 -> 89.8 us
+  // (round 1); 16384 points 109.7 -> 126.2 us cfloat, 94.2 -> 102.2 int16 (round 2).)
   typename L::raw_t raw[16];
   if (PF && blockIdx.x < args.n_buffers) {
     __amdgpu_buffer_rsrc_t r0 =

@@ -667,6 +667,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #ifndef SCN_WIDE_8192
 #define SCN_WIDE_8192 1
 #endif
+#ifndef SCN_WIDE_16384
+#define SCN_WIDE_16384 1  // 16384 points: 512 threads x 32 points with a register prefetch instead of scn_fft_kernel<64>
+#endif
 #ifndef SCN_8K_PAIR
 #define SCN_8K_PAIR 1  // the wide kernel's threads play neighbouring virtual threads (two-sample loads, 16-byte exchange-1 writes)
 #endif
@@ -674,27 +677,39 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 // The first form -- 256 threads x 64 points, one wave per SIMD, modelled on the wide kernel below -- was 1.5-1.8x slower:
 // 195 / 191 Gsamples/s against 296 / 344 for cfloat / int16 at batch 2048.)
 namespace {
-struct Geo8k {
-  static constexpr uint32_t N = 8192, T = 256, P1 = 512, P2 = 257;
-  static constexpr uint32_t EXCH = (16u * P1 > 32u * P2) ? 16u * P1 : 32u * P2;  // slots
-  static constexpr uint32_t LDS_BYTES = EXCH * 8u + 512u * 8u + 16u * 4u + 2u * 4u + 8u;
-  static constexpr uint32_t WG_PER_CU = 2;
+// the wide form for N = 256*M2, M2 = 32 (8192 points: the kernel described above) or 64 (16384 points): 8*M2 threads play
+// the 16*M2 virtual threads of passes 1 and 2, two each, and hold 32 points each; two waves per SIMD either way
+template <int M2>
+struct GeoWide {
+  static constexpr uint32_t N = 256u * M2, T = 8u * M2, TV = 16u * M2, P1 = TV, P2 = 257;
+  static constexpr uint32_t EXCH = (16u * P1 > M2 * P2) ? 16u * P1 : M2 * P2;  // slots
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + TV * 8u + 16u * 4u + 2u * 4u + 8u;
+  static constexpr uint32_t WG_PER_CU = M2 == 32 ? 2 : 1;  // 70 KiB / 140 KiB of LDS
 };
+typedef GeoWide<32> Geo8k;
 typedef float v32f __attribute__((ext_vector_type(32)));
-}  // namespace
 
-template <int KIND, bool DC, bool HITS>
-__global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
-  typedef Geo8k G;
+// 16384 points in the wide form (M2 = 64).  The 1024-thread form (scn_fft_kernel<64>: four waves per SIMD, 128 VGPRs, no room
+// to prefetch) has ONE workgroup per CU, so nothing covers its loads: its stamp profile shows 13 k of a buffer's 30 k cycles
+// waiting for the samples (and letting the next buffer's loads leave behind the stores makes it worse, see there).  512 threads
+// x 32 points are two waves per SIMD = 256 VGPRs: the next buffer is prefetched in three groups spread over the passes, as
+// at 8192 points.  Pass 3 is a 64-point DFT per kl shared by TWO lanes (l, l + 32): lane half e does the 16-point DFTs over
+// c = 4c' + e and c = 4c' + e + 2, joins them in registers (U, V = Y_e +- W_32^r' Y_(e+2): the 8192-point kernel's last step),
+// the odd half multiplies by W_64^r', and one v_permlane32_swap per register finishes the radix-4 step:
+//   X[r']      = U_0 + W U_1 (lower half)      X[r' + 32] = U_0 - W U_1 (upper half)
+//   X[r' + 16] = V_0 - i W V_1 (lower half)    X[r' + 48] = V_0 + i W V_1 (upper half)
+template <int M2, int KIND, bool DC, bool HITS>
+__device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
+  typedef GeoWide<M2> G;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
-  constexpr uint32_t N = G::N, P1 = G::P1, P2 = G::P2;
+  constexpr uint32_t N = G::N, T = G::T, TV = G::TV, P1 = G::P1, P2 = G::P2;
   constexpr bool DYN = scn_uses_queue(KIND, N);
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-  v2f *lds_tw2 = lds + G::EXCH;                              // [16][32]: W_512^(c q) at q*32 + c
-  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + 512);    // [16] DC-sum scratch (re[8], im[8])
+  v2f *lds_tw2 = lds + G::EXCH;                              // [16][M2]: W_(16 M2)^(c q) at q*M2 + c
+  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + TV);     // [16] DC-sum scratch (re[8], im[8])
   int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
   uint32_t *lds_next = reinterpret_cast<uint32_t *>(lds_hits + 2);  // [1] the buffer this workgroup takes after the next one
 
@@ -703,13 +718,16 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
 #endif
   const uint32_t t = threadIdx.x;
   const uint32_t lane = t & 63, wave = t >> 6;
-  const uint32_t c2 = t & 31u, p2 = t >> 5;  // pass-2 identity of virtual thread t: (p2, c2); of t + 256: (p2 + 8, c2)
+  const uint32_t c2 = t % M2, p2 = t / M2;   // pass-2 identities of this thread: (p2, c2) and (p2 + 8, c2), p2 < 8
+  // pass-3 identity.  M2 = 32: one whole 32-point DFT, kl = t.  M2 = 64: half e of the 64-point DFT of kl (lanes l, l + 32)
+  const uint32_t e = (M2 == 64) ? (t >> 5) & 1u : 0u;
+  const uint32_t kl = (M2 == 64) ? (t & 31u) + 32u * (t >> 6) : t;
   // Which two of the 512 pass-1 virtual threads this thread plays.  PAIR (product): tau = 2t and 2t + 1 -- their inputs
   // 512a + 2t (+1) are neighbours in memory and their exchange-1 slots neighbours in LDS, so a buffer is fetched in 16
   // loads of two samples instead of 32 of one (16 / 8 / 4 bytes per lane) and exchange 1 is written in 16 ds_write_b128
   // instead of 32 ds_write_b64.  !PAIR: tau = t and t + 256 (the first form).
   constexpr bool PAIR = SCN_8K_PAIR != 0;
-  const uint32_t tau0 = PAIR ? 2u * t : t, tau1 = PAIR ? 2u * t + 1u : t + 256u;
+  const uint32_t tau0 = PAIR ? 2u * t : t, tau1 = PAIR ? 2u * t + 1u : t + T;
 
   // first buffer's samples first: raw[2a + h] = x[512 a + tau_h]
   typename L::raw_t raw[32];
@@ -718,10 +736,10 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
     for (int a = 0; a < 16; a++)
       if (a >= a_lo && a < a_hi) {
         if (PAIR) {
-          L::template load2<AUX_LD>(r, N, t, 512u * a, raw[2 * a], raw[2 * a + 1]);
+          L::template load2<AUX_LD>(r, N, t, TV * a, raw[2 * a], raw[2 * a + 1]);
         } else {
-          raw[2 * a] = L::template load<AUX_LD>(r, N, t, 512u * a);
-          raw[2 * a + 1] = L::template load<AUX_LD>(r, N, t, 512u * a + 256u);
+          raw[2 * a] = L::template load<AUX_LD>(r, N, t, TV * a);
+          raw[2 * a + 1] = L::template load<AUX_LD>(r, N, t, TV * a + T);
         }
       }
   };
@@ -730,22 +748,22 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
         make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
     load_group(r0, 0, 16);
   }
-  // persistent constants: pass-1 twiddles of both virtual threads (table rows of 512), window taps
+  // persistent constants: pass-1 twiddles of both virtual threads (table rows of TV), window taps
   cf tw1a[16], tw1b[16];
 #pragma unroll
   for (int p = 1; p < 16; p++) {
-    tw1a[p] = from_v2f(args.tw1_table[(p - 1) * 512 + tau0]);
-    tw1b[p] = from_v2f(args.tw1_table[(p - 1) * 512 + tau1]);
+    tw1a[p] = from_v2f(args.tw1_table[(p - 1) * TV + tau0]);
+    tw1b[p] = from_v2f(args.tw1_table[(p - 1) * TV + tau1]);
   }
   float win[32];
 #pragma unroll
   for (int a = 0; a < 16; a++) {
-    win[2 * a] = args.window[512 * a + tau0] * args.scale;
-    win[2 * a + 1] = args.window[512 * a + tau1] * args.scale;
+    win[2 * a] = args.window[TV * a + tau0] * args.scale;
+    win[2 * a + 1] = args.window[TV * a + tau1] * args.scale;
   }
-  // pass-2 twiddles W_512^(c q) = W_N^(16 c q), entry q*32 + c: this thread fills entries t and t + 256
+  // pass-2 twiddles W_(16 M2)^(c q) = W_N^(16 c q), entry q*M2 + c: this thread fills entries t (q = p2) and t + T (q = p2 + 8)
   lds_tw2[t] = args.twiddle[(16u * p2 * c2) & (N - 1)];
-  lds_tw2[t + 256] = args.twiddle[(16u * (p2 + 8u) * c2) & (N - 1)];
+  lds_tw2[t + T] = args.twiddle[(16u * (p2 + 8u) * c2) & (N - 1)];
   SCN_WORK_QUEUE_SETUP();
   if (t == 0) {
     lds_hits[0] = lds_hits[1] = 0;
@@ -754,17 +772,19 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   __syncthreads();
 
   v2f *w1 = lds + tau0;                    // + p*P1 (the second virtual thread: + (tau1 - tau0))
-  v2f *r1 = lds + p2 * P1 + c2;            // + b*32 (+ 8*P1 for the second)
+  v2f *r1 = lds + p2 * P1 + c2;            // + b*M2 (+ 8*P1 for the second)
   v2f *w2 = lds + c2 * P2 + p2;            // + 16*q (+ 8 for the second)
-  v2f *r3 = lds + t;                       // + c*P2
-  const v2f *tw2 = lds_tw2 + c2;           // + q*32
-  const uint32_t st_voff = t * 4u;         // output r of this thread is bin j = t + 256 r
+  v2f *r3 = lds + e * P2 + kl;             // M2 = 32: + c*P2;  M2 = 64: + (4c')*P2 and + (4c' + 2)*P2
+  const v2f *tw2 = lds_tw2 + c2;           // + q*M2
+  // output o of this thread is bin j = jbase + 256 o  (M2 = 64: o = r' + 16 h is block r = o + 32 e)
+  const uint32_t jbase = kl + 8192u * e;
+  const uint32_t st_voff = jbase * 4u;
 
   uint32_t keepmask = 0;  // K5 mask of this thread's 32 bins (process.cpp:46-52)
   if (HITS) {
 #pragma unroll
     for (int r = 0; r < 32; r++) {
-      const uint32_t j = t + 256u * r;
+      const uint32_t j = jbase + 256u * r;
       const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
       const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
       keepmask |= keep ? (1u << r) : 0u;
@@ -803,8 +823,12 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
         lds_cnt[8 + wave] = si;
       }
       __syncthreads();
-      sr = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
-      si = lds_cnt[8] + lds_cnt[9] + lds_cnt[10] + lds_cnt[11];
+      sr = si = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < T / 64u; w++) {
+        sr += lds_cnt[w];
+        si += lds_cnt[8 + w];
+      }
       dc_re = (int)((uint32_t)sr / N);  // int32 /= uint32, utility.cpp:77-78
       dc_im = (int)((uint32_t)si / N);
     }
@@ -853,7 +877,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       for (int p = 0; p < 16; p++) {
         cf y = vb[OUT16(p)];
         if (p) y = cmul(y, tw1b[p]);
-        w1[p * P1 + 256] = to_v2f(y);
+        w1[p * P1 + T] = to_v2f(y);
       }
     }
     SCN_STAMP(3);  // pass 1 + exchange-1 writes
@@ -871,14 +895,14 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
     // ---- pass 2: virtual threads (p2, c2) and (p2 + 8, c2) ----
 #pragma unroll
     for (int b = 0; b < 16; b++) {
-      va[b] = from_v2f(r1[b * 32]);
-      vb[b] = from_v2f(r1[b * 32 + 8 * P1]);
+      va[b] = from_v2f(r1[b * M2]);
+      vb[b] = from_v2f(r1[b * M2 + 8 * P1]);
     }
     fft16(va);
     fft16(vb);
 #pragma unroll
     for (int q = 1; q < 16; q++) {
-      const cf w = from_v2f(tw2[q * 32]);
+      const cf w = from_v2f(tw2[q * M2]);
       va[OUT16(q)] = cmul(va[OUT16(q)], w);
       vb[OUT16(q)] = cmul(vb[OUT16(q)], w);
     }
@@ -895,19 +919,22 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
     __syncthreads();
     SCN_STAMP(8);  // barrier 3
 
-    // ---- pass 3: one 32-point DFT over c per thread (kl = t): even c -> va, odd c -> vb ----
+    // ---- pass 3.  M2 = 32: one 32-point DFT over c per thread: even c -> va, odd c -> vb.
+    //             M2 = 64: this lane's half of a 64-point DFT: c = 4c' + e -> va, c = 4c' + e + 2 -> vb ----
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-      va[c] = from_v2f(r3[(2 * c) * P2]);
-      vb[c] = from_v2f(r3[(2 * c + 1) * P2]);
+      va[c] = from_v2f(r3[(M2 == 64 ? 4 * c : 2 * c) * P2]);
+      vb[c] = from_v2f(r3[(M2 == 64 ? 4 * c + 2 : 2 * c + 1) * P2]);
     }
     fft16(va);
     fft16(vb);
 
-    // ---- K4 + K5: X[r'] = E[r'] + W_32^r' O[r'], X[r' + 16] = E[r'] - W_32^r' O[r'] ----
+    // ---- K4 + K5: U, V = E[r'] +- W_32^r' O[r']: the outputs X[r'], X[r' + 16] themselves (M2 = 32), or this lane's
+    //      share of them (M2 = 64: one exchange across the wave's halves finishes the radix-4 step) ----
     v32f db;
     float dmax = -3.40282347e+38f;
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
+    const float sel = e ? 1.0f : 0.0f, sgn = e ? -1.0f : 1.0f;  // (M2 = 64)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const cf ev = va[OUT16(r)];
@@ -917,7 +944,28 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
         const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
         od = cmul(od, cf{cr, -sr});
       }
-      const float d0 = power_db(ev + od), d1 = power_db(ev - od);
+      cf x0 = ev + od, x1 = ev - od;
+      if constexpr (M2 == 64) {
+        if (r) {  // W_64^r' in the odd half, 1 in the even half (branch-free: both halves run the same code)
+          const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 64.0);
+          const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 64.0);
+          const cf w = cf{e ? cr : 1.0f, -sr * sel};
+          x0 = cmul(x0, w);
+          x1 = cmul(x1, w);
+        }
+        // v_permlane32_swap on two copies of a register leaves the lower half's value in [0] and the upper half's in [1], in BOTH halves
+        auto ax = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0.x), __builtin_bit_cast(unsigned, x0.x), false, false);
+        auto ay = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0.y), __builtin_bit_cast(unsigned, x0.y), false, false);
+        auto bx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x1.x), __builtin_bit_cast(unsigned, x1.x), false, false);
+        auto by = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x1.y), __builtin_bit_cast(unsigned, x1.y), false, false);
+        const cf u0 = cf{__builtin_bit_cast(float, (unsigned)ax[0]), __builtin_bit_cast(float, (unsigned)ay[0])};
+        const cf u1 = cf{__builtin_bit_cast(float, (unsigned)ax[1]), __builtin_bit_cast(float, (unsigned)ay[1])};
+        const cf v0 = cf{__builtin_bit_cast(float, (unsigned)bx[0]), __builtin_bit_cast(float, (unsigned)by[0])};
+        const cf v1 = cf{__builtin_bit_cast(float, (unsigned)bx[1]), __builtin_bit_cast(float, (unsigned)by[1])};
+        x0 = cf{__builtin_fmaf(u1.x, sgn, u0.x), __builtin_fmaf(u1.y, sgn, u0.y)};    // U_0 +- W U_1
+        x1 = cf{__builtin_fmaf(v1.y, sgn, v0.x), __builtin_fmaf(v1.x, -sgn, v0.y)};   // V_0 -+ i W V_1
+      }
+      const float d0 = power_db(x0), d1 = power_db(x1);
       db[r] = d0;
       db[r + 16] = d1;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d0), rout, st_voff, 1024u * r, AUX_ST);
@@ -953,7 +1001,7 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
             const unsigned long long m = __ballot(hit);
             if (hit) {
               const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-              if (pos < args.hit_region) region[pos] = ScnDevHit{(t + 256u * (uint32_t)r) ^ (N / 2), db[r]};
+              if (pos < args.hit_region) region[pos] = ScnDevHit{(jbase + 256u * (uint32_t)r) ^ (N / 2), db[r]};
             }
             base += (uint32_t)__popcll(m);
           }
@@ -984,6 +1032,17 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
       if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
     }
   }
+}
+}  // namespace
+
+template <int KIND, bool DC, bool HITS>
+__global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
+  scn_fft_wide_body<32, KIND, DC, HITS>(args);
+}
+
+template <int KIND, bool DC, bool HITS>
+__global__ __launch_bounds__(512, 2) void scn_fft16k_kernel(ScnFftArgs args) {
+  scn_fft_wide_body<64, KIND, DC, HITS>(args);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1285,6 +1344,32 @@ static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, int nu
   if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
   return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
 }
+template <int KIND>
+static hipError_t launch_16k_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s, hipEvent_t stop) {
+  typedef GeoWide<64> G;
+  void (*k)(ScnFftArgs) = nullptr;
+  if (dc && hits) k = scn_fft16k_kernel<KIND, true, true>;
+  else if (dc) k = scn_fft16k_kernel<KIND, true, false>;
+  else if (hits) k = scn_fft16k_kernel<KIND, false, true>;
+  else k = scn_fft16k_kernel<KIND, false, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  int grid = num_cus * (int)G::WG_PER_CU;
+  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
+  return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
+}
+static hipError_t launch_16k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
+  switch (kind) {
+    // float input: the 64 prefetch registers leave the wide form nothing to spare at 16384 points (22 VGPRs spill; deriving
+    // the second twiddle set from the first, W_N^(tau+1)p = W_N^(tau p) W_N^p, did not cure it): 113 us per 2048-buffer launch
+    // against 111 for scn_fft_kernel<64>, which therefore stays; the integer formats: 94.8 -> 88.5 us (scripts/wide16k_check.sh)
+    case SCN_K_FLOAT_COMPLEX: return launch_size<64>(kind, false, hits, args, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_16k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_16k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_16k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream, stop);
+    default: return hipErrorInvalidValue;
+  }
+}
 static hipError_t launch_8k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
     case SCN_K_FLOAT_COMPLEX: return launch_8k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream, stop);
@@ -1307,7 +1392,11 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFft
 #else
     case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream, stop);  // the 512-thread form (variant build)
 #endif
-    case 16384: return launch_size<64>(kind, dc, hits, args, num_cus, stream, stop);
+#if SCN_WIDE_16384
+    case 16384: return launch_16k(kind, dc, hits, args, num_cus, stream, stop);
+#else
+    case 16384: return launch_size<64>(kind, dc, hits, args, num_cus, stream, stop);  // the 1024-thread form (variant build)
+#endif
     default: return hipErrorInvalidValue;
   }
 }

@@ -87,6 +87,32 @@ def test_golden_4096(torch_cuda, oracle_mod):
     assert len(h) == 0 and not t.any()
 
 
+@pytest.mark.parametrize("n", [1024, 4096, 8192, 16384])
+def test_hip_against_an_independent_float32_fft(torch_cuda, n):
+    """The HIP path held directly to third-party arithmetic, without this repo's oracle in between: numpy's float32 multiply by
+    the plan's window table, pocketfft (scipy.fft on complex64) and a float32 dB map (tests/test_oracle_vs_pocketfft.py) -- two
+    independent single-precision FFTs, each a few 1e-6 from the float64 spectrum, within the 1e-5 bar of each other, and the
+    same detections wherever the threshold is clear of every evaluated bin of both."""
+    from tests.test_oracle_vs_pocketfft import float32_chain
+
+    nb = 48
+    x = synth.cfloat_batch(n, nb, seed=7 + n)
+    with Plan(n, FS, 1e9, max_batch=nb) as plan:
+        w = plan.window()
+        plan.submit_device(0, _to_dev(torch_cuda, x), nb)
+        p, _, _ = plan.collect(0)
+    p_pf = float32_chain(x, w)
+    print(n, "HIP vs pocketfft float32:", tol.compare_spectra(p, p_pf))
+    keep = tol.evaluated_mask(n)
+    thr = tol.pick_threshold(np.concatenate([p_pf, p]), n, start=10.0)   # guard band empty on BOTH spectra
+    with Plan(n, FS, thr, max_batch=nb, max_hits=nb * n) as plan:
+        plan.submit_device(0, _to_dev(torch_cuda, x), nb, 3e6 + 6e6 * np.arange(nb))
+        _, h, _ = plan.collect(0, want_power=False)
+    jj = (np.arange(n) + n // 2) % n
+    want = [(b, int(i)) for b in range(nb) for i in np.nonzero(keep[jj] & (p_pf[b][jj] > np.float32(thr)))[0]]
+    assert [(int(s), int(i)) for s, i in zip(h["seq_id"], h["i"])] == want and len(want) > 0
+
+
 def test_pinned_double_buffered_submit(torch_cuda, oracle_mod):
     """scn_host_buffer + scn_submit on both slots (the replacement of sampleBuffer.cpp's
     staging), results identical to the device-resident path and to the oracle."""

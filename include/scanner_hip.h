@@ -84,8 +84,8 @@ typedef struct scn_hit {
  * constant where one exists. */
 typedef struct scn_plan_desc {
   uint32_t struct_size;
-  uint32_t n;              /* sampleCount = FFT size (scan.cpp:85; the reference plans any count, fft.cpp:4-11): 16 ... 65536 for
-                              powers of two, 16 ... 32768 otherwise.  1024 / 2048 / 4096 / 8192 / 16384 run in the fused LDS
+  uint32_t n;              /* sampleCount = FFT size (scan.cpp:85; the reference plans any count, fft.cpp:4-11): any size from
+                              16 to 65536.  1024 / 2048 / 4096 / 8192 / 16384 run in the fused LDS
                               kernels; the other sizes through a staged, slower path (Bluestein for the sizes that are not
                               powers of two) with the same outputs */
   uint32_t sample_rate;    /* Hz (scan.cpp:92) */

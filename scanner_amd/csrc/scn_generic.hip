@@ -10,7 +10,7 @@
 //   scn_gen_finish_kernel   K4 + K5: dB (utility.cpp:86-98), fftshift-indexed mask, strict > threshold, hit records into the
 //                           buffer's region (process.cpp:46-62)
 //
-// Sizes that are NOT powers of two (16 <= N <= 32768) use the same kernels around Bluestein's identity
+// Sizes that are NOT powers of two (16 <= N < 65536) use the same kernels around Bluestein's identity
 //   X[k] = w[k] * sum_n (x[n] w[n]) conj(w)[k - n],   w[n] = exp(-i pi n^2 / N):
 // a cyclic convolution of length M = the power of two >= 2N - 1, i.e. load (x window w, zero-padded to M) -> FFT_M ->
 // multiply by the precomputed FFT_M of the chirp filter (scaled by 1/M) and conjugate -> FFT_M again (an inverse transform
@@ -257,7 +257,7 @@ hipError_t launch_load(bool dc, const ScnGenericArgs &a, int grid, hipStream_t s
 }  // namespace
 
 bool scn_generic_size_supported(uint32_t n) { return n >= 16u && n <= 65536u && (n & (n - 1u)) == 0u; }
-bool scn_bluestein_size_supported(uint32_t n) { return n >= 16u && n <= 32768u && (n & (n - 1u)) != 0u; }
+bool scn_bluestein_size_supported(uint32_t n) { return n >= 16u && n < 65536u && (n & (n - 1u)) != 0u; }  // transform length <= 131072
 
 hipError_t scn_launch_generic(int kind, bool dc, bool hits, const ScnGenericArgs &a, int num_cus, hipStream_t s) {
   if (a.n_buffers == 0) return hipSuccess;

@@ -56,7 +56,7 @@ def test_loads_and_reports_errors(built_lib):
     assert L.scn_plan_destroy(None) == capi.OK
     d.struct_size = C.sizeof(capi.PlanDesc)
     d.sample_rate, d.sample_kind, d.max_batch = 8000000, capi.KIND_FLOAT_COMPLEX, 4
-    for bad in (8, 15, 40000, 131072):                                     # too small, too large (40000 is not a power of two)
+    for bad in (8, 15, 65537, 131072):                                     # too small, too large
         d.n = bad
         assert L.scn_plan_create(C.byref(d), C.byref(h)) == capi.E_INVALID and b"16 to 65536" in L.scn_last_error()
     d.n, d.sample_kind = 4096, 9

@@ -333,13 +333,14 @@ def test_generic_sizes_vs_oracle(torch_cuda, oracle_mod, n, kind, enob, dc):
 @pytest.mark.parametrize("n,kind,enob,dc", [
     (30, capi.KIND_FLOAT_COMPLEX, 12, False), (1000, capi.KIND_SHORT_COMPLEX, 12, True), (1023, capi.KIND_FLOAT_COMPLEX, 12, False),
     (3000, capi.KIND_BYTE_COMPLEX, 8, False), (4097, capi.KIND_SHORT, 12, True), (6000, capi.KIND_FLOAT_COMPLEX, 12, False),
-    (17, capi.KIND_SHORT_COMPLEX, 12, False), (20000, capi.KIND_BYTE_COMPLEX, 8, False), (32767, capi.KIND_FLOAT_COMPLEX, 12, False),   # the ends of the range
+    (17, capi.KIND_SHORT_COMPLEX, 12, False), (20000, capi.KIND_BYTE_COMPLEX, 8, False), (32767, capi.KIND_FLOAT_COMPLEX, 12, False),
+    (65535, capi.KIND_SHORT_COMPLEX, 12, False),   # the ends of the range (65535: a 131072-point transform)
 ])
 def test_non_power_of_two_sizes_vs_oracle(torch_cuda, oracle_mod, n, kind, enob, dc):
     """--count is any integer in the reference (FFTW plans it, fft.cpp:4-11).  Sizes that are not powers of two run
     Bluestein's algorithm over the staged path; the oracle evaluates the DFT sum itself in double for them.  Odd sizes
     exercise the general form of the mask: j = (i + N/2) % N with an integer N/2 (process.cpp:45-47)."""
-    nb = 24 if n < 8000 else 3      # (the oracle's direct DFT is O(N^2) per buffer)
+    nb = 24 if n < 8000 else 3 if n < 40000 else 2      # (the oracle's direct DFT is O(N^2) per buffer)
     x = synth.cfloat_batch(n, nb, seed=80 + n % 1000, sigma=0.1)
     raw = synth.quantize(x, kind) if kind != capi.KIND_FLOAT_COMPLEX else x
     if dc:

@@ -54,6 +54,29 @@ __device__ __forceinline__ void radix4_d(cd &x0, cd &x1, cd &x2, cd &x3) {
   x3 = cd{t1.x - t3.y, t1.y + t3.x};  // t1 + i*t3
 }
 
+// a * (1 - i) * h  and  a * (-1 - i) * h  (W16^2, W16^6 with h = sqrt(1/2))
+__device__ __forceinline__ cd mul_w2_d(cd a, double h) { return cd{(a.x + a.y) * h, (a.y - a.x) * h}; }
+__device__ __forceinline__ cd mul_w6_d(cd a, double h) { return cd{(a.y - a.x) * h, -(a.x + a.y) * h}; }
+// In-register 16-point forward DFT (radix 4 x 4), in double: on return X[k] sits in v[4 (k & 3) + (k >> 2)] (OUT16 of
+// scn_device.h, whose float fft16 this mirrors).
+__device__ __forceinline__ void fft16_d(cd v[16]) {
+  const double C1 = 0.92387953251128675613, S1 = 0.38268343236508977173, H = 0.70710678118654752440;
+#pragma unroll
+  for (int n0 = 0; n0 < 4; n0++) radix4_d(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
+  // v[n0 + 4 k0] *= W16^(n0 k0)
+  v[5] = cmul_d(v[5], scn_v2d{C1, -S1});                 // W^1
+  v[9] = mul_w2_d(v[9], H);                              // W^2
+  v[13] = cmul_d(v[13], scn_v2d{S1, -C1});               // W^3
+  v[6] = mul_w2_d(v[6], H);                              // W^2
+  v[10] = cd{v[10].y, -v[10].x};                         // W^4 = -i
+  v[14] = mul_w6_d(v[14], H);                            // W^6
+  v[7] = cmul_d(v[7], scn_v2d{S1, -C1});                 // W^3
+  v[11] = mul_w6_d(v[11], H);                            // W^6
+  v[15] = cmul_d(v[15], scn_v2d{-C1, S1});               // W^9
+#pragma unroll
+  for (int k0 = 0; k0 < 4; k0++) radix4_d(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
+}
+
 template <int KIND>
 struct GenRaw;
 template <>
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(256) void scn_gen_stage_kernel(ScnGenericArgs a, co
                                                             uint32_t log2ns) {
   // every quantity is a power of two: shifts and masks, no integer division (the first version divided: 10 ms per
   // 512 x 65536-point batch instead of ~2)
-  constexpr uint32_t LR = R == 4 ? 2u : 1u;
+  constexpr uint32_t LR = R == 16 ? 4u : R == 4 ? 2u : 1u;
   const uint32_t n = a.m, log2n = a.log2m, log2per = log2n - LR, per = 1u << log2per, ns = 1u << log2ns;  // the transform length
   const size_t total = (size_t)a.n_buffers << log2per;
   for (size_t g = (size_t)blockIdx.x * 256u + threadIdx.x; g < total; g += (size_t)gridDim.x * 256u) {
@@ -183,7 +206,19 @@ __global__ __launch_bounds__(256) void scn_gen_stage_kernel(ScnGenericArgs a, co
     const uint32_t k = j & (ns - 1u);
     const uint32_t step = n >> (LR + log2ns);  // twiddle index stride in the W_N table
     const uint32_t j0 = ((j >> log2ns) << (log2ns + LR)) + k;
-    if (R == 4) {
+    if constexpr (R == 16) {
+      cd v[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) v[r] = from_v2d(x[j + r * per]);
+      if (k) {
+        const scn_v2d *tw = static_cast<const scn_v2d *>(a.twiddle);
+#pragma unroll
+        for (int r = 1; r < 16; r++) v[r] = cmul_d(v[r], tw[r * k * step]);   // r k step < n: no wrap
+      }
+      fft16_d(v);
+#pragma unroll
+      for (int r = 0; r < 16; r++) y[j0 + r * ns] = to_v2d(v[4 * (r & 3) + (r >> 2)]);
+    } else if constexpr (R == 4) {
       cd v0 = from_v2d(x[j]), v1 = from_v2d(x[j + per]), v2 = from_v2d(x[j + 2 * per]), v3 = from_v2d(x[j + 3 * per]);
       if (k) {
         const scn_v2d *tw = static_cast<const scn_v2d *>(a.twiddle);
@@ -282,7 +317,8 @@ hipError_t scn_launch_generic(int kind, bool dc, bool hits, const ScnGenericArgs
     return (int)(b < cap ? b : cap);
   };
   // forward transform of length m from `from`, ping-ponging with the other work buffer; returns where the result is:
-  // one radix-2 stage first when log2 m is odd, radix 4 from there on
+  // log2 m = 4 s + r: one radix-2 stage if r is odd, one radix-4 stage if r >= 2, radix 16 from there on -- every stage is a
+  // pass over the batch in double (32 B per point), so the fewer the better: 65536 points in 4 passes, 512 in 3
   auto transform = [&](scn_v2d *from, scn_v2d *other) -> scn_v2d * {
     scn_v2d *src = from, *dst = other;
     uint32_t log2ns = 0;
@@ -291,9 +327,14 @@ hipError_t scn_launch_generic(int kind, bool dc, bool hits, const ScnGenericArgs
       log2ns += 1;
       std::swap(src, dst);
     }
-    while (log2ns < a.log2m) {
+    if (a.log2m & 2u) {
       hipLaunchKernelGGL((scn_gen_stage_kernel<4>), dim3(blocks_for((size_t)a.m / 4 * a.n_buffers)), dim3(256), 0, s, a, src, dst, log2ns);
       log2ns += 2;
+      std::swap(src, dst);
+    }
+    while (log2ns < a.log2m) {
+      hipLaunchKernelGGL((scn_gen_stage_kernel<16>), dim3(blocks_for((size_t)a.m / 16 * a.n_buffers)), dim3(256), 0, s, a, src, dst, log2ns);
+      log2ns += 4;
       std::swap(src, dst);
     }
     return src;

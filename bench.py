@@ -345,9 +345,9 @@ def kernel_name(n, kind, hits=True):
     h = "true" if hits else "false"
     if n == 8192:
         return f"scn_fft8k_kernel<{k}, false, {h}>"
-    if n == 16384 and kind != "cfloat":  # the wide form, integer formats only (scn_kernels.hip, launch_16k)
+    if n == 16384:  # the wide form generalised to M2 = 64 (scn_kernels.hip, launch_16k)
         return f"scn_fft16k_kernel<{k}, false, {h}>"
-    if n in (1024, 2048, 4096, 16384):
+    if n in (1024, 2048, 4096):
         return f"scn_fft_kernel<{n // 256}, {k}, false, {h}>"
     return "scn_gen_load_kernel + scn_gen_stage_kernel x log4(n) + scn_gen_finish_kernel (the staged path, scn_generic.hip)"
 

@@ -667,6 +667,15 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #ifndef SCN_WIDE_8192
 #define SCN_WIDE_8192 1
 #endif
+#ifndef SCN_16K_FLOAT_PFN
+#define SCN_16K_FLOAT_PFN 8
+#endif
+#ifndef SCN_16K_INT_PFN
+#define SCN_16K_INT_PFN 16
+#endif
+#ifndef SCN_WIDE_16384_FLOAT
+#define SCN_WIDE_16384_FLOAT 1  // float input at 16384 points in the wide form with a partial prefetch (0: scn_fft_kernel<64>)
+#endif
 #ifndef SCN_WIDE_16384
 #define SCN_WIDE_16384 1  // 16384 points: 512 threads x 32 points with a register prefetch instead of scn_fft_kernel<64>
 #endif
@@ -727,6 +736,11 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
   // loads of two samples instead of 32 of one (16 / 8 / 4 bytes per lane) and exchange 1 is written in 16 ds_write_b128
   // instead of 32 ds_write_b64.  !PAIR: tau = t and t + 256 (the first form).
   constexpr bool PAIR = SCN_8K_PAIR != 0;
+  // how many of a buffer's 16 two-sample loads are prefetched during the previous buffer's passes (in three groups); the rest
+  // is fetched at the top of its own iteration.  16 everywhere except float input at 16384 points, whose 64 prefetch registers
+  // do not fit beside the lane-pair step of pass 3 (22 VGPRs spilled, slower than the 1024-thread form): there 12 (48 registers)
+  constexpr int PFN = M2 != 64 ? 16 : KIND == SCN_K_FLOAT_COMPLEX ? SCN_16K_FLOAT_PFN : SCN_16K_INT_PFN;
+  constexpr int PF0 = PFN == 16 ? 6 : PFN / 3 + 1, PF1 = PFN == 16 ? 11 : 2 * PFN / 3 + 1;
   const uint32_t tau0 = PAIR ? 2u * t : t, tau1 = PAIR ? 2u * t + 1u : t + T;
 
   // first buffer's samples first: raw[2a + h] = x[512 a + tau_h]
@@ -746,7 +760,7 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
   if (blockIdx.x < args.n_buffers) {
     __amdgpu_buffer_rsrc_t r0 =
         make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
-    load_group(r0, 0, 16);
+    load_group(r0, 0, PFN);
   }
   // persistent constants: pass-1 twiddles of both virtual threads (table rows of TV), window taps
   cf tw1a[16], tw1b[16];
@@ -805,6 +819,11 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
   while (buf < args.n_buffers) {
     SCN_STAMP(0);  // previous buffer's hit recording + loop back
     const bool more = nxt < args.n_buffers;
+    if (PFN < 16) {  // the part of this buffer that was not prefetched (float input at 16384 points: registers)
+      const __amdgpu_buffer_rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N),
+                                                  SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+      load_group(rc, PFN, 16);
+    }
     // ---- K1 + K2 ----
     int dc_re = 0, dc_im = 0;
     if (DC) {
@@ -847,7 +866,7 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
         make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N),
                   (more && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
     auto prefetch = [&](int a_lo, int a_hi) { load_group(rn, a_lo, a_hi); };  // groups of inputs a: two samples each
-    prefetch(0, 6);
+    prefetch(0, PF0);
     SCN_STAMP(2);  // issue of the first group of the next buffer's loads
 
     // ---- pass 1: virtual threads t and t + 256 ----
@@ -890,7 +909,7 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
         lds_hits[par ^ 1] = 0;
       }
     }
-    prefetch(6, 11);
+    prefetch(PF0, PF1);
 
     // ---- pass 2: virtual threads (p2, c2) and (p2 + 8, c2) ----
 #pragma unroll
@@ -909,7 +928,7 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
     SCN_STAMP(5);  // exchange-1 reads + pass 2 + twiddles (+ second load group)
     __syncthreads();  // every exchange-1 read done before the area is re-used
     SCN_STAMP(6);  // barrier 2
-    prefetch(11, 16);
+    prefetch(PF1, PFN);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       w2[q * 16] = to_v2f(va[OUT16(q)]);
@@ -1360,10 +1379,15 @@ static hipError_t launch_16k_kind(const ScnFftArgs &a, bool dc, bool hits, int n
 }
 static hipError_t launch_16k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
-    // float input: the 64 prefetch registers leave the wide form nothing to spare at 16384 points (22 VGPRs spill; deriving
-    // the second twiddle set from the first, W_N^(tau+1)p = W_N^(tau p) W_N^p, did not cure it): 113 us per 2048-buffer launch
-    // against 111 for scn_fft_kernel<64>, which therefore stays; the integer formats: 94.8 -> 88.5 us (scripts/wide16k_check.sh)
+    // us per 2048-buffer launch, scn_fft_kernel<64> -> wide form: integer formats 94.8 -> 88.5 (scripts/wide16k_check.sh); float
+    // input 111.5 -> 101.8 with HALF of a buffer prefetched (its 64 prefetch registers do not fit beside the lane-pair step:
+    // 113 us with all 16 two-sample loads prefetched and 22 VGPRs spilled; 0 / 4 / 6 / 8 / 10 / 12 / 14 / 16 prefetched:
+    // 110.9 / 107.3 / 105.9 / 101.8 / 105.7 / 108.5 / 107.1 / 113.1, scripts/wide16k_float_check.sh)
+#if SCN_WIDE_16384_FLOAT
+    case SCN_K_FLOAT_COMPLEX: return launch_16k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream, stop);
+#else
     case SCN_K_FLOAT_COMPLEX: return launch_size<64>(kind, false, hits, args, num_cus, stream, stop);
+#endif
     case SCN_K_SHORT_COMPLEX: return launch_16k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream, stop);
     case SCN_K_SHORT: return launch_16k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream, stop);
     case SCN_K_BYTE_COMPLEX: return launch_16k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream, stop);

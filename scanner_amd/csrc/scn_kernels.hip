@@ -670,6 +670,9 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #ifndef SCN_16K_FLOAT_PFN
 #define SCN_16K_FLOAT_PFN 8
 #endif
+#ifndef SCN_8K_FLOAT_PFN
+#define SCN_8K_FLOAT_PFN 16  // (8192-pt cfloat, 16 / 14 / 12 / 8 prefetched: 77.5 / 76.7 / 77.5 / 77.7 us -- flat)
+#endif
 #ifndef SCN_16K_INT_PFN
 #define SCN_16K_INT_PFN 16
 #endif
@@ -739,7 +742,7 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
   // how many of a buffer's 16 two-sample loads are prefetched during the previous buffer's passes (in three groups); the rest
   // is fetched at the top of its own iteration.  16 everywhere except float input at 16384 points, whose 64 prefetch registers
   // do not fit beside the lane-pair step of pass 3 (22 VGPRs spilled, slower than the 1024-thread form): there 12 (48 registers)
-  constexpr int PFN = M2 != 64 ? 16 : KIND == SCN_K_FLOAT_COMPLEX ? SCN_16K_FLOAT_PFN : SCN_16K_INT_PFN;
+  constexpr int PFN = M2 != 64 ? (KIND == SCN_K_FLOAT_COMPLEX ? SCN_8K_FLOAT_PFN : 16) : KIND == SCN_K_FLOAT_COMPLEX ? SCN_16K_FLOAT_PFN : SCN_16K_INT_PFN;
   constexpr int PF0 = PFN == 16 ? 6 : PFN / 3 + 1, PF1 = PFN == 16 ? 11 : 2 * PFN / 3 + 1;
   const uint32_t tau0 = PAIR ? 2u * t : t, tau1 = PAIR ? 2u * t + 1u : t + T;
 

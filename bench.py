@@ -520,38 +520,56 @@ def main():
 
     step, drain, main_state = make_loop(plan, False)
 
+    # The driver times as few as 20 steps (1.5 ms), so everything that is not a step stays out of the region AND out of the gap in
+    # front of it: the events exist (a torch event creates its HIP event at the first record), no stream-context switches, no
+    # garbage collection inside -- and nothing but the contract's barrier + synchronize between the last warm-up step and t0: the
+    # GPU leaves its power state within milliseconds of idling (a gc.collect() in that gap made the first launches of the region
+    # 90-110 us instead of 74).
+    import gc
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(ext)
+    ev1.record(ext)
+    gc.collect()
+    gc.disable()
     # settle: the same steps, untimed and reported, until the GPU is out of its idle power state
+    # At least args.settle seconds, then on in chunks of 200 steps until a chunk runs within 2 % of the fastest one seen (the first
+    # process on a freshly leased box ran its launches at 88 us instead of 74 after the fixed 0.4 s), at most 3 s in all.
     settle_steps = 0
     if args.settle > 0:
         t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < args.settle:
-            step(settle_steps)
-            settle_steps += 1
-        drain()
-        torch.cuda.synchronize()
+        best = None
+        while True:
+            tc = time.perf_counter()
+            for _ in range(200):
+                step(settle_steps)
+                settle_steps += 1
+            drain()
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            chunk = now - tc
+            best = chunk if best is None else min(best, chunk)
+            if now - t_settle >= 3.0 or (now - t_settle >= args.settle and chunk <= 1.02 * best):
+                break
     for k in range(args.warmup):
         step(k)
     drain()
-    torch.cuda.synchronize()
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    launch0 = main_state["launch"]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    launch0 = main_state["launch"]
-    with torch.cuda.stream(ext):
-        ev0.record(ext)
+    ev0.record(ext)
     for k in range(args.steps):
         step(k)
     main_state["flush"]()
-    with torch.cuda.stream(ext):
-        ev1.record(ext)
+    ev1.record(ext)
     drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     launches = main_state["launch"] - launch0
     kernel_ms = ev0.elapsed_time(ev1) / launches  # average launch-to-launch duration on the plan's stream
 
@@ -750,7 +768,7 @@ def main():
                              if c4 else
                              f"{config_tag}: {n}-pt FFT+power+threshold, batch {nb} {args.kind} buffers per GPU resident in HBM, ") +
                             f"Blackman-Harris, fs={FS} Hz, threshold {args.threshold} dB; frequency table range-sharded over "
-                            f"{world} GPU(s); {settle_steps} untimed settle steps ({args.settle} s) before the {args.warmup} warm-up steps",
+                            f"{world} GPU(s); {settle_steps} untimed settle steps (>= {args.settle} s, until the launch time is steady) before the {args.warmup} warm-up steps",
                 "n": n, "batch_per_gpu": shard, "buffers_per_launch": nb, "sample_kind": args.kind,
                 "parallelism": f"table-shard x{world}", "rotating_batches": R, "footprint_MiB": round(R * step_bytes / 2**20),
             },

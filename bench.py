@@ -578,9 +578,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = tt.tolist()
 
+    # the extra legs (reported beside the contract leg, never in `value`) time their own number of steps: a 20-step region is
+    # mostly its own start and end, and these legs exist to show steady-state rates
+    leg_steps = max(args.steps, 200)
+
     def timed_leg(pl, want_records, warm, zero_copy=False, spectrum=True):
         st, dr, state = make_loop(pl, want_records, zero_copy, spectrum)
-        for k in range(warm):
+        for k in range(max(warm, 50)):
             st(k)
         dr()
         torch.cuda.synchronize()
@@ -589,7 +593,7 @@ def main():
         if world > 1:
             dist.barrier()
         t2 = time.perf_counter()
-        for k in range(args.steps):
+        for k in range(leg_steps):
             st(k)
         dr()
         torch.cuda.synchronize()
@@ -622,12 +626,12 @@ def main():
             _, h1, _ = plan.collect(0, want_power=False, want_hits=True, hits_out=rec_buf)
             samples_us.append((time.perf_counter() - tc) * 1e6)
         collect_us = float(np.median(samples_us))
-        records = {"value": round(world * shard * n * args.steps / el3 / 1e6, 1), "unit": "Msamples/s",
-                   "ms_per_step": round(el3 / args.steps * 1e3, 5), "hits_per_step": round(nh / max(args.steps, 1), 1),
+        records = {"value": round(world * shard * n * leg_steps / el3 / 1e6, 1), "unit": "Msamples/s", "steps": leg_steps,
+                   "ms_per_step": round(el3 / leg_steps * 1e3, 5), "hits_per_step": round(nh / max(leg_steps, 1), 1),
                    "collect_with_records_us": round(collect_us, 1), "collect_with_records_us_min": round(min(samples_us), 1),
                    "collect_hits": int(len(h1)),
                    "collect_call_avg_us_in_loop": round(st3["collect_s"] / max(st3["collects"], 1) * 1e6, 1),
-                   "zero_copy_view": {"value": round(world * shard * n * args.steps / el4 / 1e6, 1), "ms_per_step": round(el4 / args.steps * 1e3, 5),
+                   "zero_copy_view": {"value": round(world * shard * n * leg_steps / el4 / 1e6, 1), "ms_per_step": round(el4 / leg_steps * 1e3, 5),
                                       "collect_plus_view_avg_us_in_loop": round(st4["collect_s"] / max(st4["collects"], 1) * 1e6, 1),
                                       "note": "the same loop reading the records in place through scn_hits_view (no copy into a caller buffer)"},
                    "note": "same steps, scn_collect returns the ordered, completed scn_hit records (built on the GPU) every step; "
@@ -644,9 +648,9 @@ def main():
                      flags=capi.OUT_SPECTRUM | capi.OUT_HITS | capi.PLAN_OVERLAP_SLOTS)
         el2, _ = timed_leg(plan2, False, max(args.warmup, 200))
 
-        overlap = {"value": round(world * shard * n * args.steps / el2 / 1e6, 1), "unit": "Msamples/s",
-                   "ms_per_step": round(el2 / args.steps * 1e3, 5),
-                   "aggregate_algorithmic_GBs_per_gpu": round(shard * n * algo_bytes_per_sample * args.steps / el2 / 1e9, 1),
+        overlap = {"value": round(world * shard * n * leg_steps / el2 / 1e6, 1), "unit": "Msamples/s", "steps": leg_steps,
+                   "ms_per_step": round(el2 / leg_steps * 1e3, 5),
+                   "aggregate_algorithmic_GBs_per_gpu": round(shard * n * algo_bytes_per_sample * leg_steps / el2 / 1e9, 1),
                    "plan_flags": "SCN_OUT_SPECTRUM|SCN_OUT_HITS|SCN_PLAN_OVERLAP_SLOTS",
                    "note": "same steps, slots on two streams so consecutive launches overlap; not used for value/roofline"}
         plan2.close()
@@ -659,9 +663,9 @@ def main():
                      flags=capi.OUT_HITS)
         el5, _ = timed_leg(plan3, False, min(args.warmup, 20), spectrum=False)
         in_bytes = algo_bytes_per_sample - 4
-        hits_only = {"value": round(world * shard * n * args.steps / el5 / 1e6, 1), "unit": "Msamples/s",
-                     "ms_per_step": round(el5 / args.steps * 1e3, 5), "algorithmic_bytes_per_sample": in_bytes,
-                     "frac_of_hbm_peak_wall": round(shard * n * in_bytes * args.steps / el5 / 1e9 / HBM_PEAK_GBS, 4),
+        hits_only = {"value": round(world * shard * n * leg_steps / el5 / 1e6, 1), "unit": "Msamples/s", "steps": leg_steps,
+                     "ms_per_step": round(el5 / leg_steps * 1e3, 5), "algorithmic_bytes_per_sample": in_bytes,
+                     "frac_of_hbm_peak_wall": round(shard * n * in_bytes * leg_steps / el5 / 1e9 / HBM_PEAK_GBS, 4),
                      "plan_flags": "SCN_OUT_HITS", "note": "wall clock over the same steps; not used for value/roofline"}
         plan3.close()
 

@@ -566,9 +566,9 @@ def main():
     ev1.record(ext)
     drain()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0  # this rank's K steps, from the common start; the job's time is the MAX over ranks (below)
     if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        dist.barrier()                  # the closing bracket: nobody goes on before everybody is done
     gc.enable()
     launches = main_state["launch"] - launch0
     kernel_ms = ev0.elapsed_time(ev1) / launches  # average launch-to-launch duration on the plan's stream

@@ -707,6 +707,7 @@ def main():
 
         def gather_job():
             try:
+                torch.cuda.set_device(dev)  # (the current device is per thread)
                 with sweep.HitGather(dev) as g:
                     res["hits"], res["per_rank"] = g.gather(hits)
                 res["info"] = {"transport": "scn_gather_hits (RCCL: ncclAllGather counts + grouped ncclSend/ncclRecv to rank 0)"}

@@ -7,4 +7,11 @@ bash scripts/prof.sh ${TAG}_c2 > /dev/null 2>&1
 bash scripts/prof.sh ${TAG}_c3 --n 8192 --kind int16 --batch 4096 > /dev/null 2>&1
 bash scripts/prof.sh ${TAG}_c4shape --batch 2048 > /dev/null 2>&1
 SCN_PROF_KERNEL=scn_welch bash scripts/prof.sh ${TAG}_c5 --welch > /dev/null 2>&1
+if [ -n "$SCN_PROF_MORE" ]; then   # the other wire formats and sizes (not BASELINE launch shapes)
+  bash scripts/prof.sh ${TAG}_n4096int16 --kind int16 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n4096int8 --kind int8 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n8192cfloat --n 8192 --batch 4096 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n16384cfloat --n 16384 --batch 2048 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n16384int16 --n 16384 --batch 2048 --kind int16 > /dev/null 2>&1
+fi
 for c in c2 c3 c4shape c5; do echo "=== $c"; cat gpurun_out/prof_${TAG}_$c/summary.txt; done

@@ -196,7 +196,7 @@ def welch_main(args):
         achieved = algo / (ms * 1e-3) / 1e9
         prof = {}
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "measured_shapes.json"))).get(f"welch/{N}/{K}/{npsd}", {})
+            prof = _tracked(f"welch/{N}/{K}/{npsd}")
         except Exception:
             pass
         emit({
@@ -340,24 +340,39 @@ def dry_run_main(args):
         dist.destroy_process_group()
 
 
-def kernel_name(n, kind, hits=True):
+def kernel_name(n, kind, hits=True, spectrum=True):
+    """the kernel's name as rocprofv3 prints it: template arguments <.., KIND, DC, HITS, SPEC> (scn_kernels.hip)"""
     k = {"cfloat": "SCN_K_FLOAT_COMPLEX", "int16": "SCN_K_SHORT_COMPLEX", "int8": "SCN_K_BYTE_COMPLEX"}[kind]
-    h = "true" if hits else "false"
+    h, sp = ("true" if hits else "false"), ("true" if spectrum else "false")
     if n == 8192:
-        return f"scn_fft8k_kernel<{k}, false, {h}>"
-    if n == 16384:  # the wide form generalised to M2 = 64 (scn_kernels.hip, launch_16k)
-        return f"scn_fft16k_kernel<{k}, false, {h}>"
+        return f"scn_fft8k_kernel<{k}, false, {h}, {sp}>"
+    if n == 16384:  # the wide form generalised to M2 = 64 (scn_kernels.hip, launch_16k); no hits-only specialisation at this size
+        return f"scn_fft16k_kernel<{k}, false, {h}, true>"
     if n in (1024, 2048, 4096):
-        return f"scn_fft_kernel<{n // 256}, {k}, false, {h}>"
+        return f"scn_fft_kernel<{n // 256}, {k}, false, {h}, {sp}>"
     return "scn_gen_load_kernel + scn_gen_stage_kernel x log4(n) + scn_gen_finish_kernel (the staged path, scn_generic.hip)"
 
 
 def tracked_profile(n, kind, nb):
     """Numbers that come from their own rocprofv3 passes (scripts/prof.sh -> profiles/measured_shapes.json): the PMC
     traffic per launch and the kernel-trace average duration; only valid for the launch shape they were collected on."""
+    return _tracked(f"{n}/{kind}/{nb}")
+
+
+def _tracked(key):
+    """An entry of profiles/measured_shapes.json, or -- if it was taken on ANOTHER build of the kernels than the one running
+    (scanner_amd.build.source_hash over the HIP sources) -- only the note that it is stale: the live line then carries
+    null traffic / rocprof fields instead of another build's numbers."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "measured_shapes.json")))
-        return j.get(f"{n}/{kind}/{nb}", {})
+        from scanner_amd import build as _build
+
+        e = json.load(open(os.path.join(ROOT, "profiles", "measured_shapes.json"))).get(key, {})
+        if not e:
+            return {}
+        now = _build.source_hash()
+        if e.get("build") != now:
+            return {"stale": f"{e.get('source')} was taken on build {e.get('build')}, this is {now}"}
+        return e
     except Exception:
         return {}
 
@@ -790,10 +805,15 @@ def main():
                 # (a separate run: profiles/measured_shapes.json, null if this shape was not profiled)
                 "measured_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),  # torch tensor copy, 1 GiB, read + write bytes
                 "frac_of_measured_copy": None if copy_gbs is None else round(achieved / copy_gbs, 4),
+                # `frac` IS frac_event: algorithmic bytes / the average launch-to-launch time of the timed steps measured with HIP
+                # events on the plan's stream / 8 TB/s.  frac_kernel_rocprof divides by the kernel's own begin-to-end average
+                # from profiles/<traffic_source> instead (same build only, else null), frac_wall by host wall time per step.
+                "frac_is": "frac_event",
                 "frac_event": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_wall": round(algo_bytes_per_launch / (wall_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "frac_kernel_rocprof": (round(algo_bytes_per_launch / (prof["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                                         if prof.get("kernel_avg_us") else None),
+                "traffic_source": prof.get("source"), "traffic_build": prof.get("build"), "traffic_stale": prof.get("stale"),
             },
             "final_sweep_hits": int(len(all_hits)),
             "final_sweep_collect_gather_ms": round(gather_ms, 3),

@@ -215,8 +215,18 @@ int scn_frequency_table(uint32_t sample_rate, double start, double stop,
  *                        other ranks by any means (the launcher's store, a file, MPI ...)
  *   scn_comm_create      every rank, collectively (ncclCommInitRank) on its device
  *   scn_gather_hits      collective: local = this rank's ordered list (host memory); on the root `all` receives
- *                        min(*n_total, all_cap) records (SCN_E_TRUNCATED if fewer than all), per_rank[world_size]
- *                        the counts; both may be NULL elsewhere.  *n_total is set on every rank.
+ *                        min(*n_total, all_cap) records (SCN_E_TRUNCATED if fewer than all -- nothing is lost, the rest
+ *                        is read with scn_gather_fetch), per_rank[world_size] the counts; both may be NULL elsewhere, and
+ *                        `all` may be NULL on the root too (learn *n_total first, then fetch into an exact-size array:
+ *                        the records are exchanged ONCE either way).  *n_total is set on every rank.  A rank that cannot
+ *                        take part (allocation failure, bad arguments) still runs the exchange and says so in it: every
+ *                        rank then returns an error and nothing is transferred -- no rank is left waiting.
+ *   scn_gather_hits_device  the same with this rank's part taken from a collected slot of its plan -- the ordered list
+ *                        the compaction kernel left in device memory (scn_hits.hip) -- instead of a host array: no
+ *                        device->host->device round trip in front of the send.  The slot must have been collected
+ *                        (scn_collect) and hold at most max_hits records.
+ *   scn_gather_fetch     NOT collective, root only: records [first, first + cap) of the last gathered list, from the
+ *                        root's device copy
  *   scn_gather_layout    host-only helper: offsets[r] = first index of rank r's records in the gathered list,
  *                        offsets[world_size] = total
  * RCCL is loaded on first use (dlopen), not at link time.
@@ -228,6 +238,9 @@ int scn_comm_create(const void *id, int rank, int world_size, int device_id, scn
 int scn_comm_destroy(scn_comm *comm);
 int scn_gather_hits(scn_comm *comm, const scn_hit *local, uint32_t n_local, uint32_t root, scn_hit *all,
                     uint64_t all_cap, uint64_t *n_total, uint32_t *per_rank);
+int scn_gather_hits_device(scn_comm *comm, scn_plan *plan, int slot, uint32_t root, scn_hit *all, uint64_t all_cap,
+                           uint64_t *n_total, uint32_t *per_rank);
+int scn_gather_fetch(scn_comm *comm, uint64_t first, scn_hit *out, uint64_t cap, uint64_t *n_written);
 int scn_gather_layout(const uint32_t *per_rank, uint32_t world_size, uint64_t *offsets);
 
 /* HackRFSource::interpolateSamples (hackRFSource.cpp:186-222), the in-band header of HackRF

@@ -23,6 +23,18 @@ def hipcc():
     return exe
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the HIP sources and headers the library is built from: names the BUILD a profile
+    was taken on (profiles/measured_shapes.json) so that bench.py never prints another build's traffic as this one's."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

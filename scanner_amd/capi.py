@@ -102,6 +102,8 @@ SYMBOLS = {
     "scn_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "scn_comm_destroy": (C.c_int, [_vp]),
     "scn_gather_hits": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64), _vp]),
+    "scn_gather_hits_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64), _vp]),
+    "scn_gather_fetch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "scn_gather_layout": (C.c_int, [_vp, C.c_uint32, _vp]),
     "scn_hackrf_sweep_fixup": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double),
                                          C.POINTER(C.c_uint32)]),
@@ -132,6 +134,8 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("SCN_LIB") and not hasattr(L, name):
+                continue  # an experiment build (SCN_LIB) of an older tree may lack newer entry points; the product library may not
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

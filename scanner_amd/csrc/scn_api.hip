@@ -148,6 +148,10 @@ struct scn_plan {
   float *d_window = nullptr;
   scn_v2f *d_twiddle = nullptr;
   scn_v2f *d_tw1_table = nullptr;  // [15][n/16], ScnFftArgs::tw1_table
+  // scn_convert_raw's device staging (the capture writer calls it per record): plan-owned, grown on demand, never per call
+  void *d_conv_in = nullptr;
+  scn_v2f *d_conv_out = nullptr;
+  uint32_t conv_cap = 0;  // buffers both hold
   Slot slot[SCN_NUM_SLOTS];
 };
 
@@ -224,7 +228,9 @@ int check_slot(scn_plan *p, int slot) {
   return SCN_OK;
 }
 
-int ensure_slot_outputs(scn_plan *p, Slot &s) {
+// `gen`: the generation of hit regions / counts the coming submit writes (allocated when first used: a plan that only ever
+// drives one slot, or submits once per slot, holds one or two of the four region sets -- 201 MB each for the C2 plan)
+int ensure_slot_outputs(scn_plan *p, Slot &s, uint32_t gen) {
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   if (p->d.mode == SCN_MODE_TIME_DOMAIN) {
     if (!s.h_td) SCN_HIP(hipHostMalloc(&s.h_td, sizeof(float) * 2 * p->d.max_batch, hipHostMallocDefault));
@@ -233,7 +239,8 @@ int ensure_slot_outputs(scn_plan *p, Slot &s) {
   if (p->d.flags & SCN_OUT_HITS) {
     // every resource under its own check: a failed allocation leaves a state the next call completes or fails on again
     const uint32_t mb = p->d.max_batch;
-    for (int g = 0; g < 2; g++) {
+    {
+      const uint32_t g = gen & 1u;
       if (!s.d_hits[g]) SCN_HIP(hipMalloc(&s.d_hits[g], sizeof(ScnDevHit) * (size_t)p->hit_region * mb));
       if (!s.d_buf_hits[g]) SCN_HIP(hipMalloc(&s.d_buf_hits[g], sizeof(uint32_t) * mb));
       if (!s.list_done[g]) SCN_HIP(hipEventCreateWithFlags(&s.list_done[g], hipEventDisableTiming));
@@ -312,7 +319,8 @@ int fetch_list(scn_plan *p, Slot &s, uint32_t count) {
 
 int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const double *fc, const uint64_t *seq,
                   float *d_power) {
-  int st = ensure_slot_outputs(p, s);
+  const bool will_flip = p->d.mode != SCN_MODE_TIME_DOMAIN && (p->d.flags & SCN_OUT_HITS) != 0 && nb != 0;
+  int st = ensure_slot_outputs(p, s, will_flip ? s.gen ^ 1u : s.gen);
   if (st) return st;
   const uint32_t n = p->d.n;
   if (p->d.mode == SCN_MODE_TIME_DOMAIN) {
@@ -362,6 +370,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.n_buffers = nb;
   a.scale = p->scale;
   a.threshold = p->d.threshold;
+  a.p_lo = scn_hit_prefilter(p->d.threshold);
   a.dc_ignore = p->d.dc_ignore_bins;
   a.i_lo = p->i_lo;
   a.i_hi = p->i_hi;
@@ -417,7 +426,8 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     ga.per_buffer_hits = a.per_buffer_hits;
     SCN_HIP(scn_launch_generic((int)p->d.sample_kind, p->d.correct_dc != 0, hits, ga, p->num_cus, s.stream));
   } else {
-    SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, a, p->fft_cus, s.stream, in_packet ? after : nullptr));
+    // (a hits-only plan handed a caller's spectrum destination runs the full kernel)
+    SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, d_power != nullptr, a, p->fft_cus, s.stream, in_packet ? after : nullptr));
   }
   if (scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
@@ -687,6 +697,8 @@ int scn_plan_destroy(scn_plan *p) {
   if (p->d_chirp) (void)hipFree(p->d_chirp);
   if (p->d_bfilter) (void)hipFree(p->d_bfilter);
   if (p->d_tw1_table) (void)hipFree(p->d_tw1_table);
+  if (p->d_conv_in) (void)hipFree(p->d_conv_in);
+  if (p->d_conv_out) (void)hipFree(p->d_conv_out);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   if (p->h2d_stream) (void)hipStreamDestroy(p->h2d_stream);
   if (p->d2h_stream) (void)hipStreamDestroy(p->d2h_stream);
@@ -752,18 +764,20 @@ int scn_convert_raw(scn_plan *p, const void *raw, uint32_t nb, float *out) {
   if (!nb) return SCN_OK;
   SCN_HIP(hipSetDevice(p->d.device_id));
   const size_t in_bytes = p->buf_bytes * nb, out_bytes = sizeof(float) * 2 * (size_t)p->d.n * nb;
-  void *d_in = nullptr;
-  scn_v2f *d_out = nullptr;
-  hipError_t e = hipMalloc(&d_in, in_bytes);
-  if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_in, raw, in_bytes, hipMemcpyHostToDevice, p->d2h_stream);
-  if (e == hipSuccess)
-    e = scn_launch_convert((int)p->d.sample_kind, p->d.correct_dc != 0, d_in, d_out, p->d.n, nb, p->scale, p->d2h_stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, p->d2h_stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(p->d2h_stream);
-  if (d_in) (void)hipFree(d_in);
-  if (d_out) (void)hipFree(d_out);
-  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? SCN_E_NOMEM : SCN_E_HIP, "scn_convert_raw: %s", hipGetErrorString(e));
+  if (p->conv_cap < nb) {  // grow the plan's staging pair (the capture writer converts one record per call: one allocation, ever)
+    if (p->d_conv_in) (void)hipFree(p->d_conv_in);
+    if (p->d_conv_out) (void)hipFree(p->d_conv_out);
+    p->d_conv_in = nullptr;
+    p->d_conv_out = nullptr;
+    p->conv_cap = 0;
+    SCN_HIP(hipMalloc(&p->d_conv_in, in_bytes));
+    SCN_HIP(hipMalloc(&p->d_conv_out, out_bytes));
+    p->conv_cap = nb;
+  }
+  SCN_HIP(hipMemcpyAsync(p->d_conv_in, raw, in_bytes, hipMemcpyHostToDevice, p->d2h_stream));
+  SCN_HIP(scn_launch_convert((int)p->d.sample_kind, p->d.correct_dc != 0, p->d_conv_in, p->d_conv_out, p->d.n, nb, p->scale, p->d2h_stream));
+  SCN_HIP(hipMemcpyAsync(out, p->d_conv_out, out_bytes, hipMemcpyDeviceToHost, p->d2h_stream));
+  SCN_HIP(hipStreamSynchronize(p->d2h_stream));
   return SCN_OK;
 }
 
@@ -890,6 +904,32 @@ int scn_hits_view(scn_plan *p, int slot, const scn_hit **hits, uint32_t *n) {
   *hits = s.h_list;
   return SCN_OK;
 }
+
+}  // extern "C"
+
+// internal (scn_gather.hip): the collected slot's ordered list where the compaction kernel left it, in device memory
+int scn_plan_device_hits(scn_plan *p, int slot, const scn_hit **d_list, uint32_t *n, int *device_id) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if (!d_list || !n) return fail(SCN_E_INVALID, "null argument");
+  Slot &s = p->slot[slot];
+  if (s.pending || !s.list_valid) return fail(SCN_E_STATE, "slot %d: no collected submit whose hit list is still on the device", slot);
+  if (s.total_hits > p->d.max_hits)
+    return fail(SCN_E_TRUNCATED, "slot %d holds %u hits, the plan's device list %u (max_hits): gather from a host list read with scn_collect_more",
+                slot, s.total_hits, p->d.max_hits);
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  if (s.total_hits) {
+    if (!s.list_built)
+      if ((st = build_list(p, s, false))) return st;
+    SCN_HIP(hipEventSynchronize(s.list_done[s.gen]));
+  }
+  *d_list = s.d_list;
+  *n = s.total_hits;
+  if (device_id) *device_id = p->d.device_id;
+  return SCN_OK;
+}
+
+extern "C" {
 
 int scn_slot_stream(scn_plan *p, int slot, void **hip_stream) {
   if (int st = check_slot(p, slot)) return st;

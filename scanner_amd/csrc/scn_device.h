@@ -24,11 +24,34 @@ __device__ __forceinline__ v2f to_v2f(cf c) { return v2f{c.x, c.y}; }
 
 namespace {
 
-// 10*log2(sqrt(P))/log2(10) == (5/log2(10)) * log2(P)
-__device__ __forceinline__ float power_db(cf x) {
-  float p = __builtin_fmaf(x.y, x.y, x.x * x.x);
-  return 1.50514997831990597607f * __builtin_amdgcn_logf(p);
+// ---- K4: the dB map, 10*log2(sqrt(P))/log2(10) == (5/log2(10)) * log2(P)  (utility.cpp:86-98) ---------------------------
+// The reference evaluates it in double and rounds once (its <cmath> log2 is the double one), i.e. its output is the
+// correctly rounded dB value of a float |X|.  v_log_f32 is good to ~1 ulp OF ITS RESULT, and log2(P) of a strong bin is a
+// large number: the product form k * v_log_f32(P) measures up to 2.2 ulp of the dB value (scripts/ubench/log_acc.hip on
+// MI355X) -- at 35 dB that alone is a 2.4e-6 relative power error, a quarter of the parity bar and the whole MEDIAN of the
+// per-buffer maximum error of round 2 (1.76e-6 at every size; an exactly rounded map leaves 0.88e-6, the float quantisation
+// of a 32..64 dB value).  The exact form splits the exponent off first (log2 of the mantissa is in [-1, 0): its ulp is
+// 6e-8) and adds k * e in two exactly representable pieces: <= 1.0 ulp, rms 0.38 (correct rounding: 0.5 / 0.29).  It costs
+// five more VALU operations per bin, so the map is DEFINED as: the product form for powers below SCN_P_EXACT_FROM = 10^3.2
+// (16 dB: its error there is <= 2.2 ulp of a value below 16, i.e. 2e-6 dB or 1e-6 in relative power), the exact form from
+// there up -- a pure function of the bin's power, the same in every kernel and output mode; the kernels evaluate the exact
+// form only in waves that hold such a bin (strong signals: rare), under a wave-uniform branch.
+#define SCN_P_EXACT_FROM 1584.8932f
+__device__ __forceinline__ float db_fast(float p) { return 1.50514997831990597607f * __builtin_amdgcn_logf(p); }
+__device__ __forceinline__ float db_exact(float p) {
+  const float m = __builtin_amdgcn_frexp_mantf(p);          // [1/2, 1); 0, inf and nan come back unchanged
+  const float e = (float)__builtin_amdgcn_frexp_expf(p);
+  const float KH = 1.505126953125f;                          // k to 12 significant bits: KH * e is exact (|e| < 256)
+  const float KL = (float)(1.50514997831990597607 - 1.505126953125);
+  return __builtin_fmaf(KL, e, __builtin_fmaf(1.50514997831990597607f, __builtin_amdgcn_logf(m), KH * e));
 }
+// the map itself, one bin
+__device__ __forceinline__ float db_of_power(float p) {
+  const float lo = db_fast(p), hi = db_exact(p);  // both evaluated, then ONE select: no per-bin branch (the callers sit behind a wave-uniform one)
+  return p >= SCN_P_EXACT_FROM ? hi : lo;
+}
+__device__ __forceinline__ float power_of(cf x) { return __builtin_fmaf(x.y, x.y, x.x * x.x); }
+__device__ __forceinline__ float power_db(cf x) { return db_of_power(power_of(x)); }
 
 __device__ __forceinline__ cf cmul(cf a, cf w) {
   return cf{__builtin_fmaf(-a.y, w.y, a.x * w.x), __builtin_fmaf(a.y, w.x, a.x * w.y)};
@@ -82,6 +105,52 @@ __device__ __forceinline__ void fft8(cf z[8]) {
     z[2 * k0] = a + b;      // X[k0]
     z[2 * k0 + 1] = a - b;  // X[k0 + 4]
   }
+}
+
+// ---- double-precision twins (the staged path of scn_generic.hip; pass 3 of the 16384-point kernel) --------------------
+// v_add_f64 issues at 0.85x, v_mul_f64 / v_fma_f64 at 0.7x the rate of v_fma_f32 on gfx950 (scripts/ubench/f64_rate.hip):
+// a double butterfly costs ~1.3x a float one, not 2x or 16x.
+typedef double scn_v2d __attribute__((ext_vector_type(2)));
+struct cd {
+  double x, y;
+};
+__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd from_v2d(scn_v2d v) { return cd{v.x, v.y}; }
+__device__ __forceinline__ scn_v2d to_v2d(cd c) { return scn_v2d{c.x, c.y}; }
+__device__ __forceinline__ cd to_cd(v2f v) { return cd{(double)v.x, (double)v.y}; }
+__device__ __forceinline__ cd cmul_d(cd a, scn_v2d w) { return cd{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+__device__ __forceinline__ cd cmul_d(cd a, double wx, double wy) {
+  return cd{__builtin_fma(-a.y, wy, a.x * wx), __builtin_fma(a.y, wx, a.x * wy)};
+}
+// DFT4 with W4 = -i, results left in (x0, x1, x2, x3) = (X0, X1, X2, X3)
+__device__ __forceinline__ void radix4_d(cd &x0, cd &x1, cd &x2, cd &x3) {
+  const cd t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = x1 - x3;
+  x0 = t0 + t2;
+  x2 = t0 - t2;
+  x1 = cd{t1.x + t3.y, t1.y - t3.x};  // t1 - i*t3
+  x3 = cd{t1.x - t3.y, t1.y + t3.x};  // t1 + i*t3
+}
+// a * (1 - i) * h  and  a * (-1 - i) * h  (W16^2, W16^6 with h = sqrt(1/2))
+__device__ __forceinline__ cd mul_w2_d(cd a, double h) { return cd{(a.x + a.y) * h, (a.y - a.x) * h}; }
+__device__ __forceinline__ cd mul_w6_d(cd a, double h) { return cd{(a.y - a.x) * h, -(a.x + a.y) * h}; }
+// In-register 16-point forward DFT (radix 4 x 4), in double: on return X[k] sits in v[OUT16(k)] like the float fft16.
+__device__ __forceinline__ void fft16_d(cd v[16]) {
+  const double C1 = 0.92387953251128675613, S1 = 0.38268343236508977173, H = 0.70710678118654752440;
+#pragma unroll
+  for (int n0 = 0; n0 < 4; n0++) radix4_d(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
+  // v[n0 + 4 k0] *= W16^(n0 k0)
+  v[5] = cmul_d(v[5], C1, -S1);                          // W^1
+  v[9] = mul_w2_d(v[9], H);                              // W^2
+  v[13] = cmul_d(v[13], S1, -C1);                        // W^3
+  v[6] = mul_w2_d(v[6], H);                              // W^2
+  v[10] = cd{v[10].y, -v[10].x};                         // W^4 = -i
+  v[14] = mul_w6_d(v[14], H);                            // W^6
+  v[7] = cmul_d(v[7], S1, -C1);                          // W^3
+  v[11] = mul_w6_d(v[11], H);                            // W^6
+  v[15] = cmul_d(v[15], -C1, S1);                        // W^9
+#pragma unroll
+  for (int k0 = 0; k0 < 4; k0++) radix4_d(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
 }
 
 // ---- global memory access through buffer descriptors ---------------------------------

@@ -24,6 +24,8 @@
 #include "../../include/scanner_hip.h"
 
 int scn_set_last_error(int status, const char *fmt, ...);  // scn_api.hip
+// scn_api.hip: the collected slot's ordered list in device memory (built if it was not yet), without a host copy
+int scn_plan_device_hits(scn_plan *p, int slot, const scn_hit **d_list, uint32_t *n, int *device_id);
 
 namespace {
 
@@ -73,9 +75,11 @@ struct scn_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   hipStream_t stream = nullptr;
-  uint32_t *d_counts = nullptr;  // [world + 1]: slot `world` holds this rank's own count
+  uint32_t *d_counts = nullptr;  // [2 * world + 2]: the gathered {count, status} pairs, then this rank's own pair
   void *d_send = nullptr, *d_recv = nullptr;
   size_t send_cap = 0, recv_cap = 0;
+  uint64_t gathered = 0;     // records of the last successful gather held in d_recv (root only)
+  bool gather_root = false;  // this rank was the root of the last successful gather
 };
 
 #define SCN_G_HIP(call)                                                                                       \
@@ -141,7 +145,7 @@ int scn_comm_create(const void *id, int rank, int world_size, int device_id, scn
   int st = SCN_OK;
   do {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(uint32_t) * ((size_t)world_size + 1u));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(uint32_t) * (2u * (size_t)world_size + 2u));
     if (e != hipSuccess) {
       st = scn_set_last_error(SCN_E_HIP, "scn_comm_create: %s", hipGetErrorString(e));
       break;
@@ -173,55 +177,158 @@ int scn_comm_destroy(scn_comm *c) {
   return SCN_OK;
 }
 
-int scn_gather_hits(scn_comm *c, const scn_hit *local, uint32_t n_local, uint32_t root, scn_hit *all, uint64_t all_cap,
-                    uint64_t *n_total, uint32_t *per_rank) {
-  if (!c || (n_local && !local) || root >= (uint32_t)c->world) return scn_set_last_error(SCN_E_INVALID, "bad arguments");
+// The collective itself, shared by the host- and the device-pointer form.  `d_local`: this rank's records in DEVICE memory
+// (already staged, or the plan's own ordered list).  Protocol, the same instruction sequence on every rank whatever its
+// arguments -- no rank can leave early and strand its peers:
+//   (1) all-gather {count, status}: a rank that could not prepare its part (allocation failure, bad list) announces it here
+//   (2) if nobody failed, the root makes room for the whole list and says so in a second one-word all-gather (its
+//       allocation can only be sized now); otherwise everybody returns the failure
+//   (3) ONE group: the root posts a receive per peer straight into its place of the rank-major list, peers send.  Every
+//       call between ncclGroupStart and ncclGroupEnd is attempted-or-skipped, never returned out of: the group is always
+//       closed, the first error reported afterwards.
+// The gathered list stays in the communicator's device buffer on the root (scn_gather_fetch reads it, locally).
+static int gather_core(scn_comm *c, const void *d_local, uint32_t n_local, int local_status, uint32_t root, uint64_t *n_total, uint32_t *per_rank) {
   RcclApi &api = rccl();
-  SCN_G_HIP(hipSetDevice(c->device));
   const uint32_t world = (uint32_t)c->world;
   const bool is_root = (uint32_t)c->rank == root;
+  c->gathered = 0;
+  c->gather_root = false;
 
-  // (1) everybody learns every rank's count
-  SCN_G_HIP(hipMemcpyAsync(c->d_counts + world, &n_local, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  SCN_G_NCCL(api.AllGather(c->d_counts + world, c->d_counts, 1, ncclUint32, c->comm, c->stream));
-  std::vector<uint32_t> counts(world);
-  SCN_G_HIP(hipMemcpyAsync(counts.data(), c->d_counts, sizeof(uint32_t) * world, hipMemcpyDeviceToHost, c->stream));
+  // (1) counts + status; slot layout of d_counts: [2 * world] gathered pairs, then this rank's own pair
+  uint32_t mine[2] = {n_local, (uint32_t)local_status};
+  SCN_G_HIP(hipMemcpyAsync(c->d_counts + 2u * world, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+  SCN_G_NCCL(api.AllGather(c->d_counts + 2u * world, c->d_counts, 2, ncclUint32, c->comm, c->stream));
+  std::vector<uint32_t> pairs(2u * world);
+  SCN_G_HIP(hipMemcpyAsync(pairs.data(), c->d_counts, sizeof(uint32_t) * 2u * world, hipMemcpyDeviceToHost, c->stream));
   SCN_G_HIP(hipStreamSynchronize(c->stream));
+  std::vector<uint32_t> counts(world);
+  int first_bad = -1;
+  for (uint32_t r = 0; r < world; r++) {
+    counts[r] = pairs[2u * r];
+    if (pairs[2u * r + 1u] != (uint32_t)SCN_OK && first_bad < 0) first_bad = (int)r;
+  }
   std::vector<uint64_t> offsets(world + 1u);
   scn_gather_layout(counts.data(), world, offsets.data());
   const uint64_t total = offsets[world];
   if (n_total) *n_total = total;
   if (per_rank) memcpy(per_rank, counts.data(), sizeof(uint32_t) * world);
+  if (first_bad >= 0) {
+    if (first_bad == c->rank) return local_status;  // (the caller has set the message)
+    return scn_set_last_error(SCN_E_COMM, "rank %d could not prepare its part of the gather (status %u): nothing was exchanged", first_bad,
+                              pairs[2u * (uint32_t)first_bad + 1u]);
+  }
   if (counts[c->rank] != n_local) return scn_set_last_error(SCN_E_COMM, "count exchange returned %u for this rank, sent %u", counts[c->rank], n_local);
 
-  // (2) one group: the root posts a receive per peer straight into its place of the rank-major list, peers send
+  // (2) the root's room for the list
   const size_t rec = sizeof(scn_hit);
+  uint32_t ready[1] = {(uint32_t)SCN_OK};
+  if (is_root) ready[0] = (uint32_t)grow(&c->d_recv, &c->recv_cap, (size_t)(total ? total : 1) * rec);
+  if (world > 1) {
+    SCN_G_HIP(hipMemcpyAsync(c->d_counts + 2u * world, ready, sizeof(ready), hipMemcpyHostToDevice, c->stream));
+    SCN_G_NCCL(api.AllGather(c->d_counts + 2u * world, c->d_counts, 1, ncclUint32, c->comm, c->stream));
+    SCN_G_HIP(hipMemcpyAsync(ready, c->d_counts + root, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    SCN_G_HIP(hipStreamSynchronize(c->stream));
+  }
+  if (ready[0] != (uint32_t)SCN_OK) {
+    if (is_root) return (int)ready[0];
+    return scn_set_last_error(SCN_E_COMM, "the root (rank %u) could not allocate room for %llu records: nothing was exchanged", root, (unsigned long long)total);
+  }
+
+  // (3) the transfers
+  ncclResult_t first_err = ncclSuccess;
+  hipError_t hip_err = hipSuccess;
+  if (is_root && n_local)
+    hip_err = hipMemcpyAsync(static_cast<char *>(c->d_recv) + offsets[root] * rec, d_local, rec * n_local, hipMemcpyDeviceToDevice, c->stream);
+  ncclResult_t r0 = api.GroupStart();
+  if (r0 == ncclSuccess) {
+    if (is_root) {
+      for (uint32_t r = 0; r < world; r++)
+        if (r != root && counts[r]) {
+          const ncclResult_t e = api.Recv(static_cast<char *>(c->d_recv) + offsets[r] * rec, rec * counts[r], ncclUint8, (int)r, c->comm, c->stream);
+          if (e != ncclSuccess && first_err == ncclSuccess) first_err = e;  // keep posting: the peers' sends are coming
+        }
+    } else if (n_local) {
+      first_err = api.Send(d_local, rec * n_local, ncclUint8, (int)root, c->comm, c->stream);
+    }
+    const ncclResult_t e = api.GroupEnd();  // always closed
+    if (e != ncclSuccess && first_err == ncclSuccess) first_err = e;
+  } else {
+    first_err = r0;
+  }
+  const hipError_t sync_err = hipStreamSynchronize(c->stream);
+  if (first_err != ncclSuccess) return scn_set_last_error(SCN_E_COMM, "gather transfers failed: %s", api.GetErrorString(first_err));
+  if (hip_err != hipSuccess || sync_err != hipSuccess)
+    return scn_set_last_error(SCN_E_HIP, "gather: %s", hipGetErrorString(hip_err != hipSuccess ? hip_err : sync_err));
   if (is_root) {
-    if (int st = grow(&c->d_recv, &c->recv_cap, (size_t)(total ? total : 1) * rec)) return st;
-    if (n_local)
-      SCN_G_HIP(hipMemcpyAsync(static_cast<char *>(c->d_recv) + offsets[root] * rec, local, rec * n_local, hipMemcpyHostToDevice, c->stream));
-  } else if (n_local) {
-    if (int st = grow(&c->d_send, &c->send_cap, rec * n_local)) return st;
-    SCN_G_HIP(hipMemcpyAsync(c->d_send, local, rec * n_local, hipMemcpyHostToDevice, c->stream));
+    c->gathered = total;
+    c->gather_root = true;
   }
-  SCN_G_NCCL(api.GroupStart());
-  if (is_root) {
-    for (uint32_t r = 0; r < world; r++)
-      if (r != root && counts[r])
-        SCN_G_NCCL(api.Recv(static_cast<char *>(c->d_recv) + offsets[r] * rec, rec * counts[r], ncclUint8, (int)r, c->comm, c->stream));
-  } else if (n_local) {
-    SCN_G_NCCL(api.Send(c->d_send, rec * n_local, ncclUint8, (int)root, c->comm, c->stream));
-  }
-  SCN_G_NCCL(api.GroupEnd());
-  uint64_t copied = 0;
-  if (is_root && all && total) {
-    copied = total < all_cap ? total : all_cap;
-    SCN_G_HIP(hipMemcpyAsync(all, c->d_recv, rec * copied, hipMemcpyDeviceToHost, c->stream));
-  }
-  SCN_G_HIP(hipStreamSynchronize(c->stream));
-  if (is_root && all && copied < total)
-    return scn_set_last_error(SCN_E_TRUNCATED, "%llu hits gathered, room for %llu", (unsigned long long)total, (unsigned long long)all_cap);
   return SCN_OK;
+}
+
+int scn_gather_fetch(scn_comm *c, uint64_t first, scn_hit *out, uint64_t cap, uint64_t *n_written) {
+  if (!c || !n_written || (cap && !out)) return scn_set_last_error(SCN_E_INVALID, "bad arguments");
+  *n_written = 0;
+  if (!c->gather_root) return scn_set_last_error(SCN_E_STATE, "no gathered list on this rank (not the root of the last gather, or it failed)");
+  if (first >= c->gathered || cap == 0) return SCN_OK;
+  SCN_G_HIP(hipSetDevice(c->device));
+  const uint64_t n = c->gathered - first < cap ? c->gathered - first : cap;
+  SCN_G_HIP(hipMemcpyAsync(out, static_cast<const scn_hit *>(c->d_recv) + first, sizeof(scn_hit) * n, hipMemcpyDeviceToHost, c->stream));
+  SCN_G_HIP(hipStreamSynchronize(c->stream));
+  *n_written = n;
+  return SCN_OK;
+}
+
+// copy-out shared by the two collective forms: min(total, all_cap) records on the root, SCN_E_TRUNCATED if not all (the rest
+// stays fetchable: scn_gather_fetch)
+static int gather_copy_out(scn_comm *c, scn_hit *all, uint64_t all_cap, uint64_t total) {
+  if (!c->gather_root || !all) return SCN_OK;
+  uint64_t got = 0;
+  if (int st = scn_gather_fetch(c, 0, all, all_cap, &got)) return st;
+  if (got < total)
+    return scn_set_last_error(SCN_E_TRUNCATED, "%llu hits gathered, room for %llu: scn_gather_fetch reads the rest from the root's device copy",
+                              (unsigned long long)total, (unsigned long long)all_cap);
+  return SCN_OK;
+}
+
+int scn_gather_hits(scn_comm *c, const scn_hit *local, uint32_t n_local, uint32_t root, scn_hit *all, uint64_t all_cap,
+                    uint64_t *n_total, uint32_t *per_rank) {
+  if (!c || root >= (uint32_t)c->world) return scn_set_last_error(SCN_E_INVALID, "bad arguments");
+  SCN_G_HIP(hipSetDevice(c->device));
+  // this rank's part into device memory; whatever goes wrong here is ANNOUNCED in the exchange, not returned before it
+  int status = SCN_OK;
+  if (n_local && !local) status = scn_set_last_error(SCN_E_INVALID, "n_local > 0 with a null list");
+  if (status == SCN_OK && n_local) {
+    status = grow(&c->d_send, &c->send_cap, sizeof(scn_hit) * (size_t)n_local);
+    if (status == SCN_OK && hipMemcpyAsync(c->d_send, local, sizeof(scn_hit) * (size_t)n_local, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      status = scn_set_last_error(SCN_E_HIP, "staging the local hit list failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  uint64_t total = 0;
+  if (int st = gather_core(c, c->d_send, status == SCN_OK ? n_local : 0u, status, root, &total, per_rank)) {
+    if (n_total) *n_total = total;
+    return st;
+  }
+  if (n_total) *n_total = total;
+  return gather_copy_out(c, all, all_cap, total);
+}
+
+int scn_gather_hits_device(scn_comm *c, scn_plan *plan, int slot, uint32_t root, scn_hit *all, uint64_t all_cap, uint64_t *n_total,
+                           uint32_t *per_rank) {
+  if (!c || root >= (uint32_t)c->world) return scn_set_last_error(SCN_E_INVALID, "bad arguments");
+  const scn_hit *d_list = nullptr;
+  uint32_t n_local = 0;
+  int dev = c->device;
+  int status = plan ? scn_plan_device_hits(plan, slot, &d_list, &n_local, &dev) : scn_set_last_error(SCN_E_INVALID, "null plan");
+  if (status == SCN_OK && dev != c->device)
+    status = scn_set_last_error(SCN_E_INVALID, "the plan lives on device %d, the communicator on device %d", dev, c->device);
+  SCN_G_HIP(hipSetDevice(c->device));
+  uint64_t total = 0;
+  if (int st = gather_core(c, d_list, status == SCN_OK ? n_local : 0u, status, root, &total, per_rank)) {
+    if (n_total) *n_total = total;
+    return st;
+  }
+  if (n_total) *n_total = total;
+  return gather_copy_out(c, all, all_cap, total);
 }
 
 }  // extern "C"

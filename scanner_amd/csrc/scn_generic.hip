@@ -36,47 +36,6 @@ namespace {
 // buffers: eight stages then round a strong tone's partial sums to float eight times (the fused kernels: three), and a
 // buffer with peak/mean power 8e3 at 32768 points read 1.0e-5 .. 1.2e-5 on bins near the mean -- AT the parity bar.  This
 // is the correctness path for unusual sizes; it is bound by its HBM passes, and it pays for the wider ones.
-typedef double scn_v2d __attribute__((ext_vector_type(2)));
-struct cd {
-  double x, y;
-};
-__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cd from_v2d(scn_v2d v) { return cd{v.x, v.y}; }
-__device__ __forceinline__ scn_v2d to_v2d(cd c) { return scn_v2d{c.x, c.y}; }
-__device__ __forceinline__ cd cmul_d(cd a, scn_v2d w) { return cd{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-// DFT4 with W4 = -i, results left in (x0, x1, x2, x3) = (X0, X1, X2, X3)
-__device__ __forceinline__ void radix4_d(cd &x0, cd &x1, cd &x2, cd &x3) {
-  const cd t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = x1 - x3;
-  x0 = t0 + t2;
-  x2 = t0 - t2;
-  x1 = cd{t1.x + t3.y, t1.y - t3.x};  // t1 - i*t3
-  x3 = cd{t1.x - t3.y, t1.y + t3.x};  // t1 + i*t3
-}
-
-// a * (1 - i) * h  and  a * (-1 - i) * h  (W16^2, W16^6 with h = sqrt(1/2))
-__device__ __forceinline__ cd mul_w2_d(cd a, double h) { return cd{(a.x + a.y) * h, (a.y - a.x) * h}; }
-__device__ __forceinline__ cd mul_w6_d(cd a, double h) { return cd{(a.y - a.x) * h, -(a.x + a.y) * h}; }
-// In-register 16-point forward DFT (radix 4 x 4), in double: on return X[k] sits in v[4 (k & 3) + (k >> 2)] (OUT16 of
-// scn_device.h, whose float fft16 this mirrors).
-__device__ __forceinline__ void fft16_d(cd v[16]) {
-  const double C1 = 0.92387953251128675613, S1 = 0.38268343236508977173, H = 0.70710678118654752440;
-#pragma unroll
-  for (int n0 = 0; n0 < 4; n0++) radix4_d(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
-  // v[n0 + 4 k0] *= W16^(n0 k0)
-  v[5] = cmul_d(v[5], scn_v2d{C1, -S1});                 // W^1
-  v[9] = mul_w2_d(v[9], H);                              // W^2
-  v[13] = cmul_d(v[13], scn_v2d{S1, -C1});               // W^3
-  v[6] = mul_w2_d(v[6], H);                              // W^2
-  v[10] = cd{v[10].y, -v[10].x};                         // W^4 = -i
-  v[14] = mul_w6_d(v[14], H);                            // W^6
-  v[7] = cmul_d(v[7], scn_v2d{S1, -C1});                 // W^3
-  v[11] = mul_w6_d(v[11], H);                            // W^6
-  v[15] = cmul_d(v[15], scn_v2d{-C1, S1});               // W^9
-#pragma unroll
-  for (int k0 = 0; k0 < 4; k0++) radix4_d(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
-}
-
 template <int KIND>
 struct GenRaw;
 template <>

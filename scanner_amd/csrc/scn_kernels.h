@@ -32,6 +32,7 @@ struct ScnFftArgs {
   float scale;              // onebymax of utility.cpp:65 (1.0 for float input)
   // K5 (process.cpp:46-62), all in the reference's uint32 arithmetic
   float threshold;
+  float p_lo;               // pre-filter of the hit path in linear power: a shade below 10^(threshold / 5) (scn_hit_prefilter)
   uint32_t dc_ignore;       // m_dcIgnoreWindow
   uint32_t i_lo, i_hi;      // halfSampleCount -/+ m_useWindow (wrapping)
   // hit records: buffer b owns slots [b*hit_region, (b+1)*hit_region), hit_region = the number of bins the mask of
@@ -130,6 +131,18 @@ bool scn_bluestein_size_supported(uint32_t n);  // everything else from 16 to 32
 hipError_t scn_launch_convert(int kind, bool correct_dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers,
                               float scale, hipStream_t stream);
 
-hipError_t scn_launch_fft(uint32_t n, int kind, bool correct_dc, bool hits, const ScnFftArgs &args,
+// hits / spectrum: what the launch reports (at least one).  hits && !spectrum runs the hits-only kernels: no stores, no
+// per-bin logarithm.
+hipError_t scn_launch_fft(uint32_t n, int kind, bool correct_dc, bool hits, bool spectrum, const ScnFftArgs &args,
                           int num_cus, hipStream_t stream, hipEvent_t stop = nullptr);
+// The linear-power pre-filter that goes with a dB threshold: every power whose dB value (the map of scn_device.h, error
+// <= 2.2 ulp) can exceed `threshold` is > the returned value.  NaN -> NaN (nothing passes), +inf -> +inf.
+static inline float scn_hit_prefilter(float threshold) {
+  if (!(threshold == threshold)) return threshold;
+  const double t = (double)threshold, guard = 1e-6 * (t < 0 ? -t : t) + 1e-5;
+  const double p = __builtin_pow(10.0, (t - guard) / 5.0);
+  float f = (float)p;
+  if ((double)f > p) f = __builtin_nextafterf(f, 0.0f);
+  return f;
+}
 bool scn_fft_size_supported(uint32_t n);

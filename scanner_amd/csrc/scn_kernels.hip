@@ -272,6 +272,51 @@ struct RawLoader<SCN_K_SHORT> {
 #define SCN_STAMP(i)
 #endif
 
+// ---- K5, the recording half (process.cpp:54-57), shared by the fused kernels ------------------------------------------
+// `pw` holds the LINEAR powers of this thread's NB bins (bin index i of output o from `bin_i`).  Candidates are found in
+// the linear domain against p_lo (a shade below 10^(threshold / 5), scn_hit_prefilter); the decision itself is
+// magnitudes[j] > m_threshold on the dB value -- the map of scn_device.h, a pure function of the power, so spectrum + hits
+// and hits-only plans decide identically and report the float the spectrum holds -- evaluated only for the output indices
+// some lane of the wave has a candidate in.  Slots of the buffer's region come from ONE LDS atomic per wave.
+template <int NB, typename VEC, typename BINI>
+__device__ __forceinline__ void scn_record_hits(VEC &pw, uint32_t keepmask, const ScnFftArgs &args, int *lds_count, uint32_t buf, uint32_t lane,
+                                                BINI bin_i) {
+  uint32_t cand = 0;
+#pragma unroll
+  for (int o = 0; o < NB; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
+  cand &= keepmask;
+  uint32_t wmc = wave_or_u32(cand);
+  if (!wmc) return;
+  uint32_t wm = wmc;
+  while (wmc) {
+    const int o = __builtin_ctz(wmc);  // wave-uniform
+    wmc &= wmc - 1u;
+    const float p = pw[o];
+    const float d = db_of_power(p);
+    pw[o] = d;  // (every lane's slot o now holds its dB value; only hit lanes read it again)
+    if (!(d > args.threshold)) cand &= ~(1u << o);  // strict >, process.cpp:54
+  }
+  const uint32_t total = wave_add_u32((uint32_t)__popc(cand));
+  if (!total) return;
+  uint32_t base = 0;
+  if (lane == 0) base = (uint32_t)atomicAdd(lds_count, (int)total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  // this wave's records take the buffer's slots [base, base + total); a region holds every bin the mask lets through, so
+  // there is no overflow path (and no global atomic)
+  ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+  while (wm) {
+    const int o = __builtin_ctz(wm);  // wave-uniform
+    wm &= wm - 1u;
+    const bool hit = (cand >> o) & 1u;
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), pw[o]};
+    }
+    base += (uint32_t)__popcll(m);
+  }
+}
+
 template <int M>
 struct Geo {
   static constexpr uint32_t N = 256u * M;
@@ -294,8 +339,14 @@ __device__ __forceinline__ constexpr int out_reg(int o) {
   return M == 4 ? o : M == 8 ? (o & ~7) + OUT8(o & 7) : OUT16(o & 15);
 }
 
-template <int M, int KIND, bool DC, bool HITS>
+// Output modes (template parameters HITS, SPEC): spectrum only (false, true), spectrum + hits (true, true), hits only
+// (true, false).  The hits-only kernel has NO store instructions and no per-bin v_log_f32: it compares the linear power with a
+// guarded linear threshold (ScnFftArgs::p_lo, a shade below 10^(threshold/5)) and evaluates the dB map -- the same function
+// of the bin's power as in the other modes, so that `magnitudes[j] > m_threshold` (process.cpp:54) decides identically --
+// only in the waves that hold a candidate.
+template <int M, int KIND, bool DC, bool HITS, bool SPEC>
 __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel(ScnFftArgs args) {
+  static_assert(HITS || SPEC, "a kernel that reports nothing");
   typedef Geo<M> G;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
@@ -570,16 +621,41 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     }
 
     // ---- K4 + K5 ----
-    v16f db;  // a true vector: the recording path below indexes it with a wave-uniform o (s_set_gpr_idx)
-    float dmax = -3.40282347e+38f;  // cheap pre-filter: max over this thread's 16 bins (NaN-free: max ignores NaN)
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
+    // The thread's 16 LINEAR powers stay in `pw` (a true vector: the recording path indexes it with a wave-uniform o,
+    // s_set_gpr_idx) for the hit path; the spectrum gets the dB map of scn_device.h: its product form inline, and -- only in
+    // waves that hold a bin from SCN_P_EXACT_FROM up -- the exact form stored over it for those bins (the other lanes' stores
+    // go to an out-of-range offset and are dropped by the descriptor's range check: no branch per bin).
+    v16f pw;
+    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the largest power of each group of four outputs (max ignores NaN)
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
 #pragma unroll
     for (int o = 0; o < 16; o++) {
-      const float d = power_db(v[out_reg<M>(o)]);
-      db[o] = d;
-      // NB: never __builtin_bit_cast a vector ELEMENT (db[o]): clang reads element 0 for every o
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 4u * joff_of(o), AUX_ST);
-      if (HITS) dmax = fmaxf(dmax, d);
+      const float q = power_of(v[out_reg<M>(o)]);
+      pw[o] = q;
+      gmax[o >> 2] = fmaxf(gmax[o >> 2], q);
+      if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 4u * joff_of(o), AUX_ST);
+    }
+    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));  // pre-filter of the hit path and of the exact half
+    if constexpr (SPEC) {
+      if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
+        // Strong bins are neighbours -- a tone's main lobe sits in ONE or two output indices o of a wave -- and the bench
+        // input has such a wave in most buffers, so this path must stay short: all 16 outputs at ~14 operations each made
+        // the wave its workgroup's straggler (+4 us per C2 launch), 16 wave-wide tests still +1 .. 4 us; so: the groups of
+        // four first, then the outputs of a group that holds one.
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+            for (int o = 4 * g; o < 4 * g + 4; o++) {
+              const float q = pw[o];  // NB: never __builtin_bit_cast a vector ELEMENT: clang reads element 0 for every o
+              if (__ballot(q >= SCN_P_EXACT_FROM)) {
+                const float d = db_exact(q);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 4u * joff_of(o), AUX_ST);
+              }
+            }
+          }
+        }
+      }
     }
     SCN_STAMP(9);  // exchange-2 reads + pass 3 + dB + stores issued
     if (t == 0) lds_next[0] = !more ? 0xffffffffu : DYN ? wq_buffer(taken) : nxt + gridDim.x;
@@ -593,35 +669,8 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       // Recording runs AFTER the barrier: a wave that holds detections does not stall the other
       // waves of its workgroup, they go on to the next buffer and meet it at that buffer's first
       // barrier (its loads are in flight meanwhile).  Only such a wave evaluates the per-bin test.
-      if (__ballot(dmax > args.threshold)) {
-        uint32_t hitmask = 0;
-#pragma unroll
-        for (int o = 0; o < 16; o++) hitmask |= (db[o] > args.threshold) ? (1u << o) : 0u;  // strict >, process.cpp:54
-        hitmask &= keepmask;
-        // one slot allocation per wave, then only the output indices some lane actually hit
-        const uint32_t total = wave_add_u32((uint32_t)__popc(hitmask));
-        if (total) {
-          uint32_t wm = wave_or_u32(hitmask);
-          uint32_t base = 0;
-          if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
-          base = __builtin_amdgcn_readfirstlane(base);
-          // this wave's records take the buffer's slots [base, base + total); a region holds every bin the mask lets
-          // through, so there is no overflow path (and no global atomic)
-          ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-          while (wm) {
-            const int o = __builtin_ctz(wm);  // wave-uniform
-            wm &= wm - 1u;
-            const bool hit = (hitmask >> o) & 1u;
-            const unsigned long long m = __ballot(hit);
-            if (hit) {
-              const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-              const uint32_t joff = (M >= 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M);
-              if (pos < args.hit_region) region[pos] = ScnDevHit{(jbase + joff) ^ (N / 2), db[o]};
-            }
-            base += (uint32_t)__popcll(m);
-          }
-        }
-      }
+      if (__ballot(pmax > args.p_lo))
+        scn_record_hits<16>(pw, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
       prev = buf;
       par ^= 1;
     }
@@ -682,6 +731,13 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #ifndef SCN_WIDE_16384
 #define SCN_WIDE_16384 1  // 16384 points: 512 threads x 32 points with a register prefetch instead of scn_fft_kernel<64>
 #endif
+#ifndef SCN_16K_P3_DOUBLE
+// EXPERIMENT, off in the product: pass 3 of the 16384-point kernel in double.  Measured on MI355X (profiles/r03_experiments.md):
+// the parity metric's tail on 3072 strong-tone buffers drops from 0.6e-5 .. 1.05e-5 to 2.2e-6 .. 3.1e-6 (the float dB
+// quantisation floor), but the lane-pair form of this kernel pays +38 % (88.6 -> 122 us spectrum-only) for the conversions,
+// the doubled lane exchange and 13 .. 35 spilled registers, and the hits-only variant does not fit the register file at all.
+#define SCN_16K_P3_DOUBLE 0
+#endif
 #ifndef SCN_8K_PAIR
 #define SCN_8K_PAIR 1  // the wide kernel's threads play neighbouring virtual threads (two-sample loads, 16-byte exchange-1 writes)
 #endif
@@ -710,9 +766,11 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 // the odd half multiplies by W_64^r', and one v_permlane32_swap per register finishes the radix-4 step:
 //   X[r']      = U_0 + W U_1 (lower half)      X[r' + 32] = U_0 - W U_1 (upper half)
 //   X[r' + 16] = V_0 - i W V_1 (lower half)    X[r' + 48] = V_0 + i W V_1 (upper half)
-template <int M2, int KIND, bool DC, bool HITS>
+template <int M2, int KIND, bool DC, bool HITS, bool SPEC>
 __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
+  static_assert(HITS || SPEC, "a kernel that reports nothing");
   typedef GeoWide<M2> G;
+  constexpr bool P3D = M2 == 64 && SCN_16K_P3_DOUBLE != 0;  // pass 3 in double (see there)
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
   constexpr uint32_t N = G::N, T = G::T, TV = G::TV, P1 = G::P1, P2 = G::P2;
@@ -766,11 +824,15 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
     load_group(r0, 0, PFN);
   }
   // persistent constants: pass-1 twiddles of both virtual threads (table rows of TV), window taps
-  cf tw1a[16], tw1b[16];
+  // (16384 points with pass 3 in double: the second virtual thread's twiddles are NOT kept -- tau1 = tau0 + 1, so
+  // W_N^(tau1 p) = W_N^(tau0 p) W_N^p with W_N^p a compile-time constant: one more complex multiply per p and buffer buys the
+  // 30 registers pass 3 needs for its double-precision values)
+  constexpr bool TW1B = !(P3D && PAIR);
+  cf tw1a[16], tw1b[TW1B ? 16 : 1];
 #pragma unroll
   for (int p = 1; p < 16; p++) {
     tw1a[p] = from_v2f(args.tw1_table[(p - 1) * TV + tau0]);
-    tw1b[p] = from_v2f(args.tw1_table[(p - 1) * TV + tau1]);
+    if (TW1B) tw1b[p] = from_v2f(args.tw1_table[(p - 1) * TV + tau1]);
   }
   float win[32];
 #pragma unroll
@@ -881,7 +943,13 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
         cf ya = va[OUT16(p)], yb = vb[OUT16(p)];
         if (p) {
           ya = cmul(ya, tw1a[p]);
-          yb = cmul(yb, tw1b[p]);
+          if constexpr (TW1B) {
+            yb = cmul(yb, tw1b[p]);
+          } else {
+            const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * p / (double)N);
+            const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * p / (double)N);
+            yb = cmul(yb, cmul(tw1a[p], cf{cr, -sr}));
+          }
         }
         typedef float v4f_t __attribute__((ext_vector_type(4)));
         *reinterpret_cast<v4f_t *>(w1 + p * P1) = v4f_t{ya.x, ya.y, yb.x, yb.y};  // slots tau0, tau0 + 1: 16-byte aligned (P1 even)
@@ -941,58 +1009,150 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
     __syncthreads();
     SCN_STAMP(8);  // barrier 3
 
-    // ---- pass 3.  M2 = 32: one 32-point DFT over c per thread: even c -> va, odd c -> vb.
-    //             M2 = 64: this lane's half of a 64-point DFT: c = 4c' + e -> va, c = 4c' + e + 2 -> vb ----
+    // K4: the thread's 32 LINEAR powers stay in `pw` (bin j = jbase + 256 r at index r) for the hit path; the spectrum gets the
+    // dB map of scn_device.h -- product form inline, exact form stored over it for the strong bins in the waves that hold one
+    // (see scn_fft_kernel)
+    v32f pw;
+    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the largest power of each group of eight outputs (max ignores NaN)
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
+    if constexpr (P3D) {
+      // ---- pass 3 in DOUBLE (16384 points).  A strong tone's partial sums are largest in the last pass, and their float
+      // rounding errors land on the 63 other bins of the tone's 64-point column (k = kl + 256 r): with peak / mean power of
+      // 3e3 .. 7e3 that is the 0.7e-5 .. 1.05e-5 tail of the parity metric at this size -- ANY float32 FFT shows it
+      // (scripts/emul_fused.py: this decomposition and pocketfft's have the same tail).  Evaluated in double from the float
+      // exchange-2 values, the last six of the fourteen radix-2 levels stop contributing: the tail shrinks 3x.  v_add_f64 /
+      // v_fma_f64 issue at 0.85x / 0.7x the float rate on gfx950 (scripts/ubench/f64_rate.hip), so the price is the
+      // conversions and ~1.3x on a third of the arithmetic.
+      // Lane half e holds the 32 values x[c''] = L2(c = 2c'' + e, kl).  Decimation in frequency, so that only 16 double
+      // values are live at a time: A[c''] = x[c''] + x[c''+16] -> DFT16 -> Y_e[2 rho];  B[c''] = (x[c''] - x[c''+16]) W_32^c''
+      // -> DFT16 -> Y_e[2 rho + 1].  Then X[r''] = Y_0[r''] + W_64^r'' Y_1[r''] (lower half), X[r'' + 32] = Y_0 - W Y_1 (upper):
+      // only |X|^2 is needed, so BOTH halves rotate by half the angle -- Y_0 conj(W_128^r'') and Y_1 W_128^r'' (same cosine,
+      // the sine's sign by lane half) -- and one v_permlane32_swap per 32-bit half of each component finishes it.
+      // (every twiddle below is a wave-uniform compile-time constant -- scalar operands, no registers: the lane halves differ
+      // by ONE sign flip per value instead.  |conj(h) Y_0 +- h Y_1| = |conj(h conj(Y_0)) +- h Y_1|: the lower half conjugates
+      // its value, both halves multiply by h = W_128^r'', and the conjugation of the lower half's product is folded into the
+      // signs of the last step.)
+      const unsigned conj_lo = e ? 0u : 0x80000000u;  // xor mask of the imaginary part's high word: lower half conjugates
+      const double sgn_x = e ? -1.0 : 1.0;             // upper half holds X[r'' + 32] = Y_0 - W Y_1
+      const double sgn_y = -sgn_x;
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-      va[c] = from_v2f(r3[(M2 == 64 ? 4 * c : 2 * c) * P2]);
-      vb[c] = from_v2f(r3[(M2 == 64 ? 4 * c + 2 : 2 * c + 1) * P2]);
-    }
-    fft16(va);
-    fft16(vb);
-
-    // ---- K4 + K5: U, V = E[r'] +- W_32^r' O[r']: the outputs X[r'], X[r' + 16] themselves (M2 = 32), or this lane's
-    //      share of them (M2 = 64: one exchange across the wave's halves finishes the radix-4 step) ----
-    v32f db;
-    float dmax = -3.40282347e+38f;
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
-    const float sel = e ? 1.0f : 0.0f, sgn = e ? -1.0f : 1.0f;  // (M2 = 64)
+      for (int h = 0; h < 2; h++) {
+        cd vd[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const cf ev = va[OUT16(r)];
-      cf od = vb[OUT16(r)];
-      if (r) {
-        const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
-        const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
-        od = cmul(od, cf{cr, -sr});
-      }
-      cf x0 = ev + od, x1 = ev - od;
-      if constexpr (M2 == 64) {
-        if (r) {  // W_64^r' in the odd half, 1 in the even half (branch-free: both halves run the same code)
-          const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 64.0);
-          const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 64.0);
-          const cf w = cf{e ? cr : 1.0f, -sr * sel};
-          x0 = cmul(x0, w);
-          x1 = cmul(x1, w);
+        for (int c = 0; c < 16; c++) {
+          const cd x0 = to_cd(r3[(2 * c) * P2]), x1 = to_cd(r3[(2 * (c + 16)) * P2]);
+          if (h == 0) {
+            vd[c] = x0 + x1;
+          } else {
+            const cd dlt = x0 - x1;
+            const double cr = __builtin_cos(6.283185307179586476925286766559 * c / 32.0), sr = __builtin_sin(6.283185307179586476925286766559 * c / 32.0);
+            vd[c] = c ? cmul_d(dlt, cr, -sr) : dlt;
+          }
         }
-        // v_permlane32_swap on two copies of a register leaves the lower half's value in [0] and the upper half's in [1], in BOTH halves
-        auto ax = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0.x), __builtin_bit_cast(unsigned, x0.x), false, false);
-        auto ay = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0.y), __builtin_bit_cast(unsigned, x0.y), false, false);
-        auto bx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x1.x), __builtin_bit_cast(unsigned, x1.x), false, false);
-        auto by = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x1.y), __builtin_bit_cast(unsigned, x1.y), false, false);
-        const cf u0 = cf{__builtin_bit_cast(float, (unsigned)ax[0]), __builtin_bit_cast(float, (unsigned)ay[0])};
-        const cf u1 = cf{__builtin_bit_cast(float, (unsigned)ax[1]), __builtin_bit_cast(float, (unsigned)ay[1])};
-        const cf v0 = cf{__builtin_bit_cast(float, (unsigned)bx[0]), __builtin_bit_cast(float, (unsigned)by[0])};
-        const cf v1 = cf{__builtin_bit_cast(float, (unsigned)bx[1]), __builtin_bit_cast(float, (unsigned)by[1])};
-        x0 = cf{__builtin_fmaf(u1.x, sgn, u0.x), __builtin_fmaf(u1.y, sgn, u0.y)};    // U_0 +- W U_1
-        x1 = cf{__builtin_fmaf(v1.y, sgn, v0.x), __builtin_fmaf(v1.x, -sgn, v0.y)};   // V_0 -+ i W V_1
+        fft16_d(vd);
+#pragma unroll
+        for (int rho = 0; rho < 16; rho++) {
+          const int r = 2 * rho + h;  // r'': this lane's output block is r + 32 e
+          cd y = vd[OUT16(rho)];
+          unsigned long long by = __builtin_bit_cast(unsigned long long, y.y);
+          if (r) {
+            by ^= (unsigned long long)conj_lo << 32;
+            y.y = __builtin_bit_cast(double, by);
+            const double cr = __builtin_cos(6.283185307179586476925286766559 * r / 128.0), sr = __builtin_sin(6.283185307179586476925286766559 * r / 128.0);
+            y = cmul_d(y, cr, -sr);
+            by = __builtin_bit_cast(unsigned long long, y.y);
+          }
+          // both halves' values into both halves: [0] = the lower half's (A = h conj(Y_0); r'' = 0: Y_0 itself), [1] = the upper half's (B = h Y_1)
+          const unsigned long long bx = __builtin_bit_cast(unsigned long long, y.x);
+          auto sxl = __builtin_amdgcn_permlane32_swap((unsigned)bx, (unsigned)bx, false, false);
+          auto sxh = __builtin_amdgcn_permlane32_swap((unsigned)(bx >> 32), (unsigned)(bx >> 32), false, false);
+          auto syl = __builtin_amdgcn_permlane32_swap((unsigned)by, (unsigned)by, false, false);
+          auto syh = __builtin_amdgcn_permlane32_swap((unsigned)(by >> 32), (unsigned)(by >> 32), false, false);
+          const double ax = __builtin_bit_cast(double, ((unsigned long long)(unsigned)sxh[0] << 32) | (unsigned)sxl[0]);
+          const double bxx = __builtin_bit_cast(double, ((unsigned long long)(unsigned)sxh[1] << 32) | (unsigned)sxl[1]);
+          const double ay = __builtin_bit_cast(double, ((unsigned long long)(unsigned)syh[0] << 32) | (unsigned)syl[0]);
+          const double byy = __builtin_bit_cast(double, ((unsigned long long)(unsigned)syh[1] << 32) | (unsigned)syl[1]);
+          // X = conj(A) +- B (r'' = 0: A +- B): real parts A.x +- B.x; imaginary parts -A.y +- B.y, whose overall sign |X|^2 does not see
+          const double xr = __builtin_fma(bxx, sgn_x, ax), xi = __builtin_fma(byy, r ? sgn_y : sgn_x, ay);
+          const float q = (float)__builtin_fma(xi, xi, xr * xr);
+          pw[r] = q;
+          gmax[r >> 3] = fmaxf(gmax[r >> 3], q);
+          if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 1024u * r, AUX_ST);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads and conversions out of the first half's live range
       }
-      const float d0 = power_db(x0), d1 = power_db(x1);
-      db[r] = d0;
-      db[r + 16] = d1;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d0), rout, st_voff, 1024u * r, AUX_ST);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), rout, st_voff, 1024u * (r + 16), AUX_ST);
-      if (HITS) dmax = fmaxf(dmax, fmaxf(d0, d1));
+    } else {
+      // ---- pass 3.  M2 = 32: one 32-point DFT over c per thread: even c -> va, odd c -> vb.
+      //             M2 = 64: this lane's half of a 64-point DFT: c = 4c' + e -> va, c = 4c' + e + 2 -> vb ----
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        va[c] = from_v2f(r3[(M2 == 64 ? 4 * c : 2 * c) * P2]);
+        vb[c] = from_v2f(r3[(M2 == 64 ? 4 * c + 2 : 2 * c + 1) * P2]);
+      }
+      fft16(va);
+      fft16(vb);
+      // U, V = E[r'] +- W_32^r' O[r']: the outputs X[r'], X[r' + 16] themselves (M2 = 32), or this lane's share of them
+      // (M2 = 64: one exchange across the wave's halves finishes the radix-4 step)
+      const float sel = e ? 1.0f : 0.0f, sgn = e ? -1.0f : 1.0f;  // (M2 = 64)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const cf ev = va[OUT16(r)];
+        cf od = vb[OUT16(r)];
+        if (r) {
+          const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
+          const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
+          od = cmul(od, cf{cr, -sr});
+        }
+        cf x0 = ev + od, x1 = ev - od;
+        if constexpr (M2 == 64) {
+          if (r) {  // W_64^r' in the odd half, 1 in the even half (branch-free: both halves run the same code)
+            const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 64.0);
+            const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 64.0);
+            const cf w = cf{e ? cr : 1.0f, -sr * sel};
+            x0 = cmul(x0, w);
+            x1 = cmul(x1, w);
+          }
+          // v_permlane32_swap on two copies of a register leaves the lower half's value in [0] and the upper half's in [1], in BOTH halves
+          auto ax = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0.x), __builtin_bit_cast(unsigned, x0.x), false, false);
+          auto ay = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0.y), __builtin_bit_cast(unsigned, x0.y), false, false);
+          auto bx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x1.x), __builtin_bit_cast(unsigned, x1.x), false, false);
+          auto by = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x1.y), __builtin_bit_cast(unsigned, x1.y), false, false);
+          const cf u0 = cf{__builtin_bit_cast(float, (unsigned)ax[0]), __builtin_bit_cast(float, (unsigned)ay[0])};
+          const cf u1 = cf{__builtin_bit_cast(float, (unsigned)ax[1]), __builtin_bit_cast(float, (unsigned)ay[1])};
+          const cf v0 = cf{__builtin_bit_cast(float, (unsigned)bx[0]), __builtin_bit_cast(float, (unsigned)by[0])};
+          const cf v1 = cf{__builtin_bit_cast(float, (unsigned)bx[1]), __builtin_bit_cast(float, (unsigned)by[1])};
+          x0 = cf{__builtin_fmaf(u1.x, sgn, u0.x), __builtin_fmaf(u1.y, sgn, u0.y)};    // U_0 +- W U_1
+          x1 = cf{__builtin_fmaf(v1.y, sgn, v0.x), __builtin_fmaf(v1.x, -sgn, v0.y)};   // V_0 -+ i W V_1
+        }
+        const float p0 = power_of(x0), p1 = power_of(x1);
+        pw[r] = p0;
+        pw[r + 16] = p1;
+        gmax[r >> 3] = fmaxf(gmax[r >> 3], p0);
+        gmax[2 + (r >> 3)] = fmaxf(gmax[2 + (r >> 3)], p1);
+        if constexpr (SPEC) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p0)), rout, st_voff, 1024u * r, AUX_ST);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p1)), rout, st_voff, 1024u * (r + 16), AUX_ST);
+        }
+      }
+    }
+
+    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));  // pre-filter of the hit path and of the exact half
+    if constexpr (SPEC) {
+      if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {  // groups of eight outputs first, then the outputs of a group that holds a strong bin (see scn_fft_kernel)
+          if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+            for (int r = 8 * g; r < 8 * g + 8; r++) {
+              const float q = pw[r];
+              if (__ballot(q >= SCN_P_EXACT_FROM)) {
+                const float d = db_exact(q);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 1024u * r, AUX_ST);
+              }
+            }
+          }
+        }
+      }
     }
     SCN_STAMP(9);  // exchange-2 reads + pass 3 + dB + stores issued
     if (t == 0) lds_next[0] = !more ? 0xffffffffu : DYN ? wq_buffer(taken) : nxt + gridDim.x;
@@ -1003,32 +1163,8 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
 #endif
     const uint32_t after = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
     if (HITS) {
-      if (__ballot(dmax > args.threshold)) {
-        uint32_t hitmask = 0;
-#pragma unroll
-        for (int r = 0; r < 32; r++) hitmask |= (db[r] > args.threshold) ? (1u << r) : 0u;  // strict >, process.cpp:54
-        hitmask &= keepmask;
-        const uint32_t total = wave_add_u32((uint32_t)__popc(hitmask));
-        if (total) {
-          uint32_t wm = wave_or_u32(hitmask);
-          uint32_t base = 0;
-          if (lane == 0) base = (uint32_t)atomicAdd(&lds_hits[par], (int)total);
-          base = __builtin_amdgcn_readfirstlane(base);
-          // slots [base, base + total) of the buffer's region (never overflows, see scn_fft_kernel)
-          ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-          while (wm) {
-            const int r = __builtin_ctz(wm);  // wave-uniform
-            wm &= wm - 1u;
-            const bool hit = (hitmask >> r) & 1u;
-            const unsigned long long m = __ballot(hit);
-            if (hit) {
-              const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-              if (pos < args.hit_region) region[pos] = ScnDevHit{(jbase + 256u * (uint32_t)r) ^ (N / 2), db[r]};
-            }
-            base += (uint32_t)__popcll(m);
-          }
-        }
-      }
+      if (__ballot(pmax > args.p_lo))
+        scn_record_hits<32>(pw, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
       prev = buf;
       par ^= 1;
     }
@@ -1057,14 +1193,14 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
 }
 }  // namespace
 
-template <int KIND, bool DC, bool HITS>
+template <int KIND, bool DC, bool HITS, bool SPEC>
 __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
-  scn_fft_wide_body<32, KIND, DC, HITS>(args);
+  scn_fft_wide_body<32, KIND, DC, HITS, SPEC>(args);
 }
 
-template <int KIND, bool DC, bool HITS>
+template <int KIND, bool DC, bool HITS, bool SPEC>
 __global__ __launch_bounds__(512, 2) void scn_fft16k_kernel(ScnFftArgs args) {
-  scn_fft_wide_body<64, KIND, DC, HITS>(args);
+  scn_fft_wide_body<64, KIND, DC, HITS, SPEC>(args);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1320,14 +1456,43 @@ static hipError_t launch_with_stop(K k, int grid, uint32_t threads, uint32_t lds
   return hipGetLastError();
 }
 
+// Output mode of a launch: which of the three kernels of a (size, wire format, DC) combination runs
+//   hits && spec: spectrum + hits;   !hits: spectrum only;   hits && !spec: hits only (no stores, no per-bin logarithm)
+template <template <bool, bool, bool> class K>
+static void (*pick_mode(bool dc, bool hits, bool spec))(ScnFftArgs) {
+  if (!hits) return dc ? K<true, false, true>::fn : K<false, false, true>::fn;
+  if (spec) return dc ? K<true, true, true>::fn : K<false, true, true>::fn;
+  return dc ? K<true, true, false>::fn : K<false, true, false>::fn;
+}
 template <int M, int KIND>
-static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s, hipEvent_t stop) {
+struct NarrowK {
+  template <bool DC, bool HITS, bool SPEC>
+  struct T {
+    static constexpr void (*fn)(ScnFftArgs) = scn_fft_kernel<M, KIND, DC, HITS, SPEC>;
+  };
+};
+template <int KIND>
+struct Wide8K {
+  template <bool DC, bool HITS, bool SPEC>
+  struct T {
+    static constexpr void (*fn)(ScnFftArgs) = scn_fft8k_kernel<KIND, DC, HITS, SPEC>;
+  };
+};
+template <int KIND>
+struct Wide16K {
+  // (no hits-only specialisation at 16384 points: without the store instructions hipcc's allocation of this kernel's 256
+  // registers falls apart -- 42 .. 75 VGPRs of persistent twiddles and window taps spilled and reloaded per buffer -- so a
+  // hits-only plan runs the spectrum + hits kernel with a zero-record store descriptor, as all sizes did before round 3)
+  template <bool DC, bool HITS, bool SPEC>
+  struct T {
+    static constexpr void (*fn)(ScnFftArgs) = scn_fft16k_kernel<KIND, DC, HITS, HITS ? true : SPEC>;
+  };
+};
+
+template <int M, int KIND>
+static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
   typedef Geo<M> G;
-  void (*k)(ScnFftArgs) = nullptr;
-  if (dc && hits) k = scn_fft_kernel<M, KIND, true, true>;
-  else if (dc) k = scn_fft_kernel<M, KIND, true, false>;
-  else if (hits) k = scn_fft_kernel<M, KIND, false, true>;
-  else k = scn_fft_kernel<M, KIND, false, false>;
+  void (*k)(ScnFftArgs) = pick_mode<NarrowK<M, KIND>::template T>(dc, hits, spec);
   if (G::LDS_BYTES > 65536u) {
     // > 64 KiB of dynamic LDS needs the opt-in; it is per function AND per device, and a process may
     // drive several GPUs (one plan per consumer thread), so it is simply set on every launch
@@ -1341,24 +1506,20 @@ static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, int num_c
 }
 
 template <int M>
-static hipError_t launch_size(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
+static hipError_t launch_size(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_kind<M, SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream, stop);
-    case SCN_K_SHORT_COMPLEX: return launch_kind<M, SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_kind<M, SCN_K_SHORT>(args, dc, hits, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_kind<M, SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_FLOAT_COMPLEX: return launch_kind<M, SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_kind<M, SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_kind<M, SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_kind<M, SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }
 
-template <int KIND>
-static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s, hipEvent_t stop) {
-  typedef Geo8k G;
-  void (*k)(ScnFftArgs) = nullptr;
-  if (dc && hits) k = scn_fft8k_kernel<KIND, true, true>;
-  else if (dc) k = scn_fft8k_kernel<KIND, true, false>;
-  else if (hits) k = scn_fft8k_kernel<KIND, false, true>;
-  else k = scn_fft8k_kernel<KIND, false, false>;
+template <int M2, void (*(*PICK)(bool, bool, bool))(ScnFftArgs)>
+static hipError_t launch_wide(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
+  typedef GeoWide<M2> G;
+  void (*k)(ScnFftArgs) = PICK(dc, hits, spec);
   // > 64 KiB of dynamic LDS: opt-in per function and per device, set on every launch (see launch_kind)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
   if (e != hipSuccess) return e;
@@ -1367,62 +1528,57 @@ static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, int nu
   return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
 }
 template <int KIND>
-static hipError_t launch_16k_kind(const ScnFftArgs &a, bool dc, bool hits, int num_cus, hipStream_t s, hipEvent_t stop) {
-  typedef GeoWide<64> G;
-  void (*k)(ScnFftArgs) = nullptr;
-  if (dc && hits) k = scn_fft16k_kernel<KIND, true, true>;
-  else if (dc) k = scn_fft16k_kernel<KIND, true, false>;
-  else if (hits) k = scn_fft16k_kernel<KIND, false, true>;
-  else k = scn_fft16k_kernel<KIND, false, false>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  int grid = num_cus * (int)G::WG_PER_CU;
-  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
-  return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
+static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
+  return launch_wide<32, pick_mode<Wide8K<KIND>::template T>>(a, dc, hits, spec, num_cus, s, stop);
 }
-static hipError_t launch_16k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
+template <int KIND>
+static hipError_t launch_16k_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
+  return launch_wide<64, pick_mode<Wide16K<KIND>::template T>>(a, dc, hits, spec, num_cus, s, stop);
+}
+static hipError_t launch_16k(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
     // us per 2048-buffer launch, scn_fft_kernel<64> -> wide form: integer formats 94.8 -> 88.5 (scripts/wide16k_check.sh); float
     // input 111.5 -> 101.8 with HALF of a buffer prefetched (its 64 prefetch registers do not fit beside the lane-pair step:
     // 113 us with all 16 two-sample loads prefetched and 22 VGPRs spilled; 0 / 4 / 6 / 8 / 10 / 12 / 14 / 16 prefetched:
     // 110.9 / 107.3 / 105.9 / 101.8 / 105.7 / 108.5 / 107.1 / 113.1, scripts/wide16k_float_check.sh)
 #if SCN_WIDE_16384_FLOAT
-    case SCN_K_FLOAT_COMPLEX: return launch_16k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream, stop);
+    case SCN_K_FLOAT_COMPLEX: return launch_16k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
 #else
-    case SCN_K_FLOAT_COMPLEX: return launch_size<64>(kind, false, hits, args, num_cus, stream, stop);
+    case SCN_K_FLOAT_COMPLEX: return launch_size<64>(kind, false, hits, spec, args, num_cus, stream, stop);
 #endif
-    case SCN_K_SHORT_COMPLEX: return launch_16k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_16k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_16k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_16k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_16k_kind<SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_16k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }
-static hipError_t launch_8k(int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
+static hipError_t launch_8k(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_8k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, num_cus, stream, stop);
-    case SCN_K_SHORT_COMPLEX: return launch_8k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_8k_kind<SCN_K_SHORT>(args, dc, hits, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_8k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, num_cus, stream, stop);
+    case SCN_K_FLOAT_COMPLEX: return launch_8k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_8k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_8k_kind<SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_8k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, const ScnFftArgs &args, int num_cus,
+hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus,
                           hipStream_t stream, hipEvent_t stop) {
+  if (!hits && !spec) return hipErrorInvalidValue;
   if (args.n_buffers == 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
   switch (n) {
-    case 1024: return launch_size<4>(kind, dc, hits, args, num_cus, stream, stop);
-    case 2048: return launch_size<8>(kind, dc, hits, args, num_cus, stream, stop);
-    case 4096: return launch_size<16>(kind, dc, hits, args, num_cus, stream, stop);
+    case 1024: return launch_size<4>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 2048: return launch_size<8>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 4096: return launch_size<16>(kind, dc, hits, spec, args, num_cus, stream, stop);
 #if SCN_WIDE_8192
-    case 8192: return launch_8k(kind, dc, hits, args, num_cus, stream, stop);
+    case 8192: return launch_8k(kind, dc, hits, spec, args, num_cus, stream, stop);
 #else
-    case 8192: return launch_size<32>(kind, dc, hits, args, num_cus, stream, stop);  // the 512-thread form (variant build)
+    case 8192: return launch_size<32>(kind, dc, hits, spec, args, num_cus, stream, stop);  // the 512-thread form (variant build)
 #endif
 #if SCN_WIDE_16384
-    case 16384: return launch_16k(kind, dc, hits, args, num_cus, stream, stop);
+    case 16384: return launch_16k(kind, dc, hits, spec, args, num_cus, stream, stop);
 #else
-    case 16384: return launch_size<64>(kind, dc, hits, args, num_cus, stream, stop);  // the 1024-thread form (variant build)
+    case 16384: return launch_size<64>(kind, dc, hits, spec, args, num_cus, stream, stop);  // the 1024-thread form (variant build)
 #endif
     default: return hipErrorInvalidValue;
   }

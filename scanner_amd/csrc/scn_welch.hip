@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, SCN_WELCH_ROWS_WPS) void scn_welch_rows_kernel
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.psd_db + (size_t)psd * WN, WN * 4u);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-      const float d = 1.50514997831990597607f * __builtin_amdgcn_logf(acc[q] * args.inv_k);  // 5*log10(mean)
+      const float d = db_of_power(acc[q] * args.inv_k);  // 5*log10(mean), the dB map of scn_device.h
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, q * 16384u, 0);
     }
   } else {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void scn_welch_combine_kernel(ScnWelchArgs arg
     for (uint32_t part = 1; part < args.parts; part++) sum += reinterpret_cast<const v4f *>(args.partial)[(size_t)part * total4 + e];
     v4f d;
 #pragma unroll
-    for (int c = 0; c < 4; c++) d[c] = 1.50514997831990597607f * __builtin_amdgcn_logf(sum[c] * args.inv_k);  // 5*log10(mean)
+    for (int c = 0; c < 4; c++) d[c] = db_of_power(sum[c] * args.inv_k);  // 5*log10(mean), the dB map of scn_device.h
     reinterpret_cast<v4f *>(args.psd_db)[e] = d;
   }
 }

@@ -18,6 +18,7 @@ FileSource::FileSource(const std::string &path, uint32_t sampleRate, uint32_t sa
 bool FileSource::Start() { return m_file != nullptr; }
 
 FileSource::~FileSource() {
+  StopThread();  // the producer may be inside ReadOne: join it BEFORE the file is closed
   if (m_file) fclose(m_file);
 }
 

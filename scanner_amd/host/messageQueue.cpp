@@ -175,8 +175,13 @@ void SampleQueue::BeginWrite(uint64_t startSequenceId, std::string fileName) {
   std::unique_lock<std::mutex> lock(m_historyMutex);
   m_writeStart = startSequenceId;
   m_writeEnd = std::numeric_limits<uint64_t>::max();
+  // a capture still waiting for its EndWrite when the next trigger begins ends where the new one starts
+  if (!m_captures.empty() && m_captures.back().open) {
+    m_captures.back().end = startSequenceId;
+    m_captures.back().open = false;
+  }
   if (file) {
-    m_captures.push_back(CaptureJob{file, startSequenceId, m_writeEnd});
+    m_captures.push_back(CaptureJob{file, startSequenceId, m_writeEnd, true});
     m_writeWake.notify_one();
   }
 }
@@ -185,7 +190,12 @@ void SampleQueue::EndWrite(uint64_t sequenceId) {
   printf("EndWrite %lu\n", (unsigned long)sequenceId);  // messageQueue.h:285
   std::unique_lock<std::mutex> lock(m_historyMutex);
   m_writeEnd = sequenceId;
-  if (!m_captures.empty()) m_captures.back().end = sequenceId;
+  // only the job the matching BeginWrite queued gets its end: if that BeginWrite queued nothing (writing switched off, or
+  // its file could not be opened) the newest job belongs to an EARLIER trigger whose end is already fixed -- leave it alone
+  if (!m_captures.empty() && m_captures.back().open) {
+    m_captures.back().end = sequenceId;
+    m_captures.back().open = false;
+  }
   m_writeWake.notify_one();
 }
 

@@ -120,6 +120,7 @@ class SampleQueue {
   struct CaptureJob {
     FILE *file;
     uint64_t next, end;  // the writer still owes the records with ids in [next, end)
+    bool open;           // its EndWrite has not come yet: `end` is still the placeholder
   };
   void WriteThreadWorker();
   bool WriterNeeds(uint64_t sequenceId) const;  // some queued capture has not dumped this record yet

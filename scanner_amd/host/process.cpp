@@ -23,6 +23,14 @@ bool ProcessSamples::Ok(int st, const char *what) {
   return false;
 }
 
+bool ProcessSamples::Fail(const std::string &text) {
+  fprintf(stderr, "%s\n", text.c_str());
+  std::lock_guard<std::mutex> g(m_errorMutex);
+  if (m_error.empty()) m_error = text;
+  m_failed = true;
+  return false;
+}
+
 std::string ProcessSamples::GetLastError() {
   std::lock_guard<std::mutex> g(m_errorMutex);
   return m_error;
@@ -122,7 +130,12 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   size_t stageBytes = 0, bufBytes = 0;
   for (int s = 0; s < SCN_NUM_SLOTS; s++)
     if (!Ok(scn_host_buffer(plan, s, (void **)&stage[s], &stageBytes), "scn_host_buffer")) return abandon(plan);
-  if (!Ok(scn_buffer_bytes(plan, &bufBytes), "scn_buffer_bytes") || bufBytes != q.GetBufferBytes()) return abandon(plan);
+  if (!Ok(scn_buffer_bytes(plan, &bufBytes), "scn_buffer_bytes")) return abandon(plan);
+  if (bufBytes != q.GetBufferBytes()) {  // the queue was built for another sample kind / count than this ProcessSamples
+    Fail("ProcessSamples: the queue's buffers are " + std::to_string(q.GetBufferBytes()) + " bytes, the plan's " + std::to_string(bufBytes) +
+         " (sample kind or count mismatch)");
+    return abandon(plan);
+  }
 
   std::vector<double> fc(d.max_batch);
   std::vector<uint64_t> seq(d.max_batch);

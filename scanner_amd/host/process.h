@@ -56,6 +56,7 @@ class ProcessSamples {
   void UpdateEndSequenceId(uint64_t newEndSequenceId);
   void ProcessWrite(bool doWrite, double centerFrequency, uint64_t sequenceId);
   bool Ok(int status, const char *what);  // logs and remembers the first failed C-ABI call
+  bool Fail(const std::string &text);     // the same for an error found on this side of the C-ABI; returns false
 
   static const uint32_t MAX_THREADS = 8;  // process.h:49
   uint32_t m_sampleCount, m_sampleRate, m_enob;

@@ -53,7 +53,9 @@ SignalSource::SignalSource(uint32_t sampleRate, uint32_t sampleCount, double sta
       m_timer(doTiming, 10000) {}  // 10 000 tunes are kept (s_maxIndex, signalSource.h:23)
 
 SignalSource::~SignalSource() {
-  // a front-end destroyed mid-stream must not leave its producer running on a dead object
+  // Last resort only: by now the derived part of the object is gone, so a producer still inside the derived
+  // ThreadWorker is already running on dead members.  Every front-end calls StopThread() first thing in its own
+  // destructor (SyntheticSource, FileSource do); this join merely keeps the std::thread from terminating the process.
   m_finished = true;
   if (m_thread && m_thread->joinable()) m_thread->join();
 }

@@ -26,6 +26,7 @@ SyntheticSource::SyntheticSource(uint32_t sampleRate, uint32_t sampleCount, doub
 }
 
 SyntheticSource::~SyntheticSource() {
+  StopThread();  // the producer may be inside Generate / the dump fwrite: join it BEFORE the members it uses go away
   if (m_dump) fclose(m_dump);
 }
 

@@ -44,6 +44,11 @@ class Plan:
         self._keep = [None] * capi.NUM_SLOTS
 
     # -- lifetime -----------------------------------------------------------
+    @property
+    def handle(self):
+        """the scn_plan* (for C-ABI calls that take a plan: scn_gather_hits_device)"""
+        return self._h
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._L.scn_plan_destroy(self._h)

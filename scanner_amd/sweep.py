@@ -67,27 +67,33 @@ class HitGather:
             return self._gather_rccl(hits, dst)
         return self._gather_torch(hits, dst)
 
-    def _gather_rccl(self, hits, dst):
+    def _gather_rccl(self, hits, dst, plan=None, slot=0):
+        """ONE collective (counts, then the records straight into the root's device list); the root then reads the list --
+        whose length it only knows now -- into an exact-size array with scn_gather_fetch, a local call.  With `plan`,
+        this rank's part is the slot's ordered list as the compaction kernel left it in device memory (no host staging)."""
         L = capi.lib()
         total = C.c_uint64()
         per_rank = np.zeros(self.world, np.uint32)
-        # first call learns the total (all == NULL), the root then receives into an exact-size array
-        out = None
         vp = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)  # noqa: E731
-        if self.rank == dst:
-            # counts are only known after the all-gather inside the call: size for the worst case cheaply by asking twice
-            st = L.scn_gather_hits(self._comm, vp(hits), len(hits), dst, None, 0, C.byref(total),
-                                   per_rank.ctypes.data_as(C.c_void_p))
+        if plan is not None:
+            st = L.scn_gather_hits_device(self._comm, plan.handle, slot, dst, None, 0, C.byref(total), per_rank.ctypes.data_as(C.c_void_p))
+            capi.check(st, "scn_gather_hits_device")
+        else:
+            st = L.scn_gather_hits(self._comm, vp(hits), len(hits), dst, None, 0, C.byref(total), per_rank.ctypes.data_as(C.c_void_p))
             capi.check(st, "scn_gather_hits")
-            out = np.zeros(total.value, capi.HIT_DTYPE)
-            st = L.scn_gather_hits(self._comm, vp(hits), len(hits), dst, vp(out), out.size, C.byref(total),
-                                   per_rank.ctypes.data_as(C.c_void_p))
-            capi.check(st, "scn_gather_hits")
-            return out, per_rank
-        for _ in range(2):
-            capi.check(L.scn_gather_hits(self._comm, vp(hits), len(hits), dst, None, 0, C.byref(total),
-                                         per_rank.ctypes.data_as(C.c_void_p)), "scn_gather_hits")
-        return np.zeros(0, capi.HIT_DTYPE), per_rank
+        if self.rank != dst:
+            return np.zeros(0, capi.HIT_DTYPE), per_rank
+        out = np.zeros(total.value, capi.HIT_DTYPE)
+        got = C.c_uint64()
+        capi.check(L.scn_gather_fetch(self._comm, 0, vp(out), out.size, C.byref(got)), "scn_gather_fetch")
+        assert got.value == total.value
+        return out, per_rank
+
+    def gather_device(self, plan, slot, dst=0):
+        """Every rank passes a plan whose `slot` has been collected; its ordered device list is sent as it is."""
+        if not self._comm:
+            raise RuntimeError("gather_device needs the RCCL communicator (a cuda device)")
+        return self._gather_rccl(None, dst, plan=plan, slot=slot)
 
     def _gather_torch(self, hits, dst):
         import torch

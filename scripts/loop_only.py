@@ -10,17 +10,21 @@ records = len(sys.argv) > 2 and sys.argv[2] == "1"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 kind_name = sys.argv[4] if len(sys.argv) > 4 else "cfloat"
 nb = int(sys.argv[5]) if len(sys.argv) > 5 else 8192
-kind = {"cfloat": capi.KIND_FLOAT_COMPLEX, "int16": capi.KIND_SHORT_COMPLEX}[kind_name]
+kind = {"cfloat": capi.KIND_FLOAT_COMPLEX, "int16": capi.KIND_SHORT_COMPLEX, "int8": capi.KIND_BYTE_COMPLEX}[kind_name]
 dev = torch.device("cuda", 0)
 R = 4
 raws = []
 for r in range(R):
     x = synth.cfloat_batch_torch(n, nb, seed=2 + 1000 * r, device=dev)
-    raws.append(torch.clamp(torch.round(x * 2047.0), -2048, 2047).to(torch.int16).contiguous() if kind_name == "int16" else x)
+    if kind_name == "int16":
+        x = torch.clamp(torch.round(x * 2047.0), -2048, 2047).to(torch.int16).contiguous()
+    elif kind_name == "int8":
+        x = torch.clamp(torch.round(x * 127.0), -128, 127).to(torch.int8).contiguous()
+    raws.append(x)
 outs = [torch.empty((nb, n), dtype=torch.float32, device=dev) for r in range(R)]
 fc = 3e6 + 6e6 * np.arange(nb)
 torch.cuda.synchronize()
-plan = Plan(n, 8000000, 10.0, kind=kind, max_batch=nb, max_hits=nb * 64)
+plan = Plan(n, 8000000, 10.0, kind=kind, enob=8 if kind_name == "int8" else 12, max_batch=nb, max_hits=nb * 64)
 buf = np.zeros(nb * 64, capi.HIT_DTYPE) if records else None
 pend = [False, False]
 t_settle = time.perf_counter()

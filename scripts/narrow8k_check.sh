@@ -4,6 +4,6 @@
 cd "$GRAFT_REPO_ROOT"
 for lib in "" scanner_amd/variants/lib_narrow8k.so scanner_amd/variants/lib_narrowpf.so; do
   for shape in "8192 int16 4096" "8192 int8 4096"; do
-    echo -n "lib=${lib:-product} $shape: "; SCN_LIB=$lib python3 scripts/loop_only.py 1500 0 $shape 2>/dev/null | tail -1
+    echo -n "lib=${lib:-product} $shape: "; SCN_LIB=$lib python3 scripts/loop_only.py 1500 0 $shape | tail -1
   done
 done

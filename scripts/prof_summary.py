@@ -1,4 +1,15 @@
 """Summarise a scripts/prof.sh output directory: per-kernel stats + per-launch PMC averages."""
+def _source_hash():
+    """the build these counters were taken on (scanner_amd.build.source_hash): bench.py only reports them for the same one"""
+    try:
+        import os as _os, sys as _sys
+        _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+        from scanner_amd import build
+        return build.source_hash()
+    except Exception:
+        return None
+
+
 import csv
 import glob
 import json
@@ -94,7 +105,8 @@ if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
     json.dump(dict({"hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write,
                     "kernel_avg_us": sum(kernel_avg_us.values()) if kernel_avg_us else None,
                     "kernels": {k: round(v, 3) for k, v in kernel_avg_us.items()},
-                    "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 correction)"},
+                    "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 correction)",
+                    "build": _source_hash()},
                    **shape),
               open(os.path.join(out, "pmc_traffic.json"), "w"))
 try:

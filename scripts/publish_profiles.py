@@ -4,6 +4,9 @@ summary.txt -> profiles/<tag>_<shape>_rocprofv3_summary.txt, kernel_stats.csv be
 traffic / kernel averages into profiles/measured_shapes.json (what bench.py reads for roofline.traffic)."""
 import json, os, shutil, sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scanner_amd import build as _build
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 shapes_path = os.path.join(ROOT, "profiles", "measured_shapes.json")
@@ -23,6 +26,8 @@ for shape in ("c2", "c3", "c4shape", "c5", "n4096int16", "n4096int8", "n16384cfl
              "read_bytes": int(round(t["read_bytes"])), "write_bytes": int(round(t["write_bytes"])),
              "kernel_avg_us": round(t["kernel_avg_us"], 3), "kernels": t["kernels"],
              "source": f"profiles/{tag}_{shape}_rocprofv3_summary.txt",
+             # which build the counters were taken on (the profiling run writes it; the current tree's hash otherwise)
+             "build": t.get("build") or _build.source_hash(),
              "method": t["method"] + ("; summed over the kernels of one step" if welch else "")}
     shapes[key] = entry
     print(key, entry["kernel_avg_us"], "us")

@@ -6,7 +6,8 @@ from scanner_amd import Plan, capi, synth
 dev = torch.device('cuda', 0)
 names = {capi.KIND_FLOAT_COMPLEX: "cfloat", capi.KIND_SHORT_COMPLEX: "int16", capi.KIND_SHORT: "int16 planar", capi.KIND_BYTE_COMPLEX: "int8"}
 print(f"{'n':>5s} {'format':>13s} {'dc':>3s} | spectrum only | spectrum+hits | hits only | time-domain   (us per launch of 33.5 M samples)")
-for n in (1024, 2048, 4096, 8192, 16384):
+sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192, 16384]
+for n in sizes:
     nb = 8192 * 4096 // n
     base = [synth.cfloat_batch_torch(n, nb, seed=5 + r, device=dev) for r in range(3)]
     fc = 3e6 + 6e6 * np.arange(nb)
@@ -32,6 +33,11 @@ for n in (1024, 2048, 4096, 8192, 16384):
                     if td: p.collect_time_domain(s)
                     else: p.collect(s, False, False)
                 res = []
+                import time
+                t_settle = time.perf_counter()  # out of the idle power state first: creating a plan (allocations) lets the GPU fall
+                k = 0                           # back, and the first ~100 launches after that run at up to half speed
+                while time.perf_counter() - t_settle < 0.35:
+                    p.submit_device(k & 1, xs[k % 3], nb, fc, sync_producer=False); coll(k & 1); k += 1
                 for rnd in range(3):
                     pend = [False, False]
                     for k in range(40):

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_centres, out_dir):
+def _worker(rank, world, port, n_centres, out_dir, silent_rank=-1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,6 +38,8 @@ def _worker(rank, world, port, n_centres, out_dir):
     x = synth.cfloat_batch(n, n_centres, seed=77, sigma=0.1)[lo:hi]
     seq = np.arange(lo, hi, dtype=np.uint64)
     _, hits, _ = O.Oracle(n, fs, 9.0).run(x, fc, seq)
+    if rank == silent_rank:  # a shard that saw nothing: its (empty) list still takes part in the gather
+        hits = hits[:0]
     allh = sweep.gather_hits(hits.astype(capi.HIT_DTYPE), torch.device("cpu"))
     if rank == 0:
         np.save(os.path.join(out_dir, "gathered.npy"), allh)
@@ -61,6 +63,23 @@ def test_sharded_sweep_gather_matches_single_process(tmp_path, oracle_mod, built
     assert len(ref) > 0
     for f in ("seq_id", "i", "power_db", "freq_hz"):
         assert np.array_equal(got[f], ref[f]), f          # rank-major concatenation == global order
+
+
+def test_gather_world_three_with_an_empty_shard(tmp_path, oracle_mod, built_lib):
+    """World size 3, the middle rank's shard holds no detection (a rank whose part of the band is quiet): the
+    gathered list is the concatenation of ranks 0 and 2, in order, and nobody waits for records that never come."""
+    from scanner_amd import capi, sweep, synth
+
+    world, n_centres, n, fs = 3, 10, 1024, 8000000
+    mp.spawn(_worker, args=(world, _free_port(), n_centres, str(tmp_path), 1), nprocs=world, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    _, fc = capi.frequency_table(fs, 0.0, n_centres * 0.75 * fs)
+    x = synth.cfloat_batch(n, n_centres, seed=77, sigma=0.1)
+    _, ref, _ = oracle_mod.Oracle(n, fs, 9.0).run(x, fc, np.arange(n_centres, dtype=np.uint64))
+    lo, hi = sweep.shard_range(n_centres, 1, world)
+    keep = (ref["seq_id"] < lo) | (ref["seq_id"] >= hi)
+    assert keep.any() and not keep.all()
+    assert got.tobytes() == ref[keep].astype(capi.HIT_DTYPE).tobytes()
 
 
 def test_shard_ranges_partition():

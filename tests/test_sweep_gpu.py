@@ -88,6 +88,51 @@ def test_gather_hits_through_rccl_one_rank(torch_cuda):
         assert per_rank.tolist() == [0] and len(got) == 0
 
 
+def test_gather_from_the_slots_device_list_and_fetch_windows(torch_cuda, oracle_mod):
+    """scn_gather_hits_device sends a collected slot's ordered list from where the compaction kernel left it (no host
+    staging); `all == NULL` on the root is the free size query -- the records are exchanged once and read afterwards,
+    whole or window by window, with scn_gather_fetch."""
+    import ctypes as C
+
+    from scanner_amd import Plan, synth
+
+    L = capi.lib()
+    dev = torch_cuda.device("cuda", 0)
+    n, nb, fs, thr = 4096, 64, 8000000, 9.5
+    x = synth.cfloat_batch(n, nb, seed=41)
+    fc = 3e6 + 6e6 * np.arange(nb)
+    with Plan(n, fs, thr, max_batch=nb, max_hits=1 << 16) as plan, sweep.HitGather(dev) as g:
+        plan.submit_device(0, torch_cuda.from_numpy(x.view(np.uint8).reshape(-1)).cuda(), nb, fc)
+        _, h, _ = plan.collect(0, want_power=False, hit_cap=1 << 16)
+        assert len(h) > 100
+        got, per_rank = g.gather_device(plan, 0)                 # counts-only collective call + local fetch inside
+        assert per_rank.tolist() == [len(h)] and got.tobytes() == h.tobytes()
+        # windows of the gathered list, and past its end
+        win = np.zeros(50, capi.HIT_DTYPE)
+        k = C.c_uint64()
+        capi.check(L.scn_gather_fetch(g._comm, 37, win.ctypes.data_as(C.c_void_p), 50, C.byref(k)), "scn_gather_fetch")
+        assert k.value == 50 and win.tobytes() == h[37:87].tobytes()
+        capi.check(L.scn_gather_fetch(g._comm, len(h) - 5, win.ctypes.data_as(C.c_void_p), 50, C.byref(k)), "scn_gather_fetch")
+        assert k.value == 5 and win[:5].tobytes() == h[-5:].tobytes()
+        capi.check(L.scn_gather_fetch(g._comm, len(h), win.ctypes.data_as(C.c_void_p), 50, C.byref(k)), "scn_gather_fetch")
+        assert k.value == 0
+        # a caller buffer that is too small: truncated, nothing lost
+        small = np.zeros(10, capi.HIT_DTYPE)
+        tot = C.c_uint64()
+        st = L.scn_gather_hits_device(g._comm, plan.handle, 0, 0, small.ctypes.data_as(C.c_void_p), 10, C.byref(tot), None)
+        assert st == capi.E_TRUNCATED and tot.value == len(h) and small.tobytes() == h[:10].tobytes()
+        # a slot that was never collected: the rank ANNOUNCES the failure inside the exchange (every rank of a larger
+        # world would return an error instead of waiting for its records) and reports its own status
+        st = L.scn_gather_hits_device(g._comm, plan.handle, 1, 0, None, 0, C.byref(tot), None)
+        assert st == capi.E_STATE and tot.value == 0
+        st = L.scn_gather_hits(g._comm, None, 5, 0, None, 0, C.byref(tot), None)   # a count without a list
+        assert st == capi.E_INVALID
+        st = L.scn_gather_fetch(g._comm, 0, win.ctypes.data_as(C.c_void_p), 50, C.byref(k))
+        assert st == capi.E_STATE                                # the failed gather left no list behind
+        got, _ = g.gather_device(plan, 0)                        # and the communicator is still usable
+        assert got.tobytes() == h.tobytes()
+
+
 def test_bench_c4_line(torch_cuda):
     """bench.py --config c4 end to end (reduced table so the suite stays short; the full table is the test above)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4", "--centres", "4096", "--steps", "4",

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libscanner_hip.so")
-SOURCES = ["scn_kernels.hip", "scn_generic.hip", "scn_hits.hip", "scn_welch.hip", "scn_gather.hip", "scn_api.hip"]
+SOURCES = ["scn_kernels.hip", "scn_generic.hip", "scn_big.hip", "scn_hits.hip", "scn_welch.hip", "scn_gather.hip", "scn_api.hip"]
 HEADERS = ["scn_kernels.h", "scn_device.h", os.path.join("..", "..", "include", "scanner_hip.h")]
 ARCH = "gfx950"
 

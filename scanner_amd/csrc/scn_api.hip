@@ -130,6 +130,7 @@ struct scn_plan {
   // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
   bool direct_counts = false;
   bool generic = false;  // no fused kernel for this size: the staged path of scn_generic.hip
+  bool big = false;      // 65536 points without DC removal: the four-step pair of scn_big.hip
   uint32_t fft_m = 0, log2m = 0;     // ... and its transform length: n for a power of two, >= 2n - 1 for Bluestein
   double *d_twiddle64 = nullptr;     // [fft_m][2]: W_m^k in double (the staged path applies its tables in double)
   double *d_chirp = nullptr;         // Bluestein: [n][2], w[i] = exp(-i pi i^2 / n)
@@ -398,9 +399,28 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   // 16.8 M samples 44 -> 46..58 and 8.4 M 31 -> 29..56 (erratic: short kernels that carry an event get serialised).
   const bool after_is_done = cnt == s.stream && !s.own_stream;  // direct counts on the plan's stream
   hipEvent_t after = (!nb || s.own_stream) ? nullptr : !hits ? s.done : after_is_done ? s.done : s.kernel_done;
-  const bool in_packet = after && !p->generic &&
+  const bool in_packet = after && !p->generic && !p->big &&
                          (p->stop_event_in_packet < 0 ? (uint64_t)nb * n >= (1u << 25) : p->stop_event_in_packet != 0);
-  if (p->generic) {
+  if (p->big) {
+    if (nb && !s.d_gen_work[0]) SCN_HIP(hipMalloc(&s.d_gen_work[0], sizeof(float) * 2 * (size_t)n * p->d.max_batch));
+    ScnBigArgs ba;
+    ba.raw = d_raw;
+    ba.window = p->d_window;
+    ba.twiddle = p->d_twiddle;
+    ba.work = s.d_gen_work[0];
+    ba.power_db = d_power;
+    ba.n_buffers = nb;
+    ba.scale = p->scale;
+    ba.threshold = p->d.threshold;
+    ba.p_lo = a.p_lo;
+    ba.dc_ignore = p->d.dc_ignore_bins;
+    ba.i_lo = p->i_lo;
+    ba.i_hi = p->i_hi;
+    ba.hits = a.hits;
+    ba.hit_region = p->hit_region;
+    ba.per_buffer_hits = a.per_buffer_hits;
+    SCN_HIP(scn_launch_big((int)p->d.sample_kind, hits, d_power != nullptr, ba, p->num_cus, s.stream));
+  } else if (p->generic) {
     for (int g = 0; g < 2 && nb; g++)
       if (!s.d_gen_work[g]) SCN_HIP(hipMalloc(&s.d_gen_work[g], 2u * sizeof(double) * (size_t)p->fft_m * p->d.max_batch));
     ScnGenericArgs ga;
@@ -578,8 +598,9 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     p->fft_cus = p->num_cus;
     if (const char *e = getenv("SCN_EXP_COMPACT")) p->compact_mode = atoi(e);
     if (const char *e = getenv("SCN_EXP_RESERVE_CUS")) p->fft_cus = std::max(1, p->num_cus - atoi(e));
-    p->generic = d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n);
-    p->direct_counts = d.n >= 8192 && !p->generic;
+    p->big = d.mode == SCN_MODE_FREQUENCY_DOMAIN && scn_big_size_supported(d.n) && !(d.correct_dc && d.sample_kind != SCN_KIND_FLOAT_COMPLEX);
+    p->generic = d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !p->big;
+    p->direct_counts = d.n >= 8192 && !p->generic && !p->big;  // (the fused kernels from 8192 points up store the counts to pinned memory themselves)
     if (const char *e = getenv("SCN_EXP_DIRECT_COUNTS")) p->direct_counts = atoi(e) != 0;
     if (const char *e = getenv("SCN_EXP_STOP_EVENT")) p->stop_event_in_packet = atoi(e) != 0 ? 1 : 0;
     SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -658,9 +679,10 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
       SCN_TRY(hipMemcpy(p->d_bfilter, bfilter.data(), sizeof(double) * bfilter.size(), hipMemcpyHostToDevice));
     }
     // the same values, regrouped per thread of the fused kernel: entry (p-1, t) = W_n^(t p), t < n/16
-    const uint32_t nthreads = p->generic ? 1u : d.n / 16;  // (only the fused kernels read it)
-    std::vector<float> tw1(2 * (size_t)15 * nthreads);
-    for (uint32_t pp = 1; pp < 16; pp++)
+    uint32_t tw1_rows = 15, nthreads = 1;  // (only the fused kernels read it)
+    if (!p->generic && !p->big) scn_tw1_layout(d.n, &tw1_rows, &nthreads);
+    std::vector<float> tw1(2 * (size_t)tw1_rows * nthreads);
+    for (uint32_t pp = 1; pp <= tw1_rows; pp++)
       for (uint32_t t = 0; t < nthreads; t++) {
         const uint32_t m = (t * pp) & (tn - 1);
         tw1[2 * ((size_t)(pp - 1) * nthreads + t)] = tw[2 * m];

@@ -189,4 +189,55 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t x) {
   return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// ---- K5, the recording half (process.cpp:54-57), shared by the fused kernels ------------------------------------------
+// `pw` holds the LINEAR powers of this thread's NB bins (bin index i of output o from `bin_i`).  Candidates are found in
+// the linear domain against p_lo (a shade below 10^(threshold / 5), scn_hit_prefilter); the decision itself is
+// magnitudes[j] > m_threshold on the dB value -- the map of scn_device.h, a pure function of the power, so spectrum + hits
+// and hits-only plans decide identically and report the float the spectrum holds -- evaluated only for the output indices
+// some lane of the wave has a candidate in.  Slots of the buffer's region come from ONE LDS atomic per wave.
+// (`args`: anything with p_lo, threshold, hits, hit_region; `count`: the buffer's hit counter, in LDS or in device memory)
+template <int NB, typename VEC, typename ARGS, typename BINI>
+__device__ __forceinline__ void scn_record_hits(VEC &pw, uint32_t keepmask, const ARGS &args, int *lds_count, uint32_t buf, uint32_t lane,
+                                                BINI bin_i) {
+  uint32_t cand = 0;
+#pragma unroll
+  for (int o = 0; o < NB; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
+  cand &= keepmask;
+  uint32_t wmc = wave_or_u32(cand);
+  if (!wmc) return;
+  uint32_t wm = wmc;
+  // the dB value of every output index that has a candidate somewhere in the wave (static indexing, a scalar branch per
+  // index: with a low threshold EVERY index has one, and a data-dependent loop with register-indexed moves cost a
+  // hit-dense 16384-point launch 10 %); the exact half of the map again only where a lane holds a strong bin
+#pragma unroll
+  for (int o = 0; o < NB; o++) {
+    if ((wmc >> o) & 1u) {
+      const float p = pw[o];
+      float d = db_fast(p);
+      if (__ballot(p >= SCN_P_EXACT_FROM)) d = p >= SCN_P_EXACT_FROM ? db_exact(p) : d;
+      pw[o] = d;  // (every lane's slot o now holds its dB value; only hit lanes read it again)
+      if (!(d > args.threshold)) cand &= ~(1u << o);  // strict >, process.cpp:54
+    }
+  }
+  const uint32_t total = wave_add_u32((uint32_t)__popc(cand));
+  if (!total) return;
+  uint32_t base = 0;
+  if (lane == 0) base = (uint32_t)atomicAdd(lds_count, (int)total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  // this wave's records take the buffer's slots [base, base + total); a region holds every bin the mask lets through, so
+  // there is no overflow path (and no global atomic)
+  ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+  while (wm) {
+    const int o = __builtin_ctz(wm);  // wave-uniform
+    wm &= wm - 1u;
+    const bool hit = (cand >> o) & 1u;
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), pw[o]};
+    }
+    base += (uint32_t)__popcll(m);
+  }
+}
+
 }  // namespace

@@ -24,7 +24,7 @@ struct ScnFftArgs {
   const void *raw;          // n_buffers raw buffers back to back
   const float *window;      // [N]
   const scn_v2f *twiddle;   // W_N^m = exp(-2 pi i m / N), m in [0, N)
-  const scn_v2f *tw1_table; // [15][N/16]: entry (p-1, t) = W_N^(t p): the pass-1 constants of thread t, p-major so that a
+  const scn_v2f *tw1_table; // [15][N/16] ([31][512] for 16384 points, scn_tw1_layout): entry (p-1, t) = W_N^(t p): the pass-1 constants of thread t, p-major so that a
                             // wave loads each p with one coalesced 512-byte access (gathered from `twiddle` with lane
                             // stride 8p bytes the same 15 loads made the kernel prologue 6 us, up to 13 us, per launch)
   float *power_db;          // [n_buffers][N] or nullptr
@@ -127,6 +127,23 @@ hipError_t scn_launch_generic(int kind, bool correct_dc, bool hits, const ScnGen
 bool scn_generic_size_supported(uint32_t n);    // powers of two, 16 ... 65536
 bool scn_bluestein_size_supported(uint32_t n);  // everything else from 16 to 32768
 
+// Plain 65536-point plans through the four-step pair of scn_big.hip (columns -> tiled work buffer -> rows + K4 + K5)
+struct ScnBigArgs {
+  const void *raw;            // n_buffers raw buffers back to back
+  const float *window;        // [65536]
+  const scn_v2f *twiddle;     // W_65536^m
+  void *work;                 // [n_buffers][65536] complex float: Y[k1][n2] between the two kernels (tiled)
+  float *power_db;            // [n_buffers][65536] or nullptr
+  uint32_t n_buffers;
+  float scale, threshold, p_lo;
+  uint32_t dc_ignore, i_lo, i_hi;
+  ScnDevHit *hits;            // [n_buffers][hit_region]
+  uint32_t hit_region;
+  uint32_t *per_buffer_hits;  // [n_buffers], zeroed by the launcher
+};
+hipError_t scn_launch_big(int kind, bool hits, bool spectrum, const ScnBigArgs &args, int num_cus, hipStream_t stream);
+bool scn_big_size_supported(uint32_t n);  // 65536 (without DC removal)
+
 // K1 alone (capture path)
 hipError_t scn_launch_convert(int kind, bool correct_dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers,
                               float scale, hipStream_t stream);
@@ -146,3 +163,4 @@ static inline float scn_hit_prefilter(float threshold) {
   return f;
 }
 bool scn_fft_size_supported(uint32_t n);
+void scn_tw1_layout(uint32_t n, uint32_t *rows, uint32_t *threads);  // shape of ScnFftArgs::tw1_table for a fused size

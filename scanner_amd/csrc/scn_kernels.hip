@@ -272,51 +272,6 @@ struct RawLoader<SCN_K_SHORT> {
 #define SCN_STAMP(i)
 #endif
 
-// ---- K5, the recording half (process.cpp:54-57), shared by the fused kernels ------------------------------------------
-// `pw` holds the LINEAR powers of this thread's NB bins (bin index i of output o from `bin_i`).  Candidates are found in
-// the linear domain against p_lo (a shade below 10^(threshold / 5), scn_hit_prefilter); the decision itself is
-// magnitudes[j] > m_threshold on the dB value -- the map of scn_device.h, a pure function of the power, so spectrum + hits
-// and hits-only plans decide identically and report the float the spectrum holds -- evaluated only for the output indices
-// some lane of the wave has a candidate in.  Slots of the buffer's region come from ONE LDS atomic per wave.
-template <int NB, typename VEC, typename BINI>
-__device__ __forceinline__ void scn_record_hits(VEC &pw, uint32_t keepmask, const ScnFftArgs &args, int *lds_count, uint32_t buf, uint32_t lane,
-                                                BINI bin_i) {
-  uint32_t cand = 0;
-#pragma unroll
-  for (int o = 0; o < NB; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
-  cand &= keepmask;
-  uint32_t wmc = wave_or_u32(cand);
-  if (!wmc) return;
-  uint32_t wm = wmc;
-  while (wmc) {
-    const int o = __builtin_ctz(wmc);  // wave-uniform
-    wmc &= wmc - 1u;
-    const float p = pw[o];
-    const float d = db_of_power(p);
-    pw[o] = d;  // (every lane's slot o now holds its dB value; only hit lanes read it again)
-    if (!(d > args.threshold)) cand &= ~(1u << o);  // strict >, process.cpp:54
-  }
-  const uint32_t total = wave_add_u32((uint32_t)__popc(cand));
-  if (!total) return;
-  uint32_t base = 0;
-  if (lane == 0) base = (uint32_t)atomicAdd(lds_count, (int)total);
-  base = __builtin_amdgcn_readfirstlane(base);
-  // this wave's records take the buffer's slots [base, base + total); a region holds every bin the mask lets through, so
-  // there is no overflow path (and no global atomic)
-  ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-  while (wm) {
-    const int o = __builtin_ctz(wm);  // wave-uniform
-    wm &= wm - 1u;
-    const bool hit = (cand >> o) & 1u;
-    const unsigned long long m = __ballot(hit);
-    if (hit) {
-      const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), pw[o]};
-    }
-    base += (uint32_t)__popcll(m);
-  }
-}
-
 template <int M>
 struct Geo {
   static constexpr uint32_t N = 256u * M;
@@ -700,6 +655,221 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 }
 
 // ------------------------------------------------------------------------------------
+// 256 and 512 points (round 3): SEVERAL buffers per workgroup.
+//
+// The reference plans whatever --count it is given (fft.cpp:4-11, scan.cpp:85); below 1024 points the 16 x 16 x M form has
+// M = 2 or 1, i.e. 32 or 16 threads per buffer -- half or a quarter of a wave.  A 256-thread workgroup therefore carries
+// SLOTS = 8 (512 points) or 16 (256 points) consecutive buffers per iteration, each in its own LDS region, through the same
+// three passes as scn_fft_kernel (n = T a + M b + c, k = p + 16 q + 256 r, the same padded layouts: P1 = T + M,
+// P2 = 256 + 16 / M, conflict-free within the 16-lane groups a ds_*_b64 is served in):
+//   pass 1  thread t = M b + c of a slot: 16-pt DFT over a of x[T a + t] w[T a + t] -> * W_N^(t p) -> LDS row p
+//   pass 2  thread (p, c): 16-pt DFT over b -> * W_(16 M)^(c q) -> LDS
+//   pass 3  M = 2: eight radix-2 butterflies per thread (kl = t + 32 u -> bins kl, kl + 256);  M = 1: nothing left to transform,
+//           the exchange only transposes (thread t stores bins t + 16 u)
+// One buffer descriptor spans the workgroup's SLOTS consecutive buffers (a wave holds two or four of them, so a per-buffer
+// descriptor would not be wave-uniform); slots past the end of the batch read zeros and store nothing (range check).
+// Hits: a wave is no longer one buffer, so slots in a buffer's region come from one LDS atomic per HIT (rare) on the slot's
+// counter instead of one per wave.  These sizes ran the staged double-precision path (scn_generic.hip) at 40 Gsamples/s.
+// ------------------------------------------------------------------------------------
+namespace {
+template <int M>
+struct GeoSmall {
+  static constexpr uint32_t N = 256u * M, T = 16u * M, SLOTS = 256u / T;
+  static constexpr uint32_t P1 = T + M, P2 = 256u + 16u / M;
+  static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots per buffer
+  static constexpr uint32_t LDS_BYTES = SLOTS * EXCH * 8u + T * 8u + SLOTS * 4u + 16u;
+  static constexpr uint32_t WG_PER_CU = 3;
+};
+}  // namespace
+
+template <int M, int KIND, bool DC, bool HITS, bool SPEC>
+__global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) {
+  static_assert(M == 1 || M == 2, "256 or 512 points");
+  static_assert(HITS || SPEC, "a kernel that reports nothing");
+  typedef GeoSmall<M> G;
+  constexpr int AUX_LD = SCN_AUX_LD;
+  constexpr int AUX_ST = SCN_AUX_ST;
+  constexpr uint32_t N = G::N, T = G::T, SLOTS = G::SLOTS, P1 = G::P1, P2 = G::P2;
+  typedef RawLoader<KIND> L;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint32_t tid = threadIdx.x, t = tid % T, slot = tid / T;
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw) + slot * G::EXCH;                     // this buffer's exchange area
+  v2f *lds_tw2 = reinterpret_cast<v2f *>(smem_raw) + SLOTS * G::EXCH;                // [16][M], shared by the slots
+  int *lds_hits = reinterpret_cast<int *>(lds_tw2 + T);                              // [SLOTS]
+  const uint32_t p2 = t / M, c2 = t % M;
+  const uint32_t buf_bytes = L::kBufBytes(N);
+
+  // the iteration's SLOTS consecutive buffers under one descriptor (zero records past the end of the batch)
+  auto in_rsrc = [&](uint32_t first) {
+    const bool ok = first < args.n_buffers;
+    const uint32_t nb = ok ? (args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS) : 0u;
+    return make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(ok ? first : 0u) * buf_bytes, SCN_EXP_NO_LOADS ? 0u : nb * buf_bytes);
+  };
+  // planar int16 reads I and Q of a buffer n samples apart: the loader takes the buffer's own sample count, the slot offset
+  // goes into the index (in samples of the loader's element size)
+  typename L::raw_t raw[16];
+  auto load_group = [&](const __amdgpu_buffer_rsrc_t &r, int a_lo, int a_hi) {
+#pragma unroll
+    for (int a = 0; a < 16; a++)
+      if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(r, N, t, slot * (KIND == SCN_K_SHORT ? 2u * N : N) + T * a);
+  };
+  uint32_t first = blockIdx.x * SLOTS;
+  load_group(in_rsrc(first), 0, 16);
+
+  cf tw1[16];
+#pragma unroll
+  for (int p = 1; p < 16; p++) tw1[p] = from_v2f(args.tw1_table[(p - 1) * T + t]);
+  float win[16];
+#pragma unroll
+  for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t] * args.scale;
+  if (slot == 0) lds_tw2[t] = args.twiddle[(16 * p2 * c2) & (N - 1)];  // W_(16 M)^(c q) = W_N^(16 c q), entry q*M + c
+  if (tid < SLOTS) lds_hits[tid] = 0;
+  __syncthreads();
+
+  v2f *w1 = lds + t;                      // + p*P1
+  v2f *r1 = lds + p2 * P1 + c2;           // + b*M
+  v2f *w2 = lds + c2 * P2 + p2;           // + 16*q
+  v2f *r3 = lds + t;                      // + c*P2 + T*u
+  const v2f *tw2 = lds_tw2 + c2;          // + q*M
+  auto joff_of = [](int o) -> uint32_t { return T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M); };  // output o is bin t + joff_of(o)
+  uint32_t keepmask = 0;
+  if (HITS) {
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+      const uint32_t j = t + joff_of(o);
+      const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
+      const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
+      keepmask |= keep ? (1u << o) : 0u;
+    }
+  }
+
+  for (; first < args.n_buffers; first += gridDim.x * SLOTS) {
+    const uint32_t buf = first + slot;
+    const bool valid = buf < args.n_buffers;
+    int dc_re = 0, dc_im = 0;
+    if (DC) {
+      // integer mean with the reference's int32 /= uint32 quirk (utility.cpp:77-78), summed over the T lanes of this buffer
+      int sr = 0, si = 0;
+#pragma unroll
+      for (int a = 0; a < 16; a++) {
+        int re, im;
+        L::ints(raw[a], re, im);
+        sr += re;
+        si += im;
+      }
+#pragma unroll
+      for (uint32_t off = T / 2; off > 0; off >>= 1) {
+        sr += __shfl_xor(sr, (int)off, 64);
+        si += __shfl_xor(si, (int)off, 64);
+      }
+      dc_re = (int)((uint32_t)sr / N);
+      dc_im = (int)((uint32_t)si / N);
+    }
+    cf v[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, 1.0f) * win[a];
+    const __amdgpu_buffer_rsrc_t rn = in_rsrc(first + gridDim.x * SLOTS);
+    load_group(rn, 0, 6);
+
+    // ---- pass 1 ----
+    fft16(v);
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      cf y = v[OUT16(p)];
+      if (p) y = cmul(y, tw1[p]);
+      w1[p * P1] = to_v2f(y);
+    }
+    __syncthreads();
+    // ---- pass 2 ----
+#pragma unroll
+    for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * M]);
+    load_group(rn, 6, 11);
+    fft16(v);
+#pragma unroll
+    for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * M]));
+    __syncthreads();  // every exchange-1 read done before the area is re-used
+    load_group(rn, 11, 16);
+#pragma unroll
+    for (int q = 0; q < 16; q++) w2[q * 16] = to_v2f(v[OUT16(q)]);
+    __syncthreads();
+    // ---- pass 3 ----
+#pragma unroll
+    for (int u = 0; u < 16 / M; u++)
+#pragma unroll
+      for (int c = 0; c < M; c++) v[u * M + c] = from_v2f(r3[c * P2 + T * u]);
+    if constexpr (M == 2) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const cf a = v[2 * u], b = v[2 * u + 1];
+        v[2 * u] = a + b;      // r = 0
+        v[2 * u + 1] = a - b;  // r = 1
+      }
+    }
+    // ---- K4 (see scn_fft_kernel) ----
+    v16f pw;
+    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t nvalid = args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS;
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? nvalid * 4u * N : 0u);
+    const uint32_t st_voff = (slot * N + t) * 4u;
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+      const float q = power_of(v[o]);
+      pw[o] = q;
+      gmax[o >> 2] = fmaxf(gmax[o >> 2], q);
+      if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 4u * joff_of(o), AUX_ST);
+    }
+    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
+    if constexpr (SPEC) {
+      if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+            for (int o = 4 * g; o < 4 * g + 4; o++) {
+              const float q = pw[o];
+              if (__ballot(q >= SCN_P_EXACT_FROM)) {
+                const float d = db_exact(q);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 4u * joff_of(o), AUX_ST);
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- K5: a wave holds several buffers here, so every hit takes its slot of the region with its own LDS atomic ----
+    if (HITS) {
+      if (__ballot(valid && pmax > args.p_lo)) {
+        uint32_t cand = 0;
+#pragma unroll
+        for (int o = 0; o < 16; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
+        cand &= valid ? keepmask : 0u;
+        uint32_t wm = wave_or_u32(cand);
+        ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+        while (wm) {
+          const int o = __builtin_ctz(wm);  // wave-uniform
+          wm &= wm - 1u;
+          const float q = pw[o];
+          float d = db_fast(q);
+          if (__ballot(q >= SCN_P_EXACT_FROM)) d = q >= SCN_P_EXACT_FROM ? db_exact(q) : d;
+          if (((cand >> o) & 1u) && d > args.threshold) {  // strict >, process.cpp:54
+            const uint32_t pos = (uint32_t)atomicAdd(&lds_hits[slot], 1);
+            if (pos < args.hit_region) region[pos] = ScnDevHit{(t + joff_of(o)) ^ (N / 2), d};
+          }
+        }
+      }
+    }
+    __syncthreads();  // exchange areas free again; the slots' hit counters final
+    if (HITS && t == 0) {
+      if (valid) {
+        args.per_buffer_hits[buf] = (uint32_t)lds_hits[slot];
+        if (args.host_hits) args.host_hits[buf] = (uint32_t)lds_hits[slot];
+      }
+      lds_hits[slot] = 0;  // (the next recording is three barriers away)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // 8192 points, wide form: ONE workgroup of 256 threads per buffer, 32 points per thread.
 //
 // Same decomposition as above (n = 512a + 32b + c, k = p + 16q + 256r, passes 16 x 16 x 32), but every
@@ -732,11 +902,14 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 #define SCN_WIDE_16384 1  // 16384 points: 512 threads x 32 points with a register prefetch instead of scn_fft_kernel<64>
 #endif
 #ifndef SCN_16K_P3_DOUBLE
-// EXPERIMENT, off in the product: pass 3 of the 16384-point kernel in double.  Measured on MI355X (profiles/r03_experiments.md):
-// the parity metric's tail on 3072 strong-tone buffers drops from 0.6e-5 .. 1.05e-5 to 2.2e-6 .. 3.1e-6 (the float dB
-// quantisation floor), but the lane-pair form of this kernel pays +38 % (88.6 -> 122 us spectrum-only) for the conversions,
-// the doubled lane exchange and 13 .. 35 spilled registers, and the hits-only variant does not fit the register file at all.
-#define SCN_16K_P3_DOUBLE 0
+// Pass 3 of the 16384-point kernel in double (scn_fft16k2_body).  Measured on MI355X, 3072 strong-tone buffers per run
+// (scripts/acc16k.py) and us per 2048-buffer launch, float pass 3 -> double: parity metric max 4.9e-6 .. 7.5e-6 -> 2.9e-6 .. 4.0e-6,
+// p99 4.0e-6 -> 2.2e-6, median 1.11e-6 -> 0.88e-6 (the float quantisation of the dB value itself); cfloat 93.5 -> 100.2 us,
+// int16 75.6 -> 88.1 (+7 % / +16 %: 128 conversions and 1.2 .. 1.4x on a third of the arithmetic).  Round 2's kernel of this
+// size (16 x 16 x 64 with a lane-pair last pass, float) took 100.6 / 95.7 us on the same box and reached 1.05e-5: the bar.
+// Parity comes first, so double is the product; -DSCN_16K_P3_DOUBLE=0 is the float build.  (In the round-2 form of the
+// kernel the same change cost +38 % and spilled: the lane exchange doubles, and its registers do not fit.)
+#define SCN_16K_P3_DOUBLE 1
 #endif
 #ifndef SCN_8K_PAIR
 #define SCN_8K_PAIR 1  // the wide kernel's threads play neighbouring virtual threads (two-sample loads, 16-byte exchange-1 writes)
@@ -1193,6 +1366,316 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------
+// 16384 points as 32 x 16 x 32 (round 3): 512 threads x 32 points, one workgroup per CU.
+//
+//   n = 512 a + 32 b + c          k = p + 32 q + 512 r          a, p, c, r in [0, 32)   b, q in [0, 16)
+//   pass 1  thread tau = 32 b + c:  32-pt DFT over a of x[512 a + tau] w[..] (two 16-pt DFTs + one radix-2 step, in
+//           registers) -> * W_N^(tau p) -> LDS row p                                    L1(p, tau) = 512 p + tau
+//   pass 2  threads (p, c) and (p + 16, c):  16-pt DFT over b -> * W_512^(c q) -> LDS    L2(c, kl) = 513 c + kl, kl = p + 32 q
+//   pass 3  thread kl:  32-pt DFT over c -> X[kl + 512 r], r = 0 .. 31 -- a WHOLE DFT per thread
+//
+// The first form (scn_fft_wide_body<64>: 16 x 16 x 64) shares its 64-point last pass between two lanes: a twiddle multiply
+// of every value by W_64^r', a v_permlane32_swap per register and a combining step -- 280 of its ~1700 VALU operations per
+// thread and buffer.  Here pass 1 takes the extra radix-2 level instead (one more twiddle-free step on values that are in
+// registers anyway): ~150 operations fewer, no cross-lane traffic, every output bin of a lane 512 apart.  All four LDS access
+// patterns are conflict-free in the 16-lane groups a ds_*_b64 is served in (row pitch 513 on the transposed side).
+// Price: one virtual thread per lane in pass 1, so the samples arrive one per load (32 loads of 8 / 4 / 2 bytes per
+// lane instead of 16 of twice that).
+// With SCN_16K_P3_DOUBLE pass 3 runs in double (decimation in frequency, 16 double values live at a time): the parity
+// metric's tail at this size is the float rounding of a strong tone's partial sums in the LAST pass, which lands on the 31
+// other bins of the tone's column -- any float32 FFT shows it (scripts/emul_fused.py) -- and goes away 3x when the last five
+// radix-2 levels are exact.  v_add_f64 / v_fma_f64 issue at 0.85x / 0.7x the float rate (scripts/ubench/f64_rate.hip).
+// ------------------------------------------------------------------------------------
+#ifndef SCN_16K_V2
+#define SCN_16K_V2 1
+#endif
+#ifndef SCN_16K2_FLOAT_PFN
+#define SCN_16K2_FLOAT_PFN 16  // float input: how many of a buffer's 32 loads are prefetched across the previous buffer's passes
+#endif
+#ifndef SCN_16K2_INT_PFN
+#define SCN_16K2_INT_PFN 32
+#endif
+namespace {
+struct Geo16k2 {
+  static constexpr uint32_t N = 16384, T = 512, P1 = 512, P2 = 513;
+  static constexpr uint32_t EXCH = 32u * P2;  // slots (exchange 1 needs 32 * 512)
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 2u * 4u + 8u;
+  static constexpr uint32_t WG_PER_CU = 1;
+};
+
+template <int KIND, bool DC, bool HITS, bool SPEC>
+__device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
+  static_assert(HITS || SPEC, "a kernel that reports nothing");
+  typedef Geo16k2 G;
+  constexpr bool P3D = SCN_16K_P3_DOUBLE != 0;
+  constexpr int AUX_LD = SCN_AUX_LD;
+  constexpr int AUX_ST = SCN_AUX_ST;
+  constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
+  typedef RawLoader<KIND> L;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+  v2f *lds_tw2 = lds + G::EXCH;                             // [16][32]: W_512^(c q) at 32 q + c
+  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T);     // [16] DC-sum scratch (re[8], im[8])
+  int *lds_hits = lds_cnt + 16;                            // [2] hit counters, alternating per buffer
+
+  const uint32_t t = threadIdx.x;
+  const uint32_t lane = t & 63, wave = t >> 6;
+  const uint32_t c2 = t & 31u, p2 = t >> 5;  // pass 2: (p2, c2) and (p2 + 16, c2), p2 < 16
+  // loads prefetched, in three groups (planar int16 is two loads and a pack per sample: beside the double-precision pass 3 only half)
+  constexpr int PFN = KIND == SCN_K_FLOAT_COMPLEX ? SCN_16K2_FLOAT_PFN : (P3D && KIND == SCN_K_SHORT) ? 16 : SCN_16K2_INT_PFN;
+  constexpr int PF0 = (3 * PFN) / 8, PF1 = (11 * PFN) / 16;
+
+  // first buffer's samples first: raw[a] = x[512 a + t]
+  typename L::raw_t raw[32];
+  auto load_group = [&](const __amdgpu_buffer_rsrc_t &r, int a_lo, int a_hi) {
+#pragma unroll
+    for (int a = 0; a < 32; a++)
+      if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(r, N, t, 512u * a);
+  };
+  if (blockIdx.x < args.n_buffers) {
+    __amdgpu_buffer_rsrc_t r0 =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+    load_group(r0, 0, PFN);
+  }
+  // persistent constants: W_N^(t p), p = 1 .. 31 (table rows of 512, scn_tw1_layout), window taps.  With pass 3 in double only
+  // p = 1 .. 16 are kept and W_N^(t (p' + 16)) = W_N^(t p') W_N^(16 t) is formed per buffer: 15 more complex multiplies
+  // (+3 % of the kernel's arithmetic) buy the 30 registers the double-precision values of pass 3 need -- spilled instead,
+  // they cost 30 .. 90 % (scratch reloads at the top of every buffer).
+  constexpr int TWN = P3D ? 17 : 32;
+  cf tw1[TWN];
+#pragma unroll
+  for (int p = 1; p < TWN; p++) tw1[p] = from_v2f(args.tw1_table[(p - 1) * 512 + t]);
+  float win[32];
+#pragma unroll
+  for (int a = 0; a < 32; a++) win[a] = args.window[512u * a + t] * args.scale;
+  lds_tw2[t] = args.twiddle[(32u * p2 * c2) & (N - 1)];  // W_512^(c q) = W_N^(32 c q), entry 32 q + c = t
+  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
+  __syncthreads();
+
+  v2f *w1 = lds + t;                       // + p*P1
+  v2f *r1 = lds + p2 * P1 + c2;            // + 32 b (+ 16*P1 for the second virtual thread)
+  v2f *w2 = lds + c2 * P2 + p2;            // + 32 q (+ 16 for the second)
+  v2f *r3 = lds + t;                       // + c*P2
+  const v2f *tw2 = lds_tw2 + c2;           // + 32 q
+  const uint32_t st_voff = t * 4u;         // output o of this thread is bin j = t + 512 o
+
+  uint32_t keepmask = 0;  // K5 mask of this thread's 32 bins (process.cpp:46-52)
+  if (HITS) {
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+      const uint32_t j = t + 512u * r;
+      const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
+      const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
+      keepmask |= keep ? (1u << r) : 0u;
+    }
+  }
+  uint32_t par = 0;
+  uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running
+
+  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {  // (static assignment: one workgroup per CU)
+    const uint32_t nxt = buf + gridDim.x;
+    const bool more = nxt < args.n_buffers;
+    if (PFN < 32) {  // the part of this buffer that was not prefetched
+      const __amdgpu_buffer_rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N),
+                                                  SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+      load_group(rc, PFN, 32);
+    }
+    // ---- K1 + K2 ----
+    int dc_re = 0, dc_im = 0;
+    if (DC) {
+      int sr = 0, si = 0;
+#pragma unroll
+      for (int a = 0; a < 32; a++) {
+        int re, im;
+        L::ints(raw[a], re, im);
+        sr += re;
+        si += im;
+      }
+      sr = wave_sum(sr);
+      si = wave_sum(si);
+      if (lane == 0) {
+        lds_cnt[wave] = sr;
+        lds_cnt[8 + wave] = si;
+      }
+      __syncthreads();
+      sr = si = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < T / 64u; w++) {
+        sr += lds_cnt[w];
+        si += lds_cnt[8 + w];
+      }
+      dc_re = (int)((uint32_t)sr / N);  // int32 /= uint32, utility.cpp:77-78
+      dc_im = (int)((uint32_t)si / N);
+    }
+    cf va[16], vb[16];  // even / odd a
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+      va[a] = L::conv(raw[2 * a], dc_re, dc_im, 1.0f) * win[2 * a];
+      vb[a] = L::conv(raw[2 * a + 1], dc_re, dc_im, 1.0f) * win[2 * a + 1];
+    }
+    // next buffer of this workgroup, branch-free (zero records past the end), in three groups
+    const __amdgpu_buffer_rsrc_t rn =
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N),
+                  (more && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
+    load_group(rn, 0, PF0);
+
+    // ---- pass 1: 32-point DFT over a: E, O = DFT16 of the even / odd samples, A[p'] = E + W_32^p' O, A[p' + 16] = E - W_32^p' O ----
+    fft16(va);
+    fft16(vb);
+    cf tw16 = tw1[16];
+    if constexpr (P3D) asm volatile("" : "+v"(tw16.x), "+v"(tw16.y));  // opaque per buffer: or hipcc hoists the 15 products out of the loop and keeps them in registers
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      const cf ev = va[OUT16(p)];
+      cf od = vb[OUT16(p)];
+      if (p) {
+        const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * p / 32.0);
+        const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * p / 32.0);
+        od = cmul(od, cf{cr, -sr});
+      }
+      cf y0 = ev + od, y1 = ev - od;
+      if (p) y0 = cmul(y0, tw1[p]);
+      if constexpr (P3D) y1 = cmul(y1, p ? cmul(tw1[p], tw16) : tw16);
+      else y1 = cmul(y1, tw1[p + 16]);
+      w1[p * P1] = to_v2f(y0);
+      w1[(p + 16) * P1] = to_v2f(y1);
+    }
+    __syncthreads();  // barrier 1
+    if (HITS) {
+      if (t == 0 && prev != 0xffffffffu) {  // every wave is past the barrier: the previous buffer's recorders are done
+        args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        lds_hits[par ^ 1] = 0;
+      }
+    }
+    load_group(rn, PF0, PF1);
+
+    // ---- pass 2: virtual threads (p2, c2) and (p2 + 16, c2): DFT16 over b, twiddle W_512^(c q) ----
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+      va[b] = from_v2f(r1[b * 32]);
+      vb[b] = from_v2f(r1[b * 32 + 16 * P1]);
+    }
+    fft16(va);
+    fft16(vb);
+#pragma unroll
+    for (int q = 1; q < 16; q++) {
+      const cf w = from_v2f(tw2[q * 32]);
+      va[OUT16(q)] = cmul(va[OUT16(q)], w);
+      vb[OUT16(q)] = cmul(vb[OUT16(q)], w);
+    }
+    __syncthreads();  // barrier 2: every exchange-1 read done before the area is re-used
+    load_group(rn, PF1, PFN);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      w2[q * 32] = to_v2f(va[OUT16(q)]);
+      w2[q * 32 + 16] = to_v2f(vb[OUT16(q)]);
+    }
+    __syncthreads();  // barrier 3
+
+    // ---- pass 3: the 32-point DFT over c of column kl = t; K4 as in the other kernels (linear powers kept for the hit path,
+    //      product-form dB stored inline, exact form stored over it for strong bins in the waves that hold one) ----
+    v32f pw;
+    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
+    if constexpr (P3D) {
+      // decimation in frequency: A[c''] = x[c''] + x[c''+16] -> DFT16 -> X[2 rho];  B[c''] = (x[c''] - x[c''+16]) W_32^c'' -> DFT16 -> X[2 rho + 1]
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        cd vd[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          const cd x0 = to_cd(r3[c * P2]), x1 = to_cd(r3[(c + 16) * P2]);
+          if (h == 0) {
+            vd[c] = x0 + x1;
+          } else {
+            const cd dlt = x0 - x1;
+            const double cr = __builtin_cos(6.283185307179586476925286766559 * c / 32.0), sr = __builtin_sin(6.283185307179586476925286766559 * c / 32.0);
+            vd[c] = c ? cmul_d(dlt, cr, -sr) : dlt;
+          }
+        }
+        fft16_d(vd);
+#pragma unroll
+        for (int rho = 0; rho < 16; rho++) {
+          const int r = 2 * rho + h;
+          const cd x = vd[OUT16(rho)];
+          const float q = (float)__builtin_fma(x.y, x.y, x.x * x.x);
+          pw[r] = q;
+          gmax[r >> 3] = fmaxf(gmax[r >> 3], q);
+          if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 2048u * r, AUX_ST);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads and conversions out of the first half's live range
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        va[c] = from_v2f(r3[(2 * c) * P2]);
+        vb[c] = from_v2f(r3[(2 * c + 1) * P2]);
+      }
+      fft16(va);
+      fft16(vb);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const cf ev = va[OUT16(r)];
+        cf od = vb[OUT16(r)];
+        if (r) {
+          const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
+          const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
+          od = cmul(od, cf{cr, -sr});
+        }
+        const float p0 = power_of(ev + od), p1 = power_of(ev - od);
+        pw[r] = p0;
+        pw[r + 16] = p1;
+        gmax[r >> 3] = fmaxf(gmax[r >> 3], p0);
+        gmax[2 + (r >> 3)] = fmaxf(gmax[2 + (r >> 3)], p1);
+        if constexpr (SPEC) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p0)), rout, st_voff, 2048u * r, AUX_ST);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p1)), rout, st_voff, 2048u * (r + 16), AUX_ST);
+        }
+      }
+    }
+    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
+    if constexpr (SPEC) {
+      if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+            for (int r = 8 * g; r < 8 * g + 8; r++) {
+              const float q = pw[r];
+              if (__ballot(q >= SCN_P_EXACT_FROM)) {
+                const float d = db_exact(q);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 2048u * r, AUX_ST);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // barrier 4: exchange area free again
+    if (HITS) {
+      if (__ballot(pmax > args.p_lo))
+        scn_record_hits<32>(pw, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); });
+      prev = buf;
+      par ^= 1;
+    }
+  }
+  if (HITS) {
+    __syncthreads();  // last buffer's recorders done
+    if (t == 0 && prev != 0xffffffffu) {
+      args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+      if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+    }
+  }
+}
+}  // namespace
+
+template <int KIND, bool DC, bool HITS, bool SPEC>
+__global__ __launch_bounds__(512, 2) void scn_fft16k2_kernel(ScnFftArgs args) {
+  scn_fft16k2_body<KIND, DC, HITS, SPEC>(args);
+}
+
 template <int KIND, bool DC, bool HITS, bool SPEC>
 __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   scn_fft_wide_body<32, KIND, DC, HITS, SPEC>(args);
@@ -1532,8 +2015,25 @@ static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, bool s
   return launch_wide<32, pick_mode<Wide8K<KIND>::template T>>(a, dc, hits, spec, num_cus, s, stop);
 }
 template <int KIND>
+struct Wide16K2 {
+  template <bool DC, bool HITS, bool SPEC>
+  struct T {
+    static constexpr void (*fn)(ScnFftArgs) = scn_fft16k2_kernel<KIND, DC, HITS, SPEC>;
+  };
+};
+template <int KIND>
 static hipError_t launch_16k_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
+#if SCN_16K_V2
+  typedef Geo16k2 G;
+  void (*k)(ScnFftArgs) = pick_mode<Wide16K2<KIND>::template T>(dc, hits, spec);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  int grid = num_cus * (int)G::WG_PER_CU;
+  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
+  return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
+#else
   return launch_wide<64, pick_mode<Wide16K<KIND>::template T>>(a, dc, hits, spec, num_cus, s, stop);
+#endif
 }
 static hipError_t launch_16k(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
@@ -1562,11 +2062,41 @@ static hipError_t launch_8k(int kind, bool dc, bool hits, bool spec, const ScnFf
   }
 }
 
+template <int M, int KIND>
+struct SmallK {
+  template <bool DC, bool HITS, bool SPEC>
+  struct T {
+    static constexpr void (*fn)(ScnFftArgs) = scn_fft_small_kernel<M, KIND, DC, HITS, SPEC>;
+  };
+};
+template <int M, int KIND>
+static hipError_t launch_small_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
+  typedef GeoSmall<M> G;
+  void (*k)(ScnFftArgs) = pick_mode<SmallK<M, KIND>::template T>(dc, hits, spec);
+  const uint32_t groups = (a.n_buffers + G::SLOTS - 1u) / G::SLOTS;
+  int grid = num_cus * (int)G::WG_PER_CU;
+  if ((uint32_t)grid > groups) grid = (int)groups;
+  return launch_with_stop(k, grid, 256u, G::LDS_BYTES, s, stop, a);
+}
+template <int M>
+static hipError_t launch_small(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
+  if ((uint64_t)args.n_buffers * 256u * M * 8u > 0xffffffffull) return hipErrorInvalidValue;  // (one descriptor spans SLOTS buffers only: never near)
+  switch (kind) {
+    case SCN_K_FLOAT_COMPLEX: return launch_small_kind<M, SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_small_kind<M, SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_small_kind<M, SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_small_kind<M, SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus,
                           hipStream_t stream, hipEvent_t stop) {
   if (!hits && !spec) return hipErrorInvalidValue;
   if (args.n_buffers == 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
   switch (n) {
+    case 256: return launch_small<1>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 512: return launch_small<2>(kind, dc, hits, spec, args, num_cus, stream, stop);
     case 1024: return launch_size<4>(kind, dc, hits, spec, args, num_cus, stream, stop);
     case 2048: return launch_size<8>(kind, dc, hits, spec, args, num_cus, stream, stop);
     case 4096: return launch_size<16>(kind, dc, hits, spec, args, num_cus, stream, stop);
@@ -1584,4 +2114,12 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, bool spec, c
   }
 }
 
-bool scn_fft_size_supported(uint32_t n) { return n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
+bool scn_fft_size_supported(uint32_t n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
+
+// layout of ScnFftArgs::tw1_table for size n: `rows` rows of `threads` entries, row p-1 = W_n^(t p): 15 rows of n/16 for the
+// 16 x 16 x M kernels, 31 rows of 512 for the 32 x 16 x 32 form of 16384 points
+void scn_tw1_layout(uint32_t n, uint32_t *rows, uint32_t *threads) {
+  const bool v2 = n == 16384 && SCN_16K_V2 != 0 && SCN_WIDE_16384 != 0;
+  *rows = v2 ? 31u : 15u;
+  *threads = v2 ? 512u : n / 16u;
+}

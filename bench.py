@@ -344,12 +344,16 @@ def kernel_name(n, kind, hits=True, spectrum=True):
     """the kernel's name as rocprofv3 prints it: template arguments <.., KIND, DC, HITS, SPEC> (scn_kernels.hip)"""
     k = {"cfloat": "SCN_K_FLOAT_COMPLEX", "int16": "SCN_K_SHORT_COMPLEX", "int8": "SCN_K_BYTE_COMPLEX"}[kind]
     h, sp = ("true" if hits else "false"), ("true" if spectrum else "false")
+    if n in (256, 512):  # several buffers per workgroup
+        return f"scn_fft_small_kernel<{n // 256}, {k}, false, {h}, {sp}>"
     if n == 8192:
         return f"scn_fft8k_kernel<{k}, false, {h}, {sp}>"
-    if n == 16384:  # the wide form generalised to M2 = 64 (scn_kernels.hip, launch_16k); no hits-only specialisation at this size
-        return f"scn_fft16k_kernel<{k}, false, {h}, true>"
+    if n == 16384:  # 32 x 16 x 32, pass 3 in double
+        return f"scn_fft16k2_kernel<{k}, false, {h}, {sp}>"
     if n in (1024, 2048, 4096):
         return f"scn_fft_kernel<{n // 256}, {k}, false, {h}, {sp}>"
+    if n == 65536:
+        return f"scn_big_cols_kernel<{k}> + scn_big_rows_kernel<{h}, {sp}> (four-step 256 x 256, scn_big.hip: the work buffer's round trip is not algorithmic traffic)"
     return "scn_gen_load_kernel + scn_gen_stage_kernel x log4(n) + scn_gen_finish_kernel (the staged path, scn_generic.hip)"
 
 

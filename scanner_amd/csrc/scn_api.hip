@@ -1077,6 +1077,8 @@ struct scn_welch {
   float *d_partial = nullptr;  // [parts][max_psd][n] partial power sums (row kernel -> combine kernel); shared by the slots
                                // through stream order on the device path, per-slot copies on the pinned path
   uint32_t parts = 1;
+  hipStream_t exp_stream = nullptr;  // SCN_EXP_WELCH_CHUNK: the row kernels' stream and its events
+  hipEvent_t exp_ev[3] = {nullptr, nullptr, nullptr};
   WelchSlot slot[SCN_NUM_SLOTS];
 };
 
@@ -1100,6 +1102,32 @@ int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd, 
   a.k = w->d.segments_per_psd;
   a.n_psd = n_psd;
   a.inv_k = 1.0f / (float)w->d.segments_per_psd;
+  // EXPERIMENT (SCN_EXP_WELCH_CHUNK = c, profiles/r03_experiments.md): the submit in chunks of c PSDs, chunk k's row kernel on a
+  // second stream beside chunk k+1's column kernel, so that a chunk's slice of the work buffer (c * K * 512 KiB: 34 MB for c = 4)
+  // is read back while it can still sit in the 256 MB Infinity Cache instead of after the whole 268 MB buffer has been written.
+  static const int chunk = getenv("SCN_EXP_WELCH_CHUNK") ? atoi(getenv("SCN_EXP_WELCH_CHUNK")) : 0;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &capturing);
+  if (chunk > 0 && (uint32_t)chunk < n_psd && w->parts == 1 && capturing == hipStreamCaptureStatusNone) {
+    if (!w->exp_stream) {
+      SCN_HIP(hipStreamCreateWithFlags(&w->exp_stream, hipStreamNonBlocking));
+      for (auto &e : w->exp_ev) SCN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const uint32_t K = w->d.segments_per_psd;
+    uint32_t k = 0;
+    for (uint32_t p0 = 0; p0 < n_psd; p0 += (uint32_t)chunk, k++) {
+      ScnWelchArgs c = a;
+      c.n_psd = std::min<uint32_t>((uint32_t)chunk, n_psd - p0);
+      c.n_segments = c.n_psd * K;
+      c.in = static_cast<const char *>(d_in) + (size_t)p0 * K * w->hop * 8u;
+      c.work = static_cast<char *>(d_work) + (size_t)p0 * K * w->d.n * 8u;
+      c.psd_db = d_psd + (size_t)p0 * w->d.n;
+      SCN_HIP(scn_launch_welch_split(c, w->num_cus, stream, w->exp_stream, w->exp_ev[k & 1]));
+    }
+    SCN_HIP(hipEventRecord(w->exp_ev[2], w->exp_stream));
+    SCN_HIP(hipStreamWaitEvent(stream, w->exp_ev[2], 0));
+    return SCN_OK;
+  }
   SCN_HIP(scn_launch_welch(a, w->num_cus, stream));
   return SCN_OK;
 }
@@ -1188,6 +1216,12 @@ int scn_welch_destroy(scn_welch *w) {
   if (w->d_twiddle) (void)hipFree(w->d_twiddle);
   if (w->d_work) (void)hipFree(w->d_work);
   if (w->d_partial) (void)hipFree(w->d_partial);
+  if (w->exp_stream) {
+    (void)hipStreamSynchronize(w->exp_stream);
+    (void)hipStreamDestroy(w->exp_stream);
+  }
+  for (auto e : w->exp_ev)
+    if (e) (void)hipEventDestroy(e);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
   return SCN_OK;

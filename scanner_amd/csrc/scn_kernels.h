@@ -88,6 +88,7 @@ struct ScnWelchArgs {
   float inv_k;
 };
 hipError_t scn_launch_welch(const ScnWelchArgs &args, int num_cus, hipStream_t stream);
+hipError_t scn_launch_welch_split(const ScnWelchArgs &args, int num_cus, hipStream_t s_cols, hipStream_t s_rows, hipEvent_t ev);  // experiment
 
 // Ordered hit list (scn_hits.hip): exclusive scan of the per-buffer counts, then one wave per buffer with hits ranks
 // its records by bin (a bitmap in LDS) and writes the completed scn_hit records [first, first + out_cap) of the

@@ -242,3 +242,20 @@ hipError_t scn_launch_welch(const ScnWelchArgs &a, int num_cus, hipStream_t s) {
   hipLaunchKernelGGL(scn_welch_combine_kernel, dim3(std::min<uint32_t>(a.n_psd * 64u, 2048u)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
+
+// Experiment (SCN_EXP_WELCH_CHUNK, scn_api.hip): columns on `s_cols`, rows on `s_rows` behind an event, so that consecutive
+// chunks' row and column kernels overlap.
+hipError_t scn_launch_welch_split(const ScnWelchArgs &a, int num_cus, hipStream_t s_cols, hipStream_t s_rows, hipEvent_t ev) {
+  if (a.n_segments == 0) return hipSuccess;
+  const size_t lds = 16 * WP * sizeof(v2f);
+  uint32_t G = (uint32_t)(num_cus * 3) / 16u;
+  if (G < 1) G = 1;
+  if (G > a.n_segments) G = a.n_segments;
+  hipLaunchKernelGGL(scn_welch_cols_kernel, dim3(16 * G), dim3(256), lds, s_cols, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if ((e = hipEventRecord(ev, s_cols)) != hipSuccess) return e;
+  if ((e = hipStreamWaitEvent(s_rows, ev, 0)) != hipSuccess) return e;
+  hipLaunchKernelGGL(scn_welch_rows_kernel, dim3(16 * a.n_psd * a.parts), dim3(256), lds, s_rows, a);
+  return hipGetLastError();
+}

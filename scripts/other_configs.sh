@@ -1,7 +1,7 @@
 #!/bin/bash
 # The other BASELINE configs / wire formats, back to back on one box -> gpurun_out/configs_<tag>.jsonl
 # usage: scripts/other_configs.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/configs_$TAG.jsonl
 : > $OUT
@@ -19,8 +19,12 @@ run --n 4096 --batch 2048
 run --config c4
 run --n 16384 --batch 2048
 run --n 16384 --batch 2048 --kind int16
-run --n 512 --batch 16384 --steps 20 --warmup 3     # the staged path: a power of two without a fused kernel
-run --n 32768 --batch 256 --steps 20 --warmup 3
+run --n 512 --batch 65536                           # several buffers per workgroup (scn_fft_small_kernel)
+run --n 256 --batch 131072
+run --n 512 --batch 65536 --kind int16
+run --n 65536 --batch 512 --steps 200 --warmup 20    # the four-step pair (scn_big.hip)
+run --n 65536 --batch 512 --kind int16 --steps 200 --warmup 20
+run --n 32768 --batch 256 --steps 20 --warmup 3     # the staged path: a power of two without a fused kernel
 run --n 1000 --batch 4096 --steps 20 --warmup 3      # Bluestein
 run --welch --welch-psd 32 --steps 100 --warmup 10
 run --welch --welch-psd 8 --welch-pinned --steps 20 --warmup 3

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence in one GPU call: rocprofv3 kernel trace + PMC passes for every BASELINE launch shape, un-profiled
 # bench lines of the same build next to them.   usage: scripts/prof_all.sh <round tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
 bash scripts/prof.sh ${TAG}_c2 > /dev/null 2>&1
 bash scripts/prof.sh ${TAG}_c3 --n 8192 --kind int16 --batch 4096 > /dev/null 2>&1
@@ -13,5 +13,7 @@ if [ -n "$SCN_PROF_MORE" ]; then   # the other wire formats and sizes (not BASEL
   bash scripts/prof.sh ${TAG}_n8192cfloat --n 8192 --batch 4096 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n16384cfloat --n 16384 --batch 2048 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n16384int16 --n 16384 --batch 2048 --kind int16 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n512cfloat --n 512 --batch 65536 > /dev/null 2>&1
+  SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n65536cfloat --n 65536 --batch 512 > /dev/null 2>&1
 fi
 for c in c2 c3 c4shape c5; do echo "=== $c"; cat gpurun_out/prof_${TAG}_$c/summary.txt; done

@@ -8,7 +8,7 @@ names = {capi.KIND_FLOAT_COMPLEX: "cfloat", capi.KIND_SHORT_COMPLEX: "int16", ca
 print(f"{'n':>5s} {'format':>13s} {'dc':>3s} | spectrum only | spectrum+hits | hits only | time-domain   (us per launch of 33.5 M samples)")
 sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192, 16384]
 for n in sizes:
-    nb = 8192 * 4096 // n
+    nb = min(8192 * 4096 // n, 8192 * 4)
     base = [synth.cfloat_batch_torch(n, nb, seed=5 + r, device=dev) for r in range(3)]
     fc = 3e6 + 6e6 * np.arange(nb)
     for kind in (capi.KIND_FLOAT_COMPLEX, capi.KIND_SHORT_COMPLEX, capi.KIND_SHORT, capi.KIND_BYTE_COMPLEX):

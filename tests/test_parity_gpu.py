@@ -391,8 +391,17 @@ def test_round3_kernels_formats_and_output_modes(torch_cuda, oracle_mod, n, kind
     else:
         assert p is None
     if flags != "spectrum":
-        _assert_hits_equal(h, h_ref)
+        assert len(h) == len(h_ref)
+        for f in ("seq_id", "i", "freq_hz"):
+            assert np.array_equal(h[f], h_ref[f]), f
         assert np.array_equal(t, t_ref)
+        if flags == "both":   # a record carries the float the spectrum holds (spectra themselves are held to the bar above)
+            jj = (h["i"].astype(np.int64) + n // 2) % n
+            assert np.array_equal(h["power_db"], p[h["seq_id"].astype(np.int64), jj])
+        else:                 # no spectrum to hold them to: the bar's dB form on the bins it covers, a loose bound elsewhere
+            big = tol.db_to_power(h_ref["power_db"]) >= tol.db_to_power(p_ref).mean(axis=-1)[h_ref["seq_id"].astype(np.int64)]
+            err = np.abs(h["power_db"].astype(np.float64) - h_ref["power_db"])
+            assert np.all(err[big] <= tol.DB_REL * np.abs(h_ref["power_db"][big]) + tol.DB_ABS) and err.max(initial=0) < 0.2
 
 
 def test_strong_tone_accuracy_16384(torch_cuda, oracle_mod):

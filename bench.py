@@ -728,8 +728,14 @@ def main():
             try:
                 torch.cuda.set_device(dev)  # (the current device is per thread)
                 with sweep.HitGather(dev) as g:
-                    res["hits"], res["per_rank"] = g.gather(hits)
-                res["info"] = {"transport": "scn_gather_hits (RCCL: ncclAllGather counts + grouped ncclSend/ncclRecv to rank 0)"}
+                    if len(chunks) == 1:  # the sweep's list is one collected slot: send it from where the compaction kernel left it
+                        res["hits"], res["per_rank"] = g.gather_device(plan, 0)
+                        how = "scn_gather_hits_device (the slot's device list, no host staging)"
+                    else:
+                        res["hits"], res["per_rank"] = g.gather(hits)
+                        how = "scn_gather_hits"
+                res["info"] = {"transport": how + " (RCCL: ncclAllGather {count, status} + grouped ncclSend/ncclRecv to rank 0, one collective; "
+                                                  "rank 0 reads the list with scn_gather_fetch)"}
             except Exception as e:
                 res["error"] = str(e)[:300]
 

@@ -59,7 +59,9 @@ enum { SCN_WIN_BLACKMAN_HARRIS = 5, SCN_WIN_RECTANGULAR = 3 };
 /* output selection (flags) */
 enum {
   SCN_OUT_SPECTRUM = 1u, /* keep the N-bin dB spectrum of every buffer */
-  SCN_OUT_HITS = 2u,     /* threshold every in-band bin into the hit list */
+  SCN_OUT_HITS = 2u,     /* threshold every in-band bin into the hit list.  Alone (no SCN_OUT_SPECTRUM): the hits-only
+                          * kernels -- no spectrum is stored and no per-bin logarithm taken; the same bins are reported,
+                          * with the same power_db, as with the spectrum kept */
   /* Not an output: give each of the two slots its own compute stream, so that the launch of one slot
    * overlaps the tail of the other slot's launch (the next batch's workgroups fill the CUs the finishing
    * batch frees) instead of waiting for it to drain.  Measured on C2: one launch per 67.6 us instead of
@@ -85,9 +87,9 @@ typedef struct scn_hit {
 typedef struct scn_plan_desc {
   uint32_t struct_size;
   uint32_t n;              /* sampleCount = FFT size (scan.cpp:85; the reference plans any count, fft.cpp:4-11): any size from
-                              16 to 65536.  1024 / 2048 / 4096 / 8192 / 16384 run in the fused LDS
-                              kernels; the other sizes through a staged, slower path (Bluestein for the sizes that are not
-                              powers of two) with the same outputs */
+                              16 to 65536.  256 ... 16384 (powers of two) run in fused single-pass LDS kernels, 65536 in a
+                              four-step pair of kernels (with DC removal: the staged path); the other sizes through a
+                              staged, slower path (Bluestein for the sizes that are not powers of two) with the same outputs */
   uint32_t sample_rate;    /* Hz (scan.cpp:92) */
   uint32_t sample_kind;    /* SCN_KIND_* */
   uint32_t enob;           /* effective bits (scan.cpp:138,183) */

@@ -408,6 +408,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     ba.window = p->d_window;
     ba.twiddle = p->d_twiddle;
     ba.work = s.d_gen_work[0];
+    ba.tw256 = reinterpret_cast<const double2_scn *>(p->d_twiddle64);
     ba.power_db = d_power;
     ba.n_buffers = nb;
     ba.scale = p->scale;
@@ -639,6 +640,16 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     }
     SCN_TRY(hipMemcpyAsync(p->d_window, p->h_window.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, p->stream));
     SCN_TRY(hipMemcpyAsync(p->d_twiddle, tw.data(), sizeof(float) * 2 * tn, hipMemcpyHostToDevice, p->stream));
+    if (p->big) {  // W_256^m in double: the row transform of scn_big.hip
+      std::vector<double> tw256(2 * 256);
+      for (uint32_t m = 0; m < 256; m++) {
+        const double a = -2.0 * pi * (double)m / 256.0;
+        tw256[2 * m] = std::cos(a);
+        tw256[2 * m + 1] = std::sin(a);
+      }
+      SCN_TRY(hipMalloc(&p->d_twiddle64, sizeof(double) * tw256.size()));
+      SCN_TRY(hipMemcpy(p->d_twiddle64, tw256.data(), sizeof(double) * tw256.size(), hipMemcpyHostToDevice));
+    }
     if (p->generic) {
       std::vector<double> tw64(2 * (size_t)tn);
       for (uint32_t m = 0; m < tn; m++) {

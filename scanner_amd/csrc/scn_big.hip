@@ -9,7 +9,7 @@
 //   scn_big_cols_kernel<KIND>   K1 (utility.cpp:9-84, without DC removal: that needs the buffer's sum first and stays on the staged
 //                               path) + K2 (process.cpp:28-34), 16 x 256-pt FFTs over n1 per workgroup, twiddle W_N^(n2 k1), Y[k1][n2]
 //                               into a tiled work buffer (16 x 16 blocks of 2 KiB: whole blocks move on both sides)
-//   scn_big_rows_kernel<HITS, SPEC>  the 256-pt FFTs along n2 (fft.cpp:20-25), K4 (the dB map of scn_device.h), K5 (mask, strict >,
+//   scn_big_rows_kernel<HITS, SPEC>  the 256-pt FFTs along n2 (fft.cpp:20-25) -- in double, see there --, K4 (the dB map of scn_device.h), K5 (mask, strict >,
 //                               records into the buffer's region: scn_record_hits with the buffer's device counter; one global
 //                               atomic per wave that holds a hit).  A thread ends up with bins k1 + 256 (p + 16 q): 4-byte
 //                               pieces 1 KiB apart, so the dB values cross the workgroup's LDS once more and leave as 64-byte
@@ -144,37 +144,47 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows_kernel(ScnBigArgs args) {
   const uint32_t hi = t >> 4, lo = t & 15u;  // pass 1: (rho, b)   pass 2: (rho, p)
   const uint32_t k1 = 16u * i + hi;
 
+  // The row transform runs in DOUBLE (the float exchange between its two passes excepted).  At this size a strong tone's
+  // partial sums in the last levels are 256x the input, and their float rounding lands on the other 255 bins of the tone's
+  // row: the first, all-float form of this kernel read 1.0e-5 .. 1.9e-5 on eleven buffers (peak / mean power ~2e4) of a
+  // 30-minute fuzz -- over the parity bar, where the staged double-precision path it replaced never was.  v_add_f64 /
+  // v_fma_f64 issue at 0.85x / 0.7x the float rate on gfx950 and this kernel waits for its work-buffer reads anyway.
+  // Emulated (48 strong-tone buffers): max 6.9e-6 all float, 3.0e-6 with this, 2.2e-6 with a double exchange as well.
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(reinterpret_cast<const char *>(args.work) + (size_t)b * BN * 8u + i * 32768u, BN * 8u - i * 32768u);
-  cf v[16];
+  v2f raw[16];
 #pragma unroll
-  for (int a = 0; a < 16; a++) v[a] = from_v2f(__builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rw, t * 8u, a * 2048u, 2)));
-  cf twa[16];
+  for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rw, t * 8u, a * 2048u, 2));
+  // W_256^(b p), p = 1 .. 15, b = lo: from the plan's double table (a float twiddle would put the float error right back)
+  scn_v2d twa[16];
 #pragma unroll
-  for (int p = 1; p < 16; p++) twa[p] = from_v2f(args.twiddle[(256u * lo * p) & (BN - 1)]);  // W_256^{b p}
+  for (int p = 1; p < 16; p++) twa[p] = args.tw256[(lo * p) & 255u];
   v2f *w1 = lds + hi * BP + lo * 17u;  // + p        (row rho, slot b*17 + p)
   v2f *r1 = lds + hi * BP + lo;        // + b*17
-
-  fft16(v);
+  cd v[16];
+#pragma unroll
+  for (int a = 0; a < 16; a++) v[a] = to_cd(raw[a]);
+  fft16_d(v);
 #pragma unroll
   for (int p = 0; p < 16; p++) {
-    cf y = v[OUT16(p)];
-    if (p) y = cmul(y, twa[p]);
-    w1[p] = to_v2f(y);
+    cd y = v[OUT16(p)];
+    if (p) y = cmul_d(y, twa[p]);
+    w1[p] = v2f{(float)y.x, (float)y.y};
   }
   __syncthreads();
 #pragma unroll
-  for (int bb = 0; bb < 16; bb++) v[bb] = from_v2f(r1[bb * 17]);
-  fft16(v);
+  for (int bb = 0; bb < 16; bb++) v[bb] = to_cd(r1[bb * 17]);
+  fft16_d(v);
   __syncthreads();  // every exchange read done: the area becomes the output tile
 
   // this thread's 16 bins: k = k1 + 256 k2, k2 = lo + 16 q
   v16f pw;
-  float pmax = 0.0f;
+  float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int q = 0; q < 16; q++) {
-    const float p = power_of(v[OUT16(q)]);
+    const cd xq = v[OUT16(q)];
+    const float p = (float)__builtin_fma(xq.y, xq.y, xq.x * xq.x);
     pw[q] = p;
-    pmax = fmaxf(pmax, p);
+    gmax[q >> 2] = fmaxf(gmax[q >> 2], p);
     if constexpr (SPEC) lds_out[(lo + 16u * q) * 17u + hi] = db_of_power(p);
   }
   if constexpr (SPEC) {
@@ -198,8 +208,9 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows_kernel(ScnBigArgs args) {
       const bool keep = !(jj < args.dc_ignore || (BN - jj) < args.dc_ignore) && !(ii < args.i_lo || ii > args.i_hi);
       keepmask |= keep ? (1u << q) : 0u;
     }
+    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
     if (__ballot(pmax > args.p_lo))
-      scn_record_hits<16>(pw, keepmask, args, reinterpret_cast<int *>(args.per_buffer_hits + b), b, lane,
+      scn_record_hits<16>(pw, gmax, keepmask, args, reinterpret_cast<int *>(args.per_buffer_hits + b), b, lane,
                           [&](int q) -> uint32_t { return (k1 + 256u * (lo + 16u * (uint32_t)q)) ^ (BN / 2); });
   }
 }

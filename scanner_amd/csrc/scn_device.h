@@ -190,53 +190,52 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t x) {
 }
 
 // ---- K5, the recording half (process.cpp:54-57), shared by the fused kernels ------------------------------------------
-// `pw` holds the LINEAR powers of this thread's NB bins (bin index i of output o from `bin_i`).  Candidates are found in
-// the linear domain against p_lo (a shade below 10^(threshold / 5), scn_hit_prefilter); the decision itself is
-// magnitudes[j] > m_threshold on the dB value -- the map of scn_device.h, a pure function of the power, so spectrum + hits
-// and hits-only plans decide identically and report the float the spectrum holds -- evaluated only for the output indices
-// some lane of the wave has a candidate in.  Slots of the buffer's region come from ONE LDS atomic per wave.
-// (`args`: anything with p_lo, threshold, hits, hit_region; `count`: the buffer's hit counter, in LDS or in device memory)
+// `pw` holds the LINEAR powers of this thread's NB bins (bin index i of output o from `bin_i`), `gmax` the largest power of
+// each of its four groups of NB / 4 outputs.  Candidates are found in the linear domain against p_lo (a shade below
+// 10^(threshold / 5), scn_hit_prefilter); the decision itself is magnitudes[j] > m_threshold on the dB value -- the map above,
+// a pure function of the power, so spectrum + hits and hits-only plans decide identically and report the float the spectrum
+// holds.  A tone's detections are neighbouring bins, i.e. ONE or two output indices of neighbouring lanes: so the wave
+// tests its four groups, then the outputs of a group that holds a candidate (one compare each, into a scalar mask), and
+// every output index in that mask is evaluated once and takes its slots of the buffer's region at once, with one atomic
+// on the buffer's counter (LDS, or device memory in scn_big.hip) -- no wave-wide reductions, no second pass.  (The first form -- candidate masks for all NB
+// outputs, DPP reductions for the wave's OR and total, one atomic per wave, a register-indexed loop over the hit indices --
+// cost a wave with detections ~1400 cycles: 11 % of a C3 buffer, another 5 % of barrier skew behind it; stamp profiles in
+// profiles/r03_experiments.md.)
+// (`args`: anything with p_lo, threshold, hits, hit_region)
 template <int NB, typename VEC, typename ARGS, typename BINI>
-__device__ __forceinline__ void scn_record_hits(VEC &pw, uint32_t keepmask, const ARGS &args, int *lds_count, uint32_t buf, uint32_t lane,
-                                                BINI bin_i) {
-  uint32_t cand = 0;
+__device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count, uint32_t buf,
+                                                uint32_t lane, BINI bin_i) {
+  constexpr int GS = NB / 4;
+  // which output indices have a candidate somewhere in the wave: one compare per output of a group that holds one (static
+  // register indexing; the result is a scalar mask -- no per-lane masks, no cross-lane reduction)
+  uint32_t wmc = 0;
 #pragma unroll
-  for (int o = 0; o < NB; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
-  cand &= keepmask;
-  uint32_t wmc = wave_or_u32(cand);
-  if (!wmc) return;
-  uint32_t wm = wmc;
-  // the dB value of every output index that has a candidate somewhere in the wave (static indexing, a scalar branch per
-  // index: with a low threshold EVERY index has one, and a data-dependent loop with register-indexed moves cost a
-  // hit-dense 16384-point launch 10 %); the exact half of the map again only where a lane holds a strong bin
+  for (int g = 0; g < 4; g++) {
+    if (__ballot(gmax[g] > args.p_lo)) {
 #pragma unroll
-  for (int o = 0; o < NB; o++) {
-    if ((wmc >> o) & 1u) {
-      const float p = pw[o];
-      float d = db_fast(p);
-      if (__ballot(p >= SCN_P_EXACT_FROM)) d = p >= SCN_P_EXACT_FROM ? db_exact(p) : d;
-      pw[o] = d;  // (every lane's slot o now holds its dB value; only hit lanes read it again)
-      if (!(d > args.threshold)) cand &= ~(1u << o);  // strict >, process.cpp:54
+      for (int o = g * GS; o < (g + 1) * GS; o++) wmc |= __ballot(pw[o] > args.p_lo) ? (1u << o) : 0u;
     }
   }
-  const uint32_t total = wave_add_u32((uint32_t)__popc(cand));
-  if (!total) return;
-  uint32_t base = 0;
-  if (lane == 0) base = (uint32_t)atomicAdd(lds_count, (int)total);
-  base = __builtin_amdgcn_readfirstlane(base);
-  // this wave's records take the buffer's slots [base, base + total); a region holds every bin the mask lets through, so
-  // there is no overflow path (and no global atomic)
   ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-  while (wm) {
-    const int o = __builtin_ctz(wm);  // wave-uniform
-    wm &= wm - 1u;
-    const bool hit = (cand >> o) & 1u;
+  while (wmc) {  // a tone's main lobe: one or two indices
+    const int o = __builtin_ctz(wmc);  // wave-uniform
+    wmc &= wmc - 1u;
+    const float p = pw[o];
+    const bool cand = p > args.p_lo && ((keepmask >> o) & 1u);
+    float d = db_fast(p);
+    if (__ballot(p >= SCN_P_EXACT_FROM)) d = p >= SCN_P_EXACT_FROM ? db_exact(p) : d;
+    const bool hit = cand && d > args.threshold;  // strict >, process.cpp:54
     const unsigned long long m = __ballot(hit);
-    if (hit) {
-      const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), pw[o]};
+    if (m) {
+      const int first = __builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == (uint32_t)first) base = (uint32_t)atomicAdd(count, (int)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+      if (hit) {
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), d};
+      }
     }
-    base += (uint32_t)__popcll(m);
   }
 }
 

@@ -11,6 +11,7 @@
 #define SCN_K_FLOAT_COMPLEX 4
 
 typedef float scn_v2f __attribute__((ext_vector_type(2)));
+typedef double double2_scn __attribute__((ext_vector_type(2)));
 
 // A hit as the FFT kernel records it: slot `pos` of its buffer's region, in arbitrary order.  The compaction
 // kernels (scn_hits.hip) put the batch's records into the order a single-threaded reference run prints them
@@ -134,6 +135,7 @@ struct ScnBigArgs {
   const float *window;        // [65536]
   const scn_v2f *twiddle;     // W_65536^m
   void *work;                 // [n_buffers][65536] complex float: Y[k1][n2] between the two kernels (tiled)
+  const double2_scn *tw256;   // W_256^m, m in [0, 256), in double: the row transform's twiddles
   float *power_db;            // [n_buffers][65536] or nullptr
   uint32_t n_buffers;
   float scale, threshold, p_lo;

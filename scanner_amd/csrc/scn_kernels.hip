@@ -391,6 +391,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   auto joff_of = [](int o) -> uint32_t { return (M >= 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M); };
 #if SCN_STAMPS
   uint32_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t stamp_hit_cyc = 0, stamp_hit_n = 0;  // cycles wave 0 spent in scn_record_hits, and how often it went in
   uint32_t stamp_prev = (uint32_t)__builtin_readcyclecounter();
   const uint32_t stamp_t0 = (uint32_t)wall_clock64();  // 100 MHz
   uint32_t stamp_hw;
@@ -624,8 +625,20 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       // Recording runs AFTER the barrier: a wave that holds detections does not stall the other
       // waves of its workgroup, they go on to the next buffer and meet it at that buffer's first
       // barrier (its loads are in flight meanwhile).  Only such a wave evaluates the per-bin test.
-      if (__ballot(pmax > args.p_lo))
-        scn_record_hits<16>(pw, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
+      if (__ballot(pmax > args.p_lo)) {
+#if SCN_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t h0_ = (uint32_t)__builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        scn_record_hits<16>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
+#if SCN_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        stamp_hit_cyc += (uint32_t)__builtin_readcyclecounter() - h0_;
+        stamp_hit_n += 1;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
       prev = buf;
       par ^= 1;
     }
@@ -643,6 +656,8 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     args.power_db[(size_t)blockIdx.x * N + 14] = (float)(((xcc & 0xfu) << 8) | ((stamp_hw >> 8) & 0xffu));  // xcc, se/sh/cu
     args.power_db[(size_t)blockIdx.x * N + 15] = (float)(stamp_entry & 0xffffffu);
+    args.power_db[(size_t)blockIdx.x * N + 16] = (float)stamp_hit_cyc;
+    args.power_db[(size_t)blockIdx.x * N + 17] = (float)stamp_hit_n;
   }
 #endif
   if (HITS) {
@@ -1047,6 +1062,7 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
 
 #if SCN_STAMPS
   uint32_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t stamp_hit_cyc = 0, stamp_hit_n = 0;  // cycles wave 0 spent in scn_record_hits, and how often it went in
   uint32_t stamp_prev = (uint32_t)__builtin_readcyclecounter();
   const uint32_t stamp_t0 = (uint32_t)wall_clock64();  // 100 MHz
   uint32_t stamp_hw;
@@ -1336,8 +1352,20 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
 #endif
     const uint32_t after = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
     if (HITS) {
-      if (__ballot(pmax > args.p_lo))
-        scn_record_hits<32>(pw, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
+      if (__ballot(pmax > args.p_lo)) {
+#if SCN_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t h0_ = (uint32_t)__builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        scn_record_hits<32>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
+#if SCN_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        stamp_hit_cyc += (uint32_t)__builtin_readcyclecounter() - h0_;
+        stamp_hit_n += 1;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
       prev = buf;
       par ^= 1;
     }
@@ -1354,6 +1382,8 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     args.power_db[(size_t)blockIdx.x * N + 14] = (float)(((xcc & 0xfu) << 8) | ((stamp_hw >> 8) & 0xffu));
     args.power_db[(size_t)blockIdx.x * N + 15] = (float)(stamp_entry & 0xffffffu);
+    args.power_db[(size_t)blockIdx.x * N + 16] = (float)stamp_hit_cyc;
+    args.power_db[(size_t)blockIdx.x * N + 17] = (float)stamp_hit_n;
   }
 #endif
   if (HITS) {
@@ -1656,7 +1686,7 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     __syncthreads();  // barrier 4: exchange area free again
     if (HITS) {
       if (__ballot(pmax > args.p_lo))
-        scn_record_hits<32>(pw, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); });
+        scn_record_hits<32>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); });
       prev = buf;
       par ^= 1;
     }

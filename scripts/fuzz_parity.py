@@ -67,7 +67,9 @@ def run(budget, seed):
     worst_by_n.clear()
     while time.time() < t_end:
         # 256 / 512: several buffers per workgroup; 65536: the four-step pair (staged path with DC removal); 32768, 1000: the staged path (1000: Bluestein)
-        n = int(rng.choice([1024, 2048, 4096, 8192, 16384, 16384, 256, 512, 65536, 32768, 1000]))
+        sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else \
+            [1024, 2048, 4096, 8192, 16384, 16384, 256, 512, 65536, 32768, 1000]
+        n = int(rng.choice(sizes))
         kind = int(rng.choice(kinds))
         enob = 8 if kind == capi.KIND_BYTE_COMPLEX else int(rng.choice([12, 12, 14, 16, 10]))
         dc = bool(rng.integers(0, 2)) and kind != capi.KIND_FLOAT_COMPLEX

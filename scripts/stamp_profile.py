@@ -44,6 +44,9 @@ print(f"n={n} {kindname} flags={flags}: {len(rows)} workgroups, {rows[:,11].mean
 for i, nm in enumerate(names):
     print(f"  {nm:42s} {per[:, i].mean():8.0f} cyc  {100 * per[:, i].mean() / tot:5.1f} %   (p10 {np.percentile(per[:, i], 10):6.0f}  p90 {np.percentile(per[:, i], 90):6.0f})")
 
+hc, hn = o[:len(rows), 16], o[:len(rows), 17]
+print(f"wave 0 entered the hit path for {hn.sum() / rows[:, 11].sum() * 100:.1f} % of its buffers; {hc.sum() / max(hn.sum(), 1):.0f} cycles per entry "
+      f"(p10 {np.percentile(hc / np.maximum(hn, 1), 10):.0f}  p90 {np.percentile(hc / np.maximum(hn, 1), 90):.0f})")
 t0 = o[:len(rows), 12]; t1 = o[:len(rows), 13]; where = o[:len(rows), 14].astype(int); te = o[:len(rows), 15]
 base = te.min()
 st = (t0 - base) * 0.01; en = (t1 - base) * 0.01; ent = (te - base) * 0.01   # us

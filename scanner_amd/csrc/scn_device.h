@@ -34,8 +34,13 @@ namespace {
 // 6e-8) and adds k * e in two exactly representable pieces: <= 1.0 ulp, rms 0.38 (correct rounding: 0.5 / 0.29).  It costs
 // five more VALU operations per bin, so the map is DEFINED as: the product form for powers below SCN_P_EXACT_FROM = 10^3.2
 // (16 dB: its error there is <= 2.2 ulp of a value below 16, i.e. 2e-6 dB or 1e-6 in relative power), the exact form from
-// there up -- a pure function of the bin's power, the same in every kernel and output mode; the kernels evaluate the exact
-// form only in waves that hold such a bin (strong signals: rare), under a wave-uniform branch.
+// there up -- db_of_power, a pure function of the bin's power, the same in every kernel and output mode; the kernels
+// evaluate the exact form only in waves that hold such a bin (strong signals), under wave-uniform branches.
+// ONE exception, the 16384-point kernel: it keeps the dB values (not the powers) for its hit path -- at that size a
+// threshold near the noise floor makes every wave a hit wave, and re-deriving the values cost 15 % -- and so has the power
+// only of each thread-group's maximum at hand: there a bin gets the exact form iff it is at least SCN_P_EXACT_FROM AND its
+// group's maximum (a tone's strongest bins, one per thread); a second strong bin in the same group of the same thread keeps
+// the product form's <= 2.2 ulp.  Its three output modes apply the same rule (identical thread layout).
 #define SCN_P_EXACT_FROM 1584.8932f
 __device__ __forceinline__ float db_fast(float p) { return 1.50514997831990597607f * __builtin_amdgcn_logf(p); }
 __device__ __forceinline__ float db_exact(float p) {
@@ -202,7 +207,11 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t x) {
 // cost a wave with detections ~1400 cycles: 11 % of a C3 buffer, another 5 % of barrier skew behind it; stamp profiles in
 // profiles/r03_experiments.md.)
 // (`args`: anything with p_lo, threshold, hits, hit_region)
-template <int NB, typename VEC, typename ARGS, typename BINI>
+// IS_DB: `pw` already holds the dB values (the spectrum kernels: they have just stored them); otherwise the powers (hits-only
+// kernels), and the value is formed here by the rule the spectrum kernels of the same family use -- the exact half of the
+// map for the strong maximum of the thread's group of outputs, the product form for every other bin -- or, with PURE, by
+// db_of_power (scn_big.hip, whose spectrum is stored through that).
+template <int NB, bool IS_DB, bool PURE = false, typename VEC, typename ARGS, typename BINI>
 __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count, uint32_t buf,
                                                 uint32_t lane, BINI bin_i) {
   constexpr int GS = NB / 4;
@@ -213,27 +222,40 @@ __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4],
   for (int g = 0; g < 4; g++) {
     if (__ballot(gmax[g] > args.p_lo)) {
 #pragma unroll
-      for (int o = g * GS; o < (g + 1) * GS; o++) wmc |= __ballot(pw[o] > args.p_lo) ? (1u << o) : 0u;
+      for (int o = g * GS; o < (g + 1) * GS; o++) wmc |= __ballot(IS_DB ? pw[o] > args.threshold : pw[o] > args.p_lo) ? (1u << o) : 0u;
     }
   }
   ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-  while (wmc) {  // a tone's main lobe: one or two indices
-    const int o = __builtin_ctz(wmc);  // wave-uniform
-    wmc &= wmc - 1u;
-    const float p = pw[o];
-    const bool cand = p > args.p_lo && ((keepmask >> o) & 1u);
-    float d = db_fast(p);
-    if (__ballot(p >= SCN_P_EXACT_FROM)) d = p >= SCN_P_EXACT_FROM ? db_exact(p) : d;
-    const bool hit = cand && d > args.threshold;  // strict >, process.cpp:54
-    const unsigned long long m = __ballot(hit);
-    if (m) {
-      const int first = __builtin_ctzll(m);
-      uint32_t base = 0;
-      if (lane == (uint32_t)first) base = (uint32_t)atomicAdd(count, (int)__popcll(m));
-      base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-      if (hit) {
-        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), d};
+  // (one loop over all indices; only the group-maximum rule needs the group's maximum by name -- indexed, it went through
+  // scratch -- and gets one loop per group)
+  constexpr int NL = (!IS_DB && !PURE) ? 4 : 1;
+#pragma unroll
+  for (int g = 0; g < NL; g++) {
+    uint32_t wmg = NL == 1 ? wmc : wmc & (((1u << GS) - 1u) << (g * GS));
+    while (wmg) {  // a tone's main lobe: one or two indices
+      const int o = __builtin_ctz(wmg);  // wave-uniform
+      wmg &= wmg - 1u;
+      const float p = pw[o];
+      float d = p;
+      if constexpr (!IS_DB && PURE) {
+        d = db_fast(p);
+        if (__ballot(p >= SCN_P_EXACT_FROM)) d = p >= SCN_P_EXACT_FROM ? db_exact(p) : d;  // = db_of_power(p)
+      }
+      if constexpr (!IS_DB && !PURE) {
+        d = db_fast(p);
+        if (__ballot(p >= SCN_P_EXACT_FROM)) d = (p >= SCN_P_EXACT_FROM && p == gmax[NL == 4 ? g : 0]) ? db_exact(p) : d;
+      }
+      const bool hit = ((keepmask >> o) & 1u) && d > args.threshold && (IS_DB || p > args.p_lo);  // strict >, process.cpp:54
+      const unsigned long long m = __ballot(hit);
+      if (m) {
+        const int first = __builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == (uint32_t)first) base = (uint32_t)atomicAdd(count, (int)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+        if (hit) {
+          const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), d};
+        }
       }
     }
   }

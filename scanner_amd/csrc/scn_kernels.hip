@@ -631,7 +631,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
         const uint32_t h0_ = (uint32_t)__builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        scn_record_hits<16>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
+        scn_record_hits<16, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
 #if SCN_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         stamp_hit_cyc += (uint32_t)__builtin_readcyclecounter() - h0_;
@@ -1358,7 +1358,7 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
         const uint32_t h0_ = (uint32_t)__builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        scn_record_hits<32>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
+        scn_record_hits<32, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
 #if SCN_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         stamp_hit_cyc += (uint32_t)__builtin_readcyclecounter() - h0_;
@@ -1631,9 +1631,14 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
           const int r = 2 * rho + h;
           const cd x = vd[OUT16(rho)];
           const float q = (float)__builtin_fma(x.y, x.y, x.x * x.x);
-          pw[r] = q;
           gmax[r >> 3] = fmaxf(gmax[r >> 3], q);
-          if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 2048u * r, AUX_ST);
+          if constexpr (SPEC) {
+            const float d = db_fast(q);
+            pw[r] = d;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 2048u * r, AUX_ST);
+          } else {
+            pw[r] = q;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads and conversions out of the first half's live range
       }
@@ -1655,13 +1660,17 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
           od = cmul(od, cf{cr, -sr});
         }
         const float p0 = power_of(ev + od), p1 = power_of(ev - od);
-        pw[r] = p0;
-        pw[r + 16] = p1;
         gmax[r >> 3] = fmaxf(gmax[r >> 3], p0);
         gmax[2 + (r >> 3)] = fmaxf(gmax[2 + (r >> 3)], p1);
         if constexpr (SPEC) {
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p0)), rout, st_voff, 2048u * r, AUX_ST);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p1)), rout, st_voff, 2048u * (r + 16), AUX_ST);
+          const float d0 = db_fast(p0), d1 = db_fast(p1);
+          pw[r] = d0;
+          pw[r + 16] = d1;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d0), rout, st_voff, 2048u * r, AUX_ST);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), rout, st_voff, 2048u * (r + 16), AUX_ST);
+        } else {
+          pw[r] = p0;
+          pw[r + 16] = p1;
         }
       }
     }
@@ -1669,14 +1678,16 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     if constexpr (SPEC) {
       if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < 4; g++) {  // the exact dB value for the strong maximum of each group of eight outputs (see scn_fft_kernel)
           if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
+            const float dg = db_fast(gmax[g]), ex = db_exact(gmax[g]);
 #pragma unroll
             for (int r = 8 * g; r < 8 * g + 8; r++) {
-              const float q = pw[r];
-              if (__ballot(q >= SCN_P_EXACT_FROM)) {
-                const float d = db_exact(q);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 2048u * r, AUX_ST);
+              const float d = pw[r];
+              const bool sel = gmax[g] >= SCN_P_EXACT_FROM && d == dg;
+              if (__ballot(sel)) {  // (the maximum sits in ONE output index of a lane: the others skip the store instruction altogether)
+                pw[r] = sel ? ex : d;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ex), rout, sel ? st_voff : 0x80000000u, 2048u * r, AUX_ST);
               }
             }
           }
@@ -1686,7 +1697,7 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     __syncthreads();  // barrier 4: exchange area free again
     if (HITS) {
       if (__ballot(pmax > args.p_lo))
-        scn_record_hits<32>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); });
+        scn_record_hits<32, SPEC>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); });
       prev = buf;
       par ^= 1;
     }

@@ -130,7 +130,7 @@ struct scn_plan {
   // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
   bool direct_counts = false;
   bool generic = false;  // no fused kernel for this size: the staged path of scn_generic.hip
-  bool big = false;      // 65536 points without DC removal: the four-step pair of scn_big.hip
+  bool big = false;      // 65536 / 32768 points: the four-step pair of scn_big.hip
   uint32_t fft_m = 0, log2m = 0;     // ... and its transform length: n for a power of two, >= 2n - 1 for Bluestein
   double *d_twiddle64 = nullptr;     // [fft_m][2]: W_m^k in double (the staged path applies its tables in double)
   double *d_chirp = nullptr;         // Bluestein: [n][2], w[i] = exp(-i pi i^2 / n)
@@ -420,7 +420,10 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     ba.hits = a.hits;
     ba.hit_region = p->hit_region;
     ba.per_buffer_hits = a.per_buffer_hits;
-    SCN_HIP(scn_launch_big((int)p->d.sample_kind, hits, d_power != nullptr, ba, p->num_cus, s.stream));
+    const bool dc = p->d.correct_dc && p->d.sample_kind != SCN_KIND_FLOAT_COMPLEX;
+    if (nb && dc && !s.d_gen_work[1]) SCN_HIP(hipMalloc(&s.d_gen_work[1], sizeof(int) * 2 * (size_t)p->d.max_batch));
+    ba.dc_sums = dc ? static_cast<int *>(s.d_gen_work[1]) : nullptr;
+    SCN_HIP(scn_launch_big(n, (int)p->d.sample_kind, dc, hits, d_power != nullptr, ba, p->num_cus, s.stream));
   } else if (p->generic) {
     for (int g = 0; g < 2 && nb; g++)
       if (!s.d_gen_work[g]) SCN_HIP(hipMalloc(&s.d_gen_work[g], 2u * sizeof(double) * (size_t)p->fft_m * p->d.max_batch));
@@ -599,7 +602,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     p->fft_cus = p->num_cus;
     if (const char *e = getenv("SCN_EXP_COMPACT")) p->compact_mode = atoi(e);
     if (const char *e = getenv("SCN_EXP_RESERVE_CUS")) p->fft_cus = std::max(1, p->num_cus - atoi(e));
-    p->big = d.mode == SCN_MODE_FREQUENCY_DOMAIN && scn_big_size_supported(d.n) && !(d.correct_dc && d.sample_kind != SCN_KIND_FLOAT_COMPLEX);
+    p->big = d.mode == SCN_MODE_FREQUENCY_DOMAIN && scn_big_size_supported(d.n);
     p->generic = d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !p->big;
     p->direct_counts = d.n >= 8192 && !p->generic && !p->big;  // (the fused kernels from 8192 points up store the counts to pinned memory themselves)
     if (const char *e = getenv("SCN_EXP_DIRECT_COUNTS")) p->direct_counts = atoi(e) != 0;

@@ -211,7 +211,10 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t x) {
 // kernels), and the value is formed here by the rule the spectrum kernels of the same family use -- the exact half of the
 // map for the strong maximum of the thread's group of outputs, the product form for every other bin -- or, with PURE, by
 // db_of_power (scn_big.hip, whose spectrum is stored through that).
-template <int NB, bool IS_DB, bool PURE = false, typename VEC, typename ARGS, typename BINI>
+// ONE_ATOMIC: the counter is in device memory (scn_big.hip), where a returning atomic costs microseconds, not ~100 cycles:
+// the wave first evaluates all its candidate indices (values written back into `pw`, hit lanes and the count accumulated),
+// takes its slots with ONE atomic and records in a second pass over the indices that had hits.
+template <int NB, bool IS_DB, bool PURE = false, bool ONE_ATOMIC = false, typename VEC, typename ARGS, typename BINI>
 __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count, uint32_t buf,
                                                 uint32_t lane, BINI bin_i) {
   constexpr int GS = NB / 4;
@@ -226,6 +229,7 @@ __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4],
     }
   }
   ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+  uint32_t hm = 0, wm2 = 0, total = 0;  // ONE_ATOMIC: this lane's hits, the indices with hits, the wave's count
   // (one loop over all indices; only the group-maximum rule needs the group's maximum by name -- indexed, it went through
   // scratch -- and gets one loop per group)
   constexpr int NL = (!IS_DB && !PURE) ? 4 : 1;
@@ -247,7 +251,12 @@ __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4],
       }
       const bool hit = ((keepmask >> o) & 1u) && d > args.threshold && (IS_DB || p > args.p_lo);  // strict >, process.cpp:54
       const unsigned long long m = __ballot(hit);
-      if (m) {
+      if constexpr (ONE_ATOMIC) {
+        pw[o] = d;
+        hm |= hit ? (1u << o) : 0u;
+        wm2 |= m ? (1u << o) : 0u;
+        total += (uint32_t)__popcll(m);
+      } else if (m) {
         const int first = __builtin_ctzll(m);
         uint32_t base = 0;
         if (lane == (uint32_t)first) base = (uint32_t)atomicAdd(count, (int)__popcll(m));
@@ -257,6 +266,23 @@ __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4],
           if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), d};
         }
       }
+    }
+  }
+  if constexpr (ONE_ATOMIC) {
+    if (!total) return;
+    uint32_t base = 0;
+    if (lane == 0) base = (uint32_t)atomicAdd(count, (int)total);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    while (wm2) {
+      const int o = __builtin_ctz(wm2);  // wave-uniform
+      wm2 &= wm2 - 1u;
+      const bool hit = (hm >> o) & 1u;
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), pw[o]};
+      }
+      base += (uint32_t)__popcll(m);
     }
   }
 }

@@ -129,7 +129,7 @@ hipError_t scn_launch_generic(int kind, bool correct_dc, bool hits, const ScnGen
 bool scn_generic_size_supported(uint32_t n);    // powers of two, 16 ... 65536
 bool scn_bluestein_size_supported(uint32_t n);  // everything else from 16 to 32768
 
-// Plain 65536-point plans through the four-step pair of scn_big.hip (columns -> tiled work buffer -> rows + K4 + K5)
+// Plain 65536- / 32768-point plans through the four-step pair of scn_big.hip (columns -> tiled work buffer -> rows + K4 + K5)
 struct ScnBigArgs {
   const void *raw;            // n_buffers raw buffers back to back
   const float *window;        // [65536]
@@ -143,9 +143,10 @@ struct ScnBigArgs {
   ScnDevHit *hits;            // [n_buffers][hit_region]
   uint32_t hit_region;
   uint32_t *per_buffer_hits;  // [n_buffers], zeroed by the launcher
+  int *dc_sums;               // [n_buffers][2] scratch for DC removal of integer samples (zeroed by the launcher), or nullptr
 };
-hipError_t scn_launch_big(int kind, bool hits, bool spectrum, const ScnBigArgs &args, int num_cus, hipStream_t stream);
-bool scn_big_size_supported(uint32_t n);  // 65536 (without DC removal)
+hipError_t scn_launch_big(uint32_t n, int kind, bool correct_dc, bool hits, bool spectrum, const ScnBigArgs &args, int num_cus, hipStream_t stream);
+bool scn_big_size_supported(uint32_t n);  // 65536, 32768
 
 // K1 alone (capture path)
 hipError_t scn_launch_convert(int kind, bool correct_dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers,

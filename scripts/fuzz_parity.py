@@ -66,7 +66,7 @@ def run(budget, seed):
     near_misses.clear()
     worst_by_n.clear()
     while time.time() < t_end:
-        # 256 / 512: several buffers per workgroup; 65536: the four-step pair (staged path with DC removal); 32768, 1000: the staged path (1000: Bluestein)
+        # 256 / 512: several buffers per workgroup; 65536, 32768: the four-step pairs; 1000: the staged path (Bluestein)
         sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else \
             [1024, 2048, 4096, 8192, 16384, 16384, 256, 512, 65536, 32768, 1000]
         n = int(rng.choice(sizes))

@@ -363,14 +363,16 @@ def test_generic_sizes_vs_oracle(torch_cuda, oracle_mod, n, kind, enob, dc):
     (256, capi.KIND_SHORT_COMPLEX, 12, True), (256, capi.KIND_SHORT, 12, False), (256, capi.KIND_BYTE_COMPLEX, 8, False),
     (512, capi.KIND_FLOAT_COMPLEX, 12, False), (512, capi.KIND_SHORT_COMPLEX, 12, True), (512, capi.KIND_SHORT, 12, True),
     (65536, capi.KIND_SHORT_COMPLEX, 12, False), (65536, capi.KIND_SHORT, 12, False),
-    (65536, capi.KIND_SHORT_COMPLEX, 12, True),      # DC removal at 65536 points stays on the staged path (the buffer's sum comes first)
+    # DC removal on the four-step path: scn_big_dc_kernel takes the buffer's integer sums first
+    (65536, capi.KIND_SHORT_COMPLEX, 12, True), (65536, capi.KIND_BYTE_COMPLEX, 8, True), (32768, capi.KIND_SHORT, 12, True),
+    (32768, capi.KIND_FLOAT_COMPLEX, 12, False), (32768, capi.KIND_SHORT, 12, False), (32768, capi.KIND_BYTE_COMPLEX, 8, False),
 ])
 @pytest.mark.parametrize("flags", ["both", "hits", "spectrum"])
 def test_round3_kernels_formats_and_output_modes(torch_cuda, oracle_mod, n, kind, enob, dc, flags):
     """The kernels new in round 3 -- several buffers per workgroup at 256 / 512 points (scn_fft_small_kernel), the four-step
-    pair for plain 65536-point plans (scn_big.hip) -- for every wire format, with batch sizes that leave the last workgroup's
+    pairs for plain 65536- and 32768-point plans (scn_big.hip) -- for every wire format, with batch sizes that leave the last workgroup's
     buffer slots partly empty, in all three output modes: spectra to the bar, hit lists bit for bit."""
-    nb = {256: 16 * 9 + 5, 512: 8 * 11 + 3, 65536: 4}[n]
+    nb = {256: 16 * 9 + 5, 512: 8 * 11 + 3, 65536: 4, 32768: 7}[n]
     x = synth.cfloat_batch(n, nb, seed=170 + n % 1000, sigma=0.1)
     raw = synth.quantize(x, kind) if kind != capi.KIND_FLOAT_COMPLEX else x
     if dc:

@@ -214,6 +214,9 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t x) {
 // ONE_ATOMIC: the counter is in device memory (scn_big.hip), where a returning atomic costs microseconds, not ~100 cycles:
 // the wave first evaluates all its candidate indices (values written back into `pw`, hit lanes and the count accumulated),
 // takes its slots with ONE atomic and records in a second pass over the indices that had hits.
+#ifndef SCN_EXP_HITCUT
+#define SCN_EXP_HITCUT 0  // experiment: 1 = no record stores, 2 = candidate mask only (profiles/r03_experiments.md section 6)
+#endif
 template <int NB, bool IS_DB, bool PURE = false, bool ONE_ATOMIC = false, typename VEC, typename ARGS, typename BINI>
 __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count, uint32_t buf,
                                                 uint32_t lane, BINI bin_i) {
@@ -229,6 +232,9 @@ __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4],
     }
   }
   ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+#if SCN_EXP_HITCUT == 2
+  if (wmc != 0xdeadbeefu) return;
+#endif
   uint32_t hm = 0, wm2 = 0, total = 0;  // ONE_ATOMIC: this lane's hits, the indices with hits, the wave's count
   // (one loop over all indices; only the group-maximum rule needs the group's maximum by name -- indexed, it went through
   // scratch -- and gets one loop per group)
@@ -263,7 +269,11 @@ __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4],
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
         if (hit) {
           const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+#if SCN_EXP_HITCUT == 1
+          if (pos == 0xdeadbeefu) region[pos] = ScnDevHit{bin_i(o), d};
+#else
           if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), d};
+#endif
         }
       }
     }
@@ -283,6 +293,112 @@ __device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4],
         if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), pw[o]};
       }
       base += (uint32_t)__popcll(m);
+    }
+  }
+}
+
+// The per-lane form of the above (same decisions, same records, other order of work): every lane collects ITS candidate
+// outputs in a bit mask with straight-line VALU work (no wave-wide test per output index), then the wave takes one candidate
+// per lane per trip -- the value comes out of the registers through a select tree, not a register-indexed move -- until no lane
+// has one left.  Trips = the largest number of candidates any one lane holds (a tone's main lobe sits in neighbouring lanes of
+// one output index: 1; noise hits at the bench's threshold: 2..3) instead of the number of output indices that hold one.
+// (v_cndmask_b32 spelled out: written as C++ selects, hipcc recognises "element o of a vector" and lowers THAT as a chain of
+// 32 compares + selects, several times over -- 1400 instructions per trip)
+__device__ __forceinline__ float scn_cndmask(float a, float b, unsigned long long m) {  // lane in m ? b : a
+  float r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+  return r;
+}
+template <int NB, typename VEC>
+__device__ __forceinline__ float scn_select_output(const VEC &pw, uint32_t o) {  // all lanes active
+  float t[NB / 2];
+  const unsigned long long m0 = __ballot(o & 1u);
+#pragma unroll
+  for (int i = 0; i < NB / 2; i++) t[i] = scn_cndmask(pw[2 * i], pw[2 * i + 1], m0);
+#pragma unroll
+  for (int w = NB / 4, bit = 1; w >= 1; w >>= 1, bit++) {
+    const unsigned long long m = __ballot((o >> bit) & 1u);
+#pragma unroll
+    for (int i = 0; i < w; i++) t[i] = scn_cndmask(t[2 * i], t[2 * i + 1], m);
+  }
+  return t[0];
+}
+
+#ifndef SCN_HITS_SCAN
+#define SCN_HITS_SCAN 1
+#endif
+// HAVE_MASK: the caller collected the candidate bits (`cand`, before the keep mask) while it produced the outputs.
+template <int NB, bool IS_DB, bool PURE = false, bool HAVE_MASK = false, typename VEC, typename ARGS, typename BINI>
+__device__ __forceinline__ void scn_record_hits_lanes(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count, uint32_t buf,
+                                                      uint32_t lane, BINI bin_i, uint32_t cand = 0) {
+  constexpr int GS = NB / 4;
+  uint32_t hm = cand;
+  if constexpr (!HAVE_MASK) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (__ballot(gmax[g] > args.p_lo)) {
+#pragma unroll
+        for (int o = g * GS; o < (g + 1) * GS; o++) hm |= (IS_DB ? pw[o] > args.threshold : pw[o] > args.p_lo) ? (1u << o) : 0u;
+      }
+    }
+  }
+  hm &= keepmask;
+  ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+#if SCN_EXP_HITCUT == 2
+  if (hm != 0xdeadbeefu) return;
+#endif
+  if constexpr (IS_DB && SCN_HITS_SCAN) {
+    // the outputs ARE the dB values: every candidate bit is a hit, the wave's count is known before the first record -- one
+    // prefix sum over the lanes' counts, ONE counter atomic, then the trips carry no wave-wide step at all
+    const uint32_t cnt = (uint32_t)__builtin_popcount(hm);
+    uint32_t inc = cnt;
+    SCN_DPP_STEP(+, inc, 0x111, 0xf);
+    SCN_DPP_STEP(+, inc, 0x112, 0xf);
+    SCN_DPP_STEP(+, inc, 0x114, 0xf);
+    SCN_DPP_STEP(+, inc, 0x118, 0xf);
+    SCN_DPP_STEP(+, inc, 0x142, 0xa);
+    SCN_DPP_STEP(+, inc, 0x143, 0xc);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    if (!total) return;
+    uint32_t base = 0;
+    if (lane == 0) base = (uint32_t)atomicAdd(count, (int)total);
+    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + inc - cnt;
+    while (__ballot(hm != 0u)) {
+      const bool act = hm != 0u;
+      const uint32_t o = act ? (uint32_t)__builtin_ctz(hm) : 0u;
+      hm &= hm - 1u;
+      const float d = scn_select_output<NB>(pw, o);
+      if (act && pos < args.hit_region) region[pos] = ScnDevHit{bin_i((int)o), d};
+      pos += 1u;
+    }
+    return;
+  }
+  while (__ballot(hm != 0u)) {
+    const bool act = hm != 0u;
+    const uint32_t o = act ? (uint32_t)__builtin_ctz(hm) : 0u;
+    hm &= hm - 1u;
+    const float p = scn_select_output<NB>(pw, o);
+    float d = p;
+    if constexpr (!IS_DB) {
+      d = db_fast(p);
+      bool ex = p >= SCN_P_EXACT_FROM;
+      if constexpr (!PURE) {  // the exact form for each thread-group's strong maximum only (the 16384-point kernel's map)
+        const float gm = (o / GS) & 2u ? ((o / GS) & 1u ? gmax[3] : gmax[2]) : ((o / GS) & 1u ? gmax[1] : gmax[0]);
+        ex = ex && p == gm;
+      }
+      if (__ballot(act && ex)) d = ex ? db_exact(p) : d;
+    }
+    const bool hit = act && d > args.threshold && (IS_DB || p > args.p_lo);  // strict >, process.cpp:54
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+      const int first = __builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == (uint32_t)first) base = (uint32_t)atomicAdd(count, (int)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+      if (hit) {
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i((int)o), d};
+      }
     }
   }
 }

@@ -30,6 +30,31 @@
 
 
 #include "scn_device.h"
+// The hit path of the narrow / 8192 / 16384-point kernels: the per-lane form (scn_record_hits_lanes, product) or, with 0, the
+// per-output-index form (scn_record_hits; with SCN_ONE_ATOMIC_* its two-pass variant) -- profiles/r03_experiments.md section 6
+#ifndef SCN_HITS_LANES_N
+#define SCN_HITS_LANES_N 1
+#endif
+#ifndef SCN_HITS_LANES_W
+#define SCN_HITS_LANES_W 1
+#endif
+#ifndef SCN_HITS_LANES_16K
+#define SCN_HITS_LANES_16K 1
+#endif
+#ifndef SCN_HITS_MASK_16K
+#define SCN_HITS_MASK_16K 1  // the 16384-point HITS-ONLY kernel collects the candidate bits while it produces the powers (with the
+                             // spectrum's stores in the same loop that cost 1-3 us instead of saving 3: profiles/r03_experiments.md section 6)
+#endif
+#ifndef SCN_ONE_ATOMIC_N
+#define SCN_ONE_ATOMIC_N false
+#endif
+#ifndef SCN_ONE_ATOMIC_W
+#define SCN_ONE_ATOMIC_W false
+#endif
+#ifndef SCN_ONE_ATOMIC_16K
+#define SCN_ONE_ATOMIC_16K false
+#endif
+
 
 namespace {
 
@@ -631,7 +656,11 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
         const uint32_t h0_ = (uint32_t)__builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        scn_record_hits<16, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
+#if SCN_HITS_LANES_N
+        scn_record_hits_lanes<16, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
+#else
+        scn_record_hits<16, false, true, SCN_ONE_ATOMIC_N>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
+#endif
 #if SCN_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         stamp_hit_cyc += (uint32_t)__builtin_readcyclecounter() - h0_;
@@ -1358,7 +1387,11 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
         const uint32_t h0_ = (uint32_t)__builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        scn_record_hits<32, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
+#if SCN_HITS_LANES_W
+        scn_record_hits_lanes<32, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
+#else
+        scn_record_hits<32, false, true, SCN_ONE_ATOMIC_W>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
+#endif
 #if SCN_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         stamp_hit_cyc += (uint32_t)__builtin_readcyclecounter() - h0_;
@@ -1608,6 +1641,7 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     //      product-form dB stored inline, exact form stored over it for strong bins in the waves that hold one) ----
     v32f pw;
     float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t cand = 0;  // (HITS) this lane's candidate outputs, collected as they are produced
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
     if constexpr (P3D) {
       // decimation in frequency: A[c''] = x[c''] + x[c''+16] -> DFT16 -> X[2 rho];  B[c''] = (x[c''] - x[c''+16]) W_32^c'' -> DFT16 -> X[2 rho + 1]
@@ -1638,6 +1672,7 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 2048u * r, AUX_ST);
           } else {
             pw[r] = q;
+            if constexpr (HITS && SCN_HITS_MASK_16K) cand |= q > args.p_lo ? (1u << r) : 0u;
           }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads and conversions out of the first half's live range
@@ -1671,6 +1706,7 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
         } else {
           pw[r] = p0;
           pw[r + 16] = p1;
+          if constexpr (HITS && SCN_HITS_MASK_16K) cand |= (p0 > args.p_lo ? (1u << r) : 0u) | (p1 > args.p_lo ? (1u << (r + 16)) : 0u);
         }
       }
     }
@@ -1697,7 +1733,11 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     __syncthreads();  // barrier 4: exchange area free again
     if (HITS) {
       if (__ballot(pmax > args.p_lo))
-        scn_record_hits<32, SPEC>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); });
+#if SCN_HITS_LANES_16K
+        scn_record_hits_lanes<32, SPEC, false, !SPEC && SCN_HITS_MASK_16K != 0>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); }, cand);
+#else
+        scn_record_hits<32, SPEC, false, SCN_ONE_ATOMIC_16K>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); });
+#endif
       prev = buf;
       par ^= 1;
     }

@@ -38,6 +38,9 @@
 #ifndef SCN_HITS_LANES_W
 #define SCN_HITS_LANES_W 1
 #endif
+#ifndef SCN_HITS_LANES_S
+#define SCN_HITS_LANES_S 1
+#endif
 #ifndef SCN_HITS_LANES_16K
 #define SCN_HITS_LANES_16K 1
 #endif
@@ -887,8 +890,22 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
 #pragma unroll
         for (int o = 0; o < 16; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
         cand &= valid ? keepmask : 0u;
-        uint32_t wm = wave_or_u32(cand);
         ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+#if SCN_HITS_LANES_S
+        while (__ballot(cand != 0u)) {  // one candidate per lane per trip (scn_record_hits_lanes; here a lane's counter is its slot's)
+          const bool act = cand != 0u;
+          const uint32_t o = act ? (uint32_t)__builtin_ctz(cand) : 0u;
+          cand &= cand - 1u;
+          const float q = scn_select_output<16>(pw, o);
+          float d = db_fast(q);
+          if (__ballot(act && q >= SCN_P_EXACT_FROM)) d = q >= SCN_P_EXACT_FROM ? db_exact(q) : d;
+          if (act && d > args.threshold) {  // strict >, process.cpp:54
+            const uint32_t pos = (uint32_t)atomicAdd(&lds_hits[slot], 1);
+            if (pos < args.hit_region) region[pos] = ScnDevHit{(t + joff_of((int)o)) ^ (N / 2), d};
+          }
+        }
+#else
+        uint32_t wm = wave_or_u32(cand);
         while (wm) {
           const int o = __builtin_ctz(wm);  // wave-uniform
           wm &= wm - 1u;
@@ -900,6 +917,7 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
             if (pos < args.hit_region) region[pos] = ScnDevHit{(t + joff_of(o)) ^ (N / 2), d};
           }
         }
+#endif
       }
     }
     __syncthreads();  // exchange areas free again; the slots' hit counters final

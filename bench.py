@@ -71,6 +71,7 @@ def parse():
                     help="c4: sweeps of the rank's shard batched into one launch (0: as many as fit 8192 buffers; 1: a launch per sweep)")
     ap.add_argument("--no-hits-only-leg", action="store_true", help="skip the extra leg on a plan without SCN_OUT_SPECTRUM")
     ap.add_argument("--no-copy-ref", action="store_true", help="skip the device-to-device copy measured beside the roofline")
+    ap.add_argument("--records-depth", type=int, default=4, help="records legs: submits in flight (<= SCN_NUM_SLOTS)")
     ap.add_argument("--no-records-leg", action="store_true",
                     help="skip the extra leg that times the same steps with the ordered hit records fetched every step")
     ap.add_argument("--dry-run", action="store_true",
@@ -353,7 +354,9 @@ def kernel_name(n, kind, hits=True, spectrum=True):
     if n in (1024, 2048, 4096):
         return f"scn_fft_kernel<{n // 256}, {k}, false, {h}, {sp}>"
     if n == 65536:
-        return f"scn_big_cols_kernel<{k}> + scn_big_rows_kernel<{h}, {sp}> (four-step 256 x 256, scn_big.hip: the work buffer's round trip is not algorithmic traffic)"
+        return f"scn_big_cols_kernel<{k}, 65536, false> + scn_big_rows_kernel<{h}, {sp}> (four-step 256 x 256, scn_big.hip: the work buffer's round trip is not algorithmic traffic)"
+    if n == 32768:
+        return f"scn_big_cols_kernel<{k}, 32768, false> + scn_big_rows32k_kernel<{h}, {sp}> (four-step 256 x 128, scn_big.hip: the work buffer's round trip is not algorithmic traffic)"
     return "scn_gen_load_kernel + scn_gen_stage_kernel x log4(n) + scn_gen_finish_kernel (the staged path, scn_generic.hip)"
 
 
@@ -477,10 +480,11 @@ def main():
     plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank)
     ext = torch.cuda.ExternalStream(plan.stream_handle, device=dev)
 
-    def make_loop(pl, want_records, zero_copy=False, spectrum=True):
-        """step(k): one pass over this rank's batch = len(chunks) launches, double-buffered over the plan's two slots; the
-        results of a slot are collected right before it is reused (counts + trigger flags; the ordered records too if asked)"""
-        pending = [False, False]
+    def make_loop(pl, want_records, zero_copy=False, spectrum=True, depth=2):
+        """step(k): one pass over this rank's batch = len(chunks) launches, double-buffered over two of the plan's slots (`depth`
+        of them in the records legs); the results of a slot are collected right before it is reused (counts + trigger flags;
+        the ordered records too if asked)"""
+        pending = [False] * depth
         state = {"launch": 0, "hits": 0, "acc": 0, "group": 0}
         rec_buf = np.zeros(hit_cap, capi.HIT_DTYPE) if want_records else None  # the caller's record buffer, reused
 
@@ -503,7 +507,7 @@ def main():
                 return
             g = state["group"] % len(graws)
             state["group"] += 1
-            s = state["launch"] & 1
+            s = state["launch"] % depth
             state["launch"] += 1
             if pending[s]:
                 collect(s)
@@ -521,7 +525,7 @@ def main():
                     flush()
                 return
             for lo, hi in chunks:
-                s = state["launch"] & 1
+                s = state["launch"] % depth
                 state["launch"] += 1
                 if pending[s]:
                     collect(s)
@@ -531,7 +535,8 @@ def main():
 
         def drain():
             flush()
-            for s in ((state["launch"] & 1), ((state["launch"] + 1) & 1)):  # older slot first
+            for j in range(depth):  # oldest slot first
+                s = (state["launch"] + j) % depth
                 if pending[s]:
                     collect(s)
 
@@ -601,8 +606,8 @@ def main():
     # mostly its own start and end, and these legs exist to show steady-state rates
     leg_steps = max(args.steps, 200)
 
-    def timed_leg(pl, want_records, warm, zero_copy=False, spectrum=True):
-        st, dr, state = make_loop(pl, want_records, zero_copy, spectrum)
+    def timed_leg(pl, want_records, warm, zero_copy=False, spectrum=True, depth=2):
+        st, dr, state = make_loop(pl, want_records, zero_copy, spectrum, depth)
         for k in range(max(warm, 50)):
             st(k)
         dr()
@@ -630,9 +635,10 @@ def main():
     # scn_collect alone (everything already on the host side of PCIe: counts loop + one memcpy out of pinned memory).
     records = None
     if not args.no_records_leg:
-        el3, st3 = timed_leg(plan, True, min(args.warmup, 20))
+        el3, st3 = timed_leg(plan, True, min(args.warmup, 20), depth=args.records_depth)
         nh = st3["hits"]
-        el4, st4 = timed_leg(plan, True, min(args.warmup, 20), zero_copy=True)
+        el4, st4 = timed_leg(plan, True, min(args.warmup, 20), zero_copy=True, depth=args.records_depth)
+        el3b, _ = timed_leg(plan, True, min(args.warmup, 20))  # two in flight, as the contract leg and rounds 1-2 ran it
         rec_buf = np.zeros(hit_cap, capi.HIT_DTYPE)
         rec_buf[:] = 0  # touched: np.zeros hands out untouched pages, and their first-touch faults would be timed below
         samples_us = []
@@ -648,7 +654,8 @@ def main():
         records = {"value": round(world * shard * n * leg_steps / el3 / 1e6, 1), "unit": "Msamples/s", "steps": leg_steps,
                    "ms_per_step": round(el3 / leg_steps * 1e3, 5), "hits_per_step": round(nh / max(leg_steps, 1), 1),
                    "collect_with_records_us": round(collect_us, 1), "collect_with_records_us_min": round(min(samples_us), 1),
-                   "collect_hits": int(len(h1)),
+                   "collect_hits": int(len(h1)), "submits_in_flight": args.records_depth,
+                   "two_in_flight": {"value": round(world * shard * n * leg_steps / el3b / 1e6, 1), "ms_per_step": round(el3b / leg_steps * 1e3, 5)},
                    "collect_call_avg_us_in_loop": round(st3["collect_s"] / max(st3["collects"], 1) * 1e6, 1),
                    "zero_copy_view": {"value": round(world * shard * n * leg_steps / el4 / 1e6, 1), "ms_per_step": round(el4 / leg_steps * 1e3, 5),
                                       "collect_plus_view_avg_us_in_loop": round(st4["collect_s"] / max(st4["collects"], 1) * 1e6, 1),

@@ -109,7 +109,9 @@ typedef struct scn_plan_desc {
 } scn_plan_desc;
 
 #define SCN_DC_IGNORE_NONE 0xffffffffu
-#define SCN_NUM_SLOTS 2
+/* Submits a plan can have in flight (submit ... collect per slot).  Two cover kernel-only pipelines; with the ordered records
+ * fetched every step a submit's chain is kernel + list + DMA + the caller's copy, and three or four in flight keep the GPU fed. */
+#define SCN_NUM_SLOTS 4
 
 typedef struct scn_plan scn_plan;
 

@@ -19,7 +19,7 @@ WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 3, 5
 OUT_SPECTRUM, OUT_HITS = 1, 2
 PLAN_OVERLAP_SLOTS = 4  # each slot on its own compute stream (scanner_hip.h)
 DC_IGNORE_NONE = 0xFFFFFFFF
-NUM_SLOTS = 2
+NUM_SLOTS = 4
 ABI_VERSION = 2
 COMM_ID_BYTES = 128
 

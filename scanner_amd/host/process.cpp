@@ -126,9 +126,11 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   scn_plan *plan = nullptr;
   if (!Ok(scn_plan_create(&d, &plan), "scn_plan_create")) return abandon(nullptr);
 
-  unsigned char *stage[SCN_NUM_SLOTS];
+  constexpr int kPipe = 2;  // batches in flight: this consumer ping-pongs two of the plan's SCN_NUM_SLOTS slots
+  static_assert(kPipe <= SCN_NUM_SLOTS, "plan slots");
+  unsigned char *stage[kPipe];
   size_t stageBytes = 0, bufBytes = 0;
-  for (int s = 0; s < SCN_NUM_SLOTS; s++)
+  for (int s = 0; s < kPipe; s++)
     if (!Ok(scn_host_buffer(plan, s, (void **)&stage[s], &stageBytes), "scn_host_buffer")) return abandon(plan);
   if (!Ok(scn_buffer_bytes(plan, &bufBytes), "scn_buffer_bytes")) return abandon(plan);
   if (bufBytes != q.GetBufferBytes()) {  // the queue was built for another sample kind / count than this ProcessSamples
@@ -142,8 +144,8 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   std::vector<uint8_t> trig(d.max_batch);
   std::vector<float> tdMax(d.max_batch), tdMin(d.max_batch);
   std::vector<scn_hit> hits((size_t)d.max_batch * 64u);
-  std::vector<SampleQueue::MessageType *> inflight[SCN_NUM_SLOTS];
-  bool pending[SCN_NUM_SLOTS] = {false, false};
+  std::vector<SampleQueue::MessageType *> inflight[kPipe];
+  bool pending[kPipe] = {};
   uint64_t lastSequenceId = 0;
   double lastFrequency = 0;
 

@@ -15,5 +15,6 @@ if [ -n "$SCN_PROF_MORE" ]; then   # the other wire formats and sizes (not BASEL
   bash scripts/prof.sh ${TAG}_n16384int16 --n 16384 --batch 2048 --kind int16 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n512cfloat --n 512 --batch 65536 > /dev/null 2>&1
   SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n65536cfloat --n 65536 --batch 512 > /dev/null 2>&1
+  SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n32768cfloat --n 32768 --batch 1024 > /dev/null 2>&1
 fi
 for c in c2 c3 c4shape c5; do echo "=== $c"; cat gpurun_out/prof_${TAG}_$c/summary.txt; done

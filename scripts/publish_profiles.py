@@ -11,13 +11,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 shapes_path = os.path.join(ROOT, "profiles", "measured_shapes.json")
 shapes = json.load(open(shapes_path)) if os.path.exists(shapes_path) else {}
-for shape in ("c2", "c3", "c4shape", "c5", "n4096int16", "n4096int8", "n16384cfloat", "n16384int16", "n8192cfloat", "n512cfloat", "n65536cfloat"):
+for shape in ("c2", "c3", "c4shape", "c5", "n4096int16", "n4096int8", "n16384cfloat", "n16384int16", "n8192cfloat", "n512cfloat", "n65536cfloat", "n32768cfloat"):
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{shape}")
     if not os.path.exists(os.path.join(d, "summary.txt")):
         print("missing", d)
         continue
     shutil.copy(os.path.join(d, "summary.txt"), os.path.join(ROOT, "profiles", f"{tag}_{shape}_rocprofv3_summary.txt"))
     shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_{shape}_kernel_stats.csv"))
+    if not os.path.exists(os.path.join(d, "pmc_traffic.json")):  # (a counter pass that did not finish: the summary says so)
+        print("no traffic counters for", shape)
+        continue
     t = json.load(open(os.path.join(d, "pmc_traffic.json")))
     welch = t.get("segments_per_psd") is not None
     key = (f"welch/{t['n']}/{t['segments_per_psd']}/{t['psd_per_submit']}" if welch

@@ -62,7 +62,7 @@ enum {
   SCN_OUT_HITS = 2u,     /* threshold every in-band bin into the hit list.  Alone (no SCN_OUT_SPECTRUM): the hits-only
                           * kernels -- no spectrum is stored and no per-bin logarithm taken; the same bins are reported,
                           * with the same power_db, as with the spectrum kept */
-  /* Not an output: give each of the two slots its own compute stream, so that the launch of one slot
+  /* Not an output: give each slot its own compute stream, so that the launch of one slot
    * overlaps the tail of the other slot's launch (the next batch's workgroups fill the CUs the finishing
    * batch frees) instead of waiting for it to drain.  Measured on C2: one launch per 67.6 us instead of
    * 76.0 (+12 % throughput).  Off by default because each kernel's own begin-to-end time grows while it

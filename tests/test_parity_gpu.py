@@ -227,6 +227,54 @@ def test_overlapped_slots_give_identical_results(torch_cuda, n, kind, enob, path
     assert total > 100
 
 
+@pytest.mark.parametrize("n,kind,enob,flags", [
+    (4096, capi.KIND_FLOAT_COMPLEX, 12, 0), (4096, capi.KIND_SHORT_COMPLEX, 12, capi.PLAN_OVERLAP_SLOTS),
+    (8192, capi.KIND_BYTE_COMPLEX, 8, 0), (16384, capi.KIND_SHORT_COMPLEX, 12, 0), (512, capi.KIND_SHORT, 12, 0),
+])
+def test_all_slots_in_flight(torch_cuda, n, kind, enob, flags):
+    """SCN_NUM_SLOTS submits in flight (the records pipeline of bench.py: kernel, list kernels, DMA and the caller's copy of
+    up to four submits overlap): every spectrum bit, every ordered record and every trigger flag must equal what the same
+    batches give one at a time on slot 0 -- in a pipeline that collects a slot only right before it is reused, through the
+    copying collect and through scn_hits_view."""
+    torch = torch_cuda
+    assert capi.NUM_SLOTS >= 4
+    nb, rounds = 700, 11    # (the integer kinds pull from the buffer queue, whose bases the host tracks per slot)
+    raws = [synth.quantize(synth.cfloat_batch(n, nb, seed=1300 + k), kind) for k in range(rounds)]
+    sizes = [nb, nb - 1, 3, nb, 650, nb, 1, nb, 333, nb, nb]
+    fcs = [100e6 + 6e6 * np.arange(nb) + 11 * k for k in range(rounds)]
+    seqs = [np.arange(k * nb, (k + 1) * nb, dtype=np.uint64) for k in range(rounds)]
+    fl = capi.OUT_SPECTRUM | capi.OUT_HITS | flags
+
+    def take(plan, s, view):
+        if not view:
+            return plan.collect(s, hit_cap=1 << 18)
+        p, _, t = plan.collect(s, want_hits=False)
+        return p, plan.hits_view(s).copy(), t
+
+    with Plan(n, FS, 9.5, kind=kind, enob=enob, max_batch=nb, max_hits=1 << 18, flags=fl) as plan:
+        dev = [_to_dev(torch, r) for r in raws]
+        ref = []
+        for k in range(rounds):
+            plan.submit_device(0, dev[k], sizes[k], fcs[k][:sizes[k]], seqs[k][:sizes[k]])
+            ref.append(plan.collect(0, hit_cap=1 << 18))
+        for view in (False, True):
+            got = []
+            for k in range(rounds):
+                s = k % capi.NUM_SLOTS
+                if k >= capi.NUM_SLOTS:
+                    got.append(take(plan, s, view))
+                plan.submit_device(s, dev[k], sizes[k], fcs[k][:sizes[k]], seqs[k][:sizes[k]])
+            for j in range(capi.NUM_SLOTS):  # oldest first
+                got.append(take(plan, (rounds + j) % capi.NUM_SLOTS, view))
+            assert len(got) == rounds
+            total = 0
+            for (p0, h0, t0), (p1, h1, t1) in zip(ref, got):
+                assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+                assert h0.tobytes() == h1.tobytes() and np.array_equal(t0, t1)
+                total += len(h0)
+            assert total > 100
+
+
 @pytest.mark.parametrize("n,kind,enob,dc", [(4096, capi.KIND_SHORT_COMPLEX, 12, False), (4096, capi.KIND_BYTE_COMPLEX, 8, False),
                                             (1024, capi.KIND_SHORT, 12, True), (8192, capi.KIND_BYTE_COMPLEX, 8, False)])
 def test_buffer_queue_over_many_launches(torch_cuda, oracle_mod, n, kind, enob, dc):

@@ -31,6 +31,21 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert sorted(capi.SYMBOLS) == names
 
 
+def test_python_constants_follow_the_header():
+    """capi.py restates a few of the header's constants for ctypes callers: they must be the header's (SCN_NUM_SLOTS went from
+    2 to 4 in round 3; a stale copy would make Plan refuse -- or worse, mis-size -- the slots the library has)."""
+    src = open(HEADER).read()
+
+    def macro(name):
+        return int(re.search(r"#define\s+%s\s+(\d+)" % name, src).group(1))
+
+    assert capi.NUM_SLOTS == macro("SCN_NUM_SLOTS")
+    assert capi.ABI_VERSION == macro("SCN_ABI_VERSION")
+    enum = dict((k, int(v)) for k, v in re.findall(r"(SCN_(?:OUT_SPECTRUM|OUT_HITS|PLAN_OVERLAP_SLOTS))\s*=\s*(\d+)u", src))
+    assert (capi.OUT_SPECTRUM, capi.OUT_HITS, capi.PLAN_OVERLAP_SLOTS) == (
+        enum["SCN_OUT_SPECTRUM"], enum["SCN_OUT_HITS"], enum["SCN_PLAN_OVERLAP_SLOTS"])
+
+
 def test_header_compiles_as_c_and_cxx(tmp_path):
     for comp, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "cpp")):
         f = tmp_path / f"t.{ext}"

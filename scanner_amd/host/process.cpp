@@ -126,7 +126,11 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   scn_plan *plan = nullptr;
   if (!Ok(scn_plan_create(&d, &plan), "scn_plan_create")) return abandon(nullptr);
 
-  constexpr int kPipe = 2;  // batches in flight: this consumer ping-pongs two of the plan's SCN_NUM_SLOTS slots
+  // Batches in flight.  This consumer prints every record of every batch (process.cpp:57), so a submit's chain is kernel ->
+  // list kernels -> DMA -> the copy in scn_collect, longer than one kernel: three in flight keep the GPU fed where two left it
+  // idle between launches (the records pipeline); a batch's lines still appear as soon as the queue runs
+  // empty, and always in submit order.
+  constexpr int kPipe = 3;
   static_assert(kPipe <= SCN_NUM_SLOTS, "plan slots");
   unsigned char *stage[kPipe];
   size_t stageBytes = 0, bufBytes = 0;
@@ -207,36 +211,49 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
     pending[s] = false;
   };
 
-  int slot = 0;
+  // A ring of kPipe slots: `head` is filled next, the oldest submit in flight is `inFlight` behind it.  Results are
+  // reported in submit order (drain always takes the oldest), as a single reference thread prints them.
+  int head = 0, inFlight = 0;
   bool more = true;
-  while (more || pending[0] || pending[1]) {
-    if (pending[slot]) drain(slot);
+  auto oldest = [&] { return (head + kPipe - inFlight) % kPipe; };
+  while (more || inFlight) {
+    if (pending[head]) {  // the ring is full: the slot to refill is the oldest one
+      drain(head);
+      inFlight--;
+    }
     uint32_t n = 0;
     if (more) {
       // block for the first message only while nothing is in flight; then take what is queued
-      SampleQueue::MessageType *m = (pending[slot ^ 1]) ? q.TryGetNextSamples() : q.GetNextSamples();
-      if (!m && !pending[slot ^ 1]) more = false;
+      SampleQueue::MessageType *m = inFlight ? q.TryGetNextSamples() : q.GetNextSamples();
+      if (!m && !inFlight) more = false;
       while (m) {
-        memcpy(stage[slot] + (size_t)n * bufBytes, m->GetRawData(), bufBytes);
+        memcpy(stage[head] + (size_t)n * bufBytes, m->GetRawData(), bufBytes);
         fc[n] = m->GetHeader().m_frequency;
         seq[n] = m->GetHeader().m_sequenceId;
-        inflight[slot].push_back(m);
+        inflight[head].push_back(m);
         n++;
         if (n >= d.max_batch) break;
         m = q.TryGetNextSamples();
       }
     }
     if (n) {
-      if (Ok(scn_submit(plan, slot, n, fc.data(), seq.data()), "scn_submit")) {
-        pending[slot] = true;
+      if (Ok(scn_submit(plan, head, n, fc.data(), seq.data()), "scn_submit")) {
+        pending[head] = true;
+        inFlight++;
+        head = (head + 1) % kPipe;
       } else {  // the GPU path is gone: hand everything back and stop consuming
-        for (SampleQueue::MessageType *m : inflight[slot]) q.MessageProcessed(m);
-        inflight[slot].clear();
-        if (pending[slot ^ 1]) drain(slot ^ 1);
+        for (SampleQueue::MessageType *m : inflight[head]) q.MessageProcessed(m);
+        inflight[head].clear();
+        while (inFlight) {
+          drain(oldest());
+          inFlight--;
+        }
         return abandon(plan);
       }
+    } else if (inFlight) {  // nothing queued right now: report the oldest batch instead of spinning
+      drain(oldest());
+      inFlight--;
     }
-    slot ^= 1;
   }
   // Shutdown writing gracefully (process.cpp:311-313).
   UpdateEndSequenceId(lastSequenceId);

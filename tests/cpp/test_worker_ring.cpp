@@ -1,0 +1,242 @@
+// test_worker_ring.cpp -- CPU test of ProcessSamples::ThreadWorker's slot ring (scanner_amd/host/process.cpp) against a FAKE of
+// the C-ABI calls it makes: no GPU, no DSP.  The fake plan checks the protocol the real one relies on -- a slot is submitted
+// only when it is free, collected only when it is pending, and submits are collected OLDEST FIRST -- and answers each
+// buffer with a fixed number of records; the test reads the "freq %lu power_db %f" lines ProcessSamples printed and holds
+// them to the order the batches were submitted in (what a single reference thread prints, process.cpp:46-61).
+// The definitions here take precedence over libscanner_hip's (executable before shared libraries); what is not faked
+// (scn_frequency_table, ...) still comes from the library.  Built with -fsanitize=thread / address by tests/test_host_cpp.py.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/scanner_hip.h"
+#include "process.h"
+#include "syntheticSource.h"
+
+namespace {
+struct FakeSlot {
+  std::vector<unsigned char> stage;
+  bool pending = false;
+  uint64_t ticket = 0;
+  std::vector<double> fc;
+  std::vector<uint64_t> seq;
+  std::vector<scn_hit> list;  // the collected submit's records (scn_collect_more reads it)
+};
+struct FakePlan {
+  scn_plan_desc d;
+  size_t bufBytes = 0;
+  FakeSlot slot[SCN_NUM_SLOTS];
+};
+
+std::mutex g_m;                        // one consumer thread per test run; the lock is for the sanitizers' peace
+std::vector<std::string> g_violations;
+std::vector<uint64_t> g_expected;      // freq_hz of every record, in the order the reference would print them
+uint64_t g_tickets = 0, g_collected = 0;
+uint32_t g_hitsPerBuffer = 2;
+int g_failSubmitAt = -1;               // fail the k-th submit (1-based); -1: never
+int g_collectSleepUs = 0;              // "GPU time" a collect waits for
+int g_submits = 0, g_maxInFlight = 0, g_inFlight = 0;
+thread_local std::string g_err;
+
+void violation(const std::string &s) {
+  std::lock_guard<std::mutex> g(g_m);
+  g_violations.push_back(s);
+}
+FakePlan *P(scn_plan *p) { return reinterpret_cast<FakePlan *>(p); }
+const FakePlan *P(const scn_plan *p) { return reinterpret_cast<const FakePlan *>(p); }
+}  // namespace
+
+extern "C" {
+const char *scn_error_name(int s) { return s == SCN_OK ? "SCN_OK" : "SCN_E_FAKE"; }
+const char *scn_last_error(void) { return g_err.c_str(); }
+int scn_device_count(int *count) {
+  *count = 1;
+  return SCN_OK;
+}
+int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
+  FakePlan *p = new FakePlan;
+  p->d = *desc;
+  const size_t per = desc->sample_kind == SCN_KIND_FLOAT_COMPLEX ? 8 : desc->sample_kind == SCN_KIND_BYTE_COMPLEX ? 2 : 4;
+  p->bufBytes = per * desc->n;
+  *out = reinterpret_cast<scn_plan *>(p);
+  return SCN_OK;
+}
+int scn_plan_destroy(scn_plan *plan) {
+  FakePlan *p = P(plan);
+  for (int s = 0; s < SCN_NUM_SLOTS; s++)
+    if (p->slot[s].pending) violation("plan destroyed with slot " + std::to_string(s) + " still pending");
+  delete p;
+  return SCN_OK;
+}
+int scn_buffer_bytes(const scn_plan *plan, size_t *bytes) {
+  *bytes = P(plan)->bufBytes;
+  return SCN_OK;
+}
+int scn_host_buffer(scn_plan *plan, int slot, void **ptr, size_t *bytes) {
+  FakePlan *p = P(plan);
+  FakeSlot &s = p->slot[slot];
+  if (s.stage.empty()) s.stage.resize(p->bufBytes * p->d.max_batch);
+  *ptr = s.stage.data();
+  *bytes = s.stage.size();
+  return SCN_OK;
+}
+int scn_submit(scn_plan *plan, int slot, uint32_t n, const double *fc, const uint64_t *seq) {
+  FakePlan *p = P(plan);
+  if (slot < 0 || slot >= SCN_NUM_SLOTS) return SCN_E_INVALID;
+  FakeSlot &s = p->slot[slot];
+  std::lock_guard<std::mutex> g(g_m);
+  g_submits++;
+  if (g_submits == g_failSubmitAt) {
+    g_err = "injected failure";
+    return SCN_E_HIP;
+  }
+  if (s.pending) g_violations.push_back("submit on slot " + std::to_string(slot) + " which is still pending");
+  if (n == 0 || n > p->d.max_batch) g_violations.push_back("submit of " + std::to_string(n) + " buffers");
+  s.pending = true;
+  s.ticket = ++g_tickets;
+  s.fc.assign(fc, fc + n);
+  s.seq.assign(seq, seq + n);
+  g_inFlight++;
+  if (g_inFlight > g_maxInFlight) g_maxInFlight = g_inFlight;
+  for (uint32_t b = 0; b < n; b++)
+    for (uint32_t h = 0; h < g_hitsPerBuffer; h++) g_expected.push_back((uint64_t)fc[b] + h);
+  return SCN_OK;
+}
+int scn_collect(scn_plan *plan, int slot, float *, scn_hit *hits, uint32_t cap, uint32_t *n_hits, uint8_t *trig) {
+  FakePlan *p = P(plan);
+  FakeSlot &s = p->slot[slot];
+  if (g_collectSleepUs) std::this_thread::sleep_for(std::chrono::microseconds(g_collectSleepUs));
+  std::lock_guard<std::mutex> g(g_m);
+  if (!s.pending) {
+    g_violations.push_back("collect on slot " + std::to_string(slot) + " which is not pending");
+    return SCN_E_STATE;
+  }
+  if (s.ticket != g_collected + 1)
+    g_violations.push_back("collect out of order: ticket " + std::to_string(s.ticket) + " after " + std::to_string(g_collected));
+  g_collected = s.ticket;
+  s.pending = false;
+  g_inFlight--;
+  s.list.clear();
+  for (size_t b = 0; b < s.seq.size(); b++) {
+    if (trig) trig[b] = 0;
+    for (uint32_t h = 0; h < g_hitsPerBuffer; h++) {
+      scn_hit r;
+      r.seq_id = s.seq[b];
+      r.i = h;
+      r.power_db = 11.0f;
+      r.freq_hz = (uint64_t)s.fc[b] + h;
+      s.list.push_back(r);
+    }
+  }
+  *n_hits = (uint32_t)s.list.size();
+  const uint32_t c = *n_hits < cap ? *n_hits : cap;
+  if (hits) memcpy(hits, s.list.data(), sizeof(scn_hit) * c);
+  return (hits && c < *n_hits) ? SCN_E_TRUNCATED : SCN_OK;
+}
+int scn_collect_more(scn_plan *plan, int slot, uint32_t first, scn_hit *hits, uint32_t cap, uint32_t *n_written) {
+  FakeSlot &s = P(plan)->slot[slot];
+  std::lock_guard<std::mutex> g(g_m);
+  if (s.pending) g_violations.push_back("collect_more on a pending slot");
+  *n_written = 0;
+  if (first >= s.list.size()) return SCN_OK;
+  const uint32_t c = (uint32_t)std::min<size_t>(cap, s.list.size() - first);
+  memcpy(hits, s.list.data() + first, sizeof(scn_hit) * c);
+  *n_written = c;
+  return SCN_OK;
+}
+}  // extern "C"
+
+namespace {
+int g_failures = 0;
+#define CHECK(c)                                                  \
+  do {                                                            \
+    if (!(c)) {                                                   \
+      fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); \
+      g_failures++;                                               \
+    }                                                             \
+  } while (0)
+
+// one run: a synthetic producer, one consumer thread on the fake plan; returns the freq values ProcessSamples printed
+std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t sweeps, bool &ok) {
+  g_violations.clear();
+  g_expected.clear();
+  g_tickets = g_collected = 0;
+  g_submits = g_maxInFlight = g_inFlight = 0;
+  char path[] = "/tmp/scn_ring_XXXXXX";
+  const int fd = mkstemp(path);
+  fflush(stdout);
+  FILE *keep = stdout;
+  stdout = fdopen(fd, "w");
+  {
+    SyntheticSource source(8000000, n, 88e6, 130e6, SampleQueue::ShortComplex, 5, 0.02);
+    ProcessSamples process(n, 8000000, 12, 10.0f, gr::fft::window::WIN_BLACKMAN_HARRIS, ProcessSamples::FrequencyDomain, 1);
+    process.SetMaxBatch(batch);
+    SampleQueue q(SampleQueue::ShortComplex, 12, n, depth, false, false);
+    ok = source.Start() && source.StartStreaming(sweeps + 1, q);
+    if (ok) ok = process.StartProcessing(q);
+    source.StopStreaming();
+  }
+  fflush(stdout);
+  fclose(stdout);
+  stdout = keep;
+  std::vector<uint64_t> got;
+  FILE *f = fopen(path, "r");
+  char line[256];
+  while (f && fgets(line, sizeof(line), f)) {
+    unsigned long v;
+    if (sscanf(line, "freq %lu power_db", &v) == 1) got.push_back(v);
+  }
+  if (f) fclose(f);
+  remove(path);
+  return got;
+}
+}  // namespace
+
+int main() {
+  bool ok = false;
+  // 1. a fast producer, a "GPU" that takes its time: the ring fills up (three submits in flight) and is drained oldest first
+  g_hitsPerBuffer = 2;
+  g_failSubmitAt = -1;
+  g_collectSleepUs = 300;
+  std::vector<uint64_t> got = run(256, 4, 64, 6, ok);
+  CHECK(ok);
+  for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
+  CHECK(g_violations.empty());
+  CHECK(got.size() > 50 && got == g_expected);
+  CHECK(g_maxInFlight == 3);  // kPipe of process.cpp
+  const int fastSubmits = g_submits;
+
+  // 2. a slow producer (long buffers), an instant "GPU": the queue runs empty between batches, every batch is reported at once
+  g_collectSleepUs = 0;
+  got = run(16384, 4, 16, 2, ok);
+  CHECK(ok && g_violations.empty());
+  CHECK(got.size() > 10 && got == g_expected);
+
+  // 3. more records than the consumer's window: the rest comes through scn_collect_more, nothing lost, order kept
+  g_hitsPerBuffer = 200;  // window = max_batch * 64
+  g_collectSleepUs = 100;
+  got = run(256, 3, 32, 3, ok);
+  CHECK(ok && g_violations.empty());
+  CHECK(got == g_expected && got.size() % 200 == 0);
+
+  // 4. the GPU path dies in the middle: every submit in flight is still reported (oldest first), every message goes back to
+  //    the queue (the producer is not left blocked), StartProcessing says it failed
+  g_hitsPerBuffer = 2;
+  g_collectSleepUs = 300;
+  g_failSubmitAt = fastSubmits / 2;
+  got = run(256, 4, 64, 6, ok);
+  CHECK(!ok);
+  for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
+  CHECK(g_violations.empty());
+  CHECK(!got.empty() && got.size() == g_expected.size() && got == g_expected);  // what was submitted was reported, in order
+
+  if (g_failures) return 1;
+  printf("worker ring tests ok\n");
+  return 0;
+}

@@ -74,6 +74,30 @@ def test_host_classes_under_sanitizers(host_build, tmp_path, san):
     assert out.returncode == 0 and "host cpu tests ok" in out.stdout, out.stderr[-3000:]
 
 
+@pytest.mark.parametrize("san", ["", "thread", "address,undefined"])
+def test_worker_slot_ring_against_a_fake_plan(host_build, tmp_path, san):
+    """ProcessSamples::ThreadWorker keeps a ring of three submit slots in flight (process.cpp).  Against a fake of the C-ABI
+    calls it makes (tests/cpp/test_worker_ring.cpp: protocol checks instead of DSP) on CPU: slots are only submitted when free,
+    collected oldest first, every record is printed in submit order -- with the ring full, with the queue running empty, with
+    more records than one collect window, and when a submit fails half way.  Plain, and under TSan / ASan+UBSan."""
+    exe = tmp_path / "test_worker_ring"
+    srcs = [os.path.join(HOST, f) for f in ("frequencyTable.cpp", "messageQueue.cpp", "signalSource.cpp", "syntheticSource.cpp",
+                                            "processInterface.cpp", "sampleBuffer.cpp", "process.cpp")]
+    cmd = ["g++", "-std=gnu++11", "-O1", "-g", "-fno-omit-frame-pointer", "-pthread", "-I", HOST] + (
+        [f"-fsanitize={san}"] if san else []) + [os.path.join(ROOT, "tests", "cpp", "test_worker_ring.cpp")] + srcs + [
+        "-o", str(exe), "-L" + os.path.join(ROOT, "scanner_amd"), "-lscanner_hip", "-Wl,-rpath," + os.path.join(ROOT, "scanner_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and san and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[:200])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=env)
+    if out.returncode != 0 and "FATAL: ThreadSanitizer" in out.stderr and "unexpected memory mapping" in out.stderr:
+        pytest.skip("TSan cannot run under this kernel's address-space layout")
+    assert out.returncode == 0, out.stderr[-3000:] + out.stdout[-500:]
+    assert "worker ring tests ok" in out.stdout
+
+
 def test_reference_call_sites_compile(host_build, tmp_path):
     """The wiring of scan.cpp:211-239 written against the reference's names compiles unchanged."""
     src = tmp_path / "wiring.cpp"

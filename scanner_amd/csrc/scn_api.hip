@@ -107,20 +107,15 @@ struct Slot {
 
 }  // namespace
 
-// Where the ordered hit list of a submit is built (experiment knob SCN_EXP_COMPACT, read at plan creation):
-//   0 (default) automatic: behind the kernel on the list stream, overlapping the next launch (plus a DMA of the
-//               expected number of records to pinned host memory), IF the plan's previous collect asked for records;
-//               otherwise on demand, when a collect call asks -- callers that only want counts / trigger flags pay nothing
-//   1           always behind the kernel, on the compute stream itself (in order, before the next launch)
-//   2           always on demand
-//   3           always behind the kernel on the list stream
-enum { SCN_COMPACT_AUTO = 0, SCN_COMPACT_INLINE = 1, SCN_COMPACT_LAZY = 2, SCN_COMPACT_SIDE = 3 };
-
+// Where the ordered hit list of a submit is built: behind the kernel on the list stream, overlapping the next launch (plus a
+// DMA of the expected number of records to pinned host memory), IF the plan's previous collect asked for records; otherwise
+// on demand, when a collect call asks -- callers that only want counts / trigger flags pay nothing.  (Measured alternatives,
+// profiles/r02_compact_modes5.txt: always in order on the compute stream costs 60 us per step; always on demand puts the
+// list on the caller's critical path.)
 struct scn_plan {
   scn_plan_desc d;
   int num_cus = 0;
-  int compact_mode = SCN_COMPACT_AUTO;
-  bool records_wanted = false;  // did the last scn_collect ask for hit records? (the automatic mode's hint)
+  bool records_wanted = false;  // did the last scn_collect ask for hit records? (decides where the next list is built)
   uint32_t predict = 0;         // records the next list is expected to hold (last total + 25 %): the prefetch size
   // How the per-buffer counts reach the host.  false: a 4*n_buffers-byte copy on the d2h stream behind the kernel -- on
   // this ROCm a blit KERNEL, which runs beside the next launch when that leaves it room (up to 4096 points: yes, ~6 us)
@@ -135,8 +130,6 @@ struct scn_plan {
   double *d_twiddle64 = nullptr;     // [fft_m][2]: W_m^k in double (the staged path applies its tables in double)
   double *d_chirp = nullptr;         // Bluestein: [n][2], w[i] = exp(-i pi i^2 / n)
   double *d_bfilter = nullptr;       // Bluestein: [fft_m][2], FFT_m of the chirp filter / m
-  int stop_event_in_packet = -1;  // -1: by launch size (see submit_common); 0 / 1: experiment knob SCN_EXP_STOP_EVENT
-  int fft_cus = 0;  // CUs the FFT launch is sized for (num_cus unless SCN_EXP_RESERVE_CUS leaves some to the side stream)
   hipStream_t stream = nullptr;      // compute
   hipStream_t h2d_stream = nullptr;  // staging copies of scn_submit (overlap the other slot's kernel)
   hipStream_t d2h_stream = nullptr;  // per-buffer hit counts back to the host
@@ -275,7 +268,7 @@ ScnCompactArgs compact_args(const scn_plan *p, const Slot &s, uint32_t first, ui
 
 // the stream the slot's ordered list is built and fetched on
 hipStream_t list_stream_of(const scn_plan *p, const Slot &s) {
-  return (s.own_stream || p->compact_mode == SCN_COMPACT_INLINE) ? s.stream : p->list_stream;
+  return s.own_stream ? s.stream : p->list_stream;
 }
 
 // where work on an already complete list goes (top-up copies, scn_collect_more's windows): a stream with nothing queued
@@ -386,8 +379,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   // the list stream, beside the next launch).  With overlapped slots both follow the kernel on the slot's own stream --
   // its next kernel is two submits away, and fewer streams keep both compute streams on hardware queues of their own
   // (HIP maps streams onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one).
-  const bool eager = hits && nb && (p->compact_mode == SCN_COMPACT_INLINE || p->compact_mode == SCN_COMPACT_SIDE ||
-                                    (p->compact_mode == SCN_COMPACT_AUTO && p->records_wanted));
+  const bool eager = hits && nb && p->records_wanted;
   hipStream_t cnt = (s.own_stream || p->direct_counts) ? s.stream : p->d2h_stream;
   hipStream_t lst = list_stream_of(p, s);
   const bool fork_list = eager && lst != s.stream;
@@ -399,8 +391,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   // 16.8 M samples 44 -> 46..58 and 8.4 M 31 -> 29..56 (erratic: short kernels that carry an event get serialised).
   const bool after_is_done = cnt == s.stream && !s.own_stream;  // direct counts on the plan's stream
   hipEvent_t after = (!nb || s.own_stream) ? nullptr : !hits ? s.done : after_is_done ? s.done : s.kernel_done;
-  const bool in_packet = after && !p->generic && !p->big &&
-                         (p->stop_event_in_packet < 0 ? (uint64_t)nb * n >= (1u << 25) : p->stop_event_in_packet != 0);
+  const bool in_packet = after && !p->generic && !p->big && (uint64_t)nb * n >= (1u << 25);
   if (p->big) {
     if (nb && !s.d_gen_work[0]) SCN_HIP(hipMalloc(&s.d_gen_work[0], sizeof(float) * 2 * (size_t)n * p->d.max_batch));
     ScnBigArgs ba;
@@ -451,7 +442,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     SCN_HIP(scn_launch_generic((int)p->d.sample_kind, p->d.correct_dc != 0, hits, ga, p->num_cus, s.stream));
   } else {
     // (a hits-only plan handed a caller's spectrum destination runs the full kernel)
-    SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, d_power != nullptr, a, p->fft_cus, s.stream, in_packet ? after : nullptr));
+    SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, d_power != nullptr, a, p->num_cus, s.stream, in_packet ? after : nullptr));
   }
   if (scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
@@ -599,14 +590,9 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   }
     SCN_TRY(hipGetDeviceProperties(&prop, d.device_id));
     p->num_cus = prop.multiProcessorCount;
-    p->fft_cus = p->num_cus;
-    if (const char *e = getenv("SCN_EXP_COMPACT")) p->compact_mode = atoi(e);
-    if (const char *e = getenv("SCN_EXP_RESERVE_CUS")) p->fft_cus = std::max(1, p->num_cus - atoi(e));
     p->big = d.mode == SCN_MODE_FREQUENCY_DOMAIN && scn_big_size_supported(d.n);
     p->generic = d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !p->big;
     p->direct_counts = d.n >= 8192 && !p->generic && !p->big;  // (the fused kernels from 8192 points up store the counts to pinned memory themselves)
-    if (const char *e = getenv("SCN_EXP_DIRECT_COUNTS")) p->direct_counts = atoi(e) != 0;
-    if (const char *e = getenv("SCN_EXP_STOP_EVENT")) p->stop_event_in_packet = atoi(e) != 0 ? 1 : 0;
     SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->h2d_stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->d2h_stream, hipStreamNonBlocking));
@@ -1091,8 +1077,6 @@ struct scn_welch {
   float *d_partial = nullptr;  // [parts][max_psd][n] partial power sums (row kernel -> combine kernel); shared by the slots
                                // through stream order on the device path, per-slot copies on the pinned path
   uint32_t parts = 1;
-  hipStream_t exp_stream = nullptr;  // SCN_EXP_WELCH_CHUNK: the row kernels' stream and its events
-  hipEvent_t exp_ev[3] = {nullptr, nullptr, nullptr};
   WelchSlot slot[SCN_NUM_SLOTS];
 };
 
@@ -1116,32 +1100,6 @@ int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd, 
   a.k = w->d.segments_per_psd;
   a.n_psd = n_psd;
   a.inv_k = 1.0f / (float)w->d.segments_per_psd;
-  // EXPERIMENT (SCN_EXP_WELCH_CHUNK = c, profiles/r03_experiments.md): the submit in chunks of c PSDs, chunk k's row kernel on a
-  // second stream beside chunk k+1's column kernel, so that a chunk's slice of the work buffer (c * K * 512 KiB: 34 MB for c = 4)
-  // is read back while it can still sit in the 256 MB Infinity Cache instead of after the whole 268 MB buffer has been written.
-  static const int chunk = getenv("SCN_EXP_WELCH_CHUNK") ? atoi(getenv("SCN_EXP_WELCH_CHUNK")) : 0;
-  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(stream, &capturing);
-  if (chunk > 0 && (uint32_t)chunk < n_psd && w->parts == 1 && capturing == hipStreamCaptureStatusNone) {
-    if (!w->exp_stream) {
-      SCN_HIP(hipStreamCreateWithFlags(&w->exp_stream, hipStreamNonBlocking));
-      for (auto &e : w->exp_ev) SCN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    const uint32_t K = w->d.segments_per_psd;
-    uint32_t k = 0;
-    for (uint32_t p0 = 0; p0 < n_psd; p0 += (uint32_t)chunk, k++) {
-      ScnWelchArgs c = a;
-      c.n_psd = std::min<uint32_t>((uint32_t)chunk, n_psd - p0);
-      c.n_segments = c.n_psd * K;
-      c.in = static_cast<const char *>(d_in) + (size_t)p0 * K * w->hop * 8u;
-      c.work = static_cast<char *>(d_work) + (size_t)p0 * K * w->d.n * 8u;
-      c.psd_db = d_psd + (size_t)p0 * w->d.n;
-      SCN_HIP(scn_launch_welch_split(c, w->num_cus, stream, w->exp_stream, w->exp_ev[k & 1]));
-    }
-    SCN_HIP(hipEventRecord(w->exp_ev[2], w->exp_stream));
-    SCN_HIP(hipStreamWaitEvent(stream, w->exp_ev[2], 0));
-    return SCN_OK;
-  }
   SCN_HIP(scn_launch_welch(a, w->num_cus, stream));
   return SCN_OK;
 }
@@ -1194,7 +1152,6 @@ int scn_welch_create(const scn_welch_desc *desc, scn_welch **out) {
     // enough row workgroups for one per CU: 16 tiles x max_psd x parts >= CUs, parts <= 4 and <= K (measured, 8 PSDs per
     // submit: 68.5 / 75.9 / 73.7 Gsamples/s with 1 / 2 / 4 parts; from 16 PSDs per submit up the split only costs)
     while (w->parts < 4u && w->parts * 2u <= d.segments_per_psd && 16u * d.max_psd * w->parts < (uint32_t)w->num_cus) w->parts *= 2u;
-    if (const char *env = getenv("SCN_EXP_WELCH_PARTS")) w->parts = std::max(1, std::min(atoi(env), (int)d.segments_per_psd));
     if (w->parts > 1 && (e = hipMalloc(&w->d_partial, sizeof(float) * (size_t)d.n * d.max_psd * w->parts)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(w->d_window, win.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, w->stream)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(w->d_twiddle, tw.data(), sizeof(float) * 2 * d.n, hipMemcpyHostToDevice, w->stream)) != hipSuccess) break;
@@ -1230,12 +1187,6 @@ int scn_welch_destroy(scn_welch *w) {
   if (w->d_twiddle) (void)hipFree(w->d_twiddle);
   if (w->d_work) (void)hipFree(w->d_work);
   if (w->d_partial) (void)hipFree(w->d_partial);
-  if (w->exp_stream) {
-    (void)hipStreamSynchronize(w->exp_stream);
-    (void)hipStreamDestroy(w->exp_stream);
-  }
-  for (auto e : w->exp_ev)
-    if (e) (void)hipEventDestroy(e);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
   return SCN_OK;

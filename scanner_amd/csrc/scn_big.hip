@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows_kernel(ScnBigArgs args) {
     }
     const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
     if (__ballot(pmax > args.p_lo))
-      scn_record_hits<16, false, true, true>(pw, gmax, keepmask, args, reinterpret_cast<int *>(args.per_buffer_hits + b), b, lane,
+      scn_record_hits_device_counter<16>(pw, gmax, keepmask, args, reinterpret_cast<int *>(args.per_buffer_hits + b), b, lane,
                           [&](int q) -> uint32_t { return (k1 + 256u * (lo + 16u * (uint32_t)q)) ^ (BN / 2); });
   }
 }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows32k_kernel(ScnBigArgs args
     }
     const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
     if (__ballot(pmax > args.p_lo))
-      scn_record_hits<16, false, true, true>(pw, gmax, keepmask, args, reinterpret_cast<int *>(args.per_buffer_hits + b), b, lane,
+      scn_record_hits_device_counter<16>(pw, gmax, keepmask, args, reinterpret_cast<int *>(args.per_buffer_hits + b), b, lane,
                                        [&](int o) -> uint32_t { return (k1 + 256u * k2_of(o)) ^ (N / 2); });
   }
 }

@@ -199,109 +199,68 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t x) {
 // each of its four groups of NB / 4 outputs.  Candidates are found in the linear domain against p_lo (a shade below
 // 10^(threshold / 5), scn_hit_prefilter); the decision itself is magnitudes[j] > m_threshold on the dB value -- the map above,
 // a pure function of the power, so spectrum + hits and hits-only plans decide identically and report the float the spectrum
-// holds.  A tone's detections are neighbouring bins, i.e. ONE or two output indices of neighbouring lanes: so the wave
-// tests its four groups, then the outputs of a group that holds a candidate (one compare each, into a scalar mask), and
-// every output index in that mask is evaluated once and takes its slots of the buffer's region at once, with one atomic
-// on the buffer's counter (LDS, or device memory in scn_big.hip) -- no wave-wide reductions, no second pass.  (The first form -- candidate masks for all NB
-// outputs, DPP reductions for the wave's OR and total, one atomic per wave, a register-indexed loop over the hit indices --
-// cost a wave with detections ~1400 cycles: 11 % of a C3 buffer, another 5 % of barrier skew behind it; stamp profiles in
-// profiles/r03_experiments.md.)
-// (`args`: anything with p_lo, threshold, hits, hit_region)
-// IS_DB: `pw` already holds the dB values (the spectrum kernels: they have just stored them); otherwise the powers (hits-only
-// kernels), and the value is formed here by the rule the spectrum kernels of the same family use -- the exact half of the
-// map for the strong maximum of the thread's group of outputs, the product form for every other bin -- or, with PURE, by
-// db_of_power (scn_big.hip, whose spectrum is stored through that).
-// ONE_ATOMIC: the counter is in device memory (scn_big.hip), where a returning atomic costs microseconds, not ~100 cycles:
-// the wave first evaluates all its candidate indices (values written back into `pw`, hit lanes and the count accumulated),
-// takes its slots with ONE atomic and records in a second pass over the indices that had hits.
-#ifndef SCN_EXP_HITCUT
-#define SCN_EXP_HITCUT 0  // experiment: 1 = no record stores, 2 = candidate mask only (profiles/r03_experiments.md section 6)
-#endif
-template <int NB, bool IS_DB, bool PURE = false, bool ONE_ATOMIC = false, typename VEC, typename ARGS, typename BINI>
-__device__ __forceinline__ void scn_record_hits(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count, uint32_t buf,
-                                                uint32_t lane, BINI bin_i) {
+// holds.  (`args`: anything with p_lo, threshold, hits, hit_region.)
+//
+// scn_record_hits_device_counter: the form for a hit counter in DEVICE memory (scn_big.hip: a buffer is spread over many
+// workgroups), where a returning atomic costs microseconds, not ~100 cycles.  A tone's detections are neighbouring bins,
+// i.e. ONE or two output indices of neighbouring lanes: the wave tests its four groups, then the outputs of a group that
+// holds a candidate (one compare each, into a scalar mask), evaluates every output index in that mask once (values written
+// back into `pw`, hit lanes and the count accumulated), takes its slots with ONE atomic and records in a second pass over
+// the indices that had hits.
+template <int NB, typename VEC, typename ARGS, typename BINI>
+__device__ __forceinline__ void scn_record_hits_device_counter(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count,
+                                                               uint32_t buf, uint32_t lane, BINI bin_i) {
   constexpr int GS = NB / 4;
-  // which output indices have a candidate somewhere in the wave: one compare per output of a group that holds one (static
-  // register indexing; the result is a scalar mask -- no per-lane masks, no cross-lane reduction)
-  uint32_t wmc = 0;
+  uint32_t wmc = 0;  // output indices with a candidate somewhere in the wave (a scalar mask: no per-lane masks, no cross-lane reduction)
 #pragma unroll
   for (int g = 0; g < 4; g++) {
     if (__ballot(gmax[g] > args.p_lo)) {
 #pragma unroll
-      for (int o = g * GS; o < (g + 1) * GS; o++) wmc |= __ballot(IS_DB ? pw[o] > args.threshold : pw[o] > args.p_lo) ? (1u << o) : 0u;
+      for (int o = g * GS; o < (g + 1) * GS; o++) wmc |= __ballot(pw[o] > args.p_lo) ? (1u << o) : 0u;
     }
   }
   ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-#if SCN_EXP_HITCUT == 2
-  if (wmc != 0xdeadbeefu) return;
-#endif
-  uint32_t hm = 0, wm2 = 0, total = 0;  // ONE_ATOMIC: this lane's hits, the indices with hits, the wave's count
-  // (one loop over all indices; only the group-maximum rule needs the group's maximum by name -- indexed, it went through
-  // scratch -- and gets one loop per group)
-  constexpr int NL = (!IS_DB && !PURE) ? 4 : 1;
-#pragma unroll
-  for (int g = 0; g < NL; g++) {
-    uint32_t wmg = NL == 1 ? wmc : wmc & (((1u << GS) - 1u) << (g * GS));
-    while (wmg) {  // a tone's main lobe: one or two indices
-      const int o = __builtin_ctz(wmg);  // wave-uniform
-      wmg &= wmg - 1u;
-      const float p = pw[o];
-      float d = p;
-      if constexpr (!IS_DB && PURE) {
-        d = db_fast(p);
-        if (__ballot(p >= SCN_P_EXACT_FROM)) d = p >= SCN_P_EXACT_FROM ? db_exact(p) : d;  // = db_of_power(p)
-      }
-      if constexpr (!IS_DB && !PURE) {
-        d = db_fast(p);
-        if (__ballot(p >= SCN_P_EXACT_FROM)) d = (p >= SCN_P_EXACT_FROM && p == gmax[NL == 4 ? g : 0]) ? db_exact(p) : d;
-      }
-      const bool hit = ((keepmask >> o) & 1u) && d > args.threshold && (IS_DB || p > args.p_lo);  // strict >, process.cpp:54
-      const unsigned long long m = __ballot(hit);
-      if constexpr (ONE_ATOMIC) {
-        pw[o] = d;
-        hm |= hit ? (1u << o) : 0u;
-        wm2 |= m ? (1u << o) : 0u;
-        total += (uint32_t)__popcll(m);
-      } else if (m) {
-        const int first = __builtin_ctzll(m);
-        uint32_t base = 0;
-        if (lane == (uint32_t)first) base = (uint32_t)atomicAdd(count, (int)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-        if (hit) {
-          const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-#if SCN_EXP_HITCUT == 1
-          if (pos == 0xdeadbeefu) region[pos] = ScnDevHit{bin_i(o), d};
-#else
-          if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), d};
-#endif
-        }
-      }
-    }
+  uint32_t hm = 0, wm2 = 0, total = 0;  // this lane's hits, the indices with hits, the wave's count
+  while (wmc) {  // a tone's main lobe: one or two indices
+    const int o = __builtin_ctz(wmc);  // wave-uniform
+    wmc &= wmc - 1u;
+    const float p = pw[o];
+    float d = db_fast(p);
+    if (__ballot(p >= SCN_P_EXACT_FROM)) d = p >= SCN_P_EXACT_FROM ? db_exact(p) : d;  // = db_of_power(p)
+    const bool hit = ((keepmask >> o) & 1u) && d > args.threshold && p > args.p_lo;  // strict >, process.cpp:54
+    const unsigned long long m = __ballot(hit);
+    pw[o] = d;
+    hm |= hit ? (1u << o) : 0u;
+    wm2 |= m ? (1u << o) : 0u;
+    total += (uint32_t)__popcll(m);
   }
-  if constexpr (ONE_ATOMIC) {
-    if (!total) return;
-    uint32_t base = 0;
-    if (lane == 0) base = (uint32_t)atomicAdd(count, (int)total);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    while (wm2) {
-      const int o = __builtin_ctz(wm2);  // wave-uniform
-      wm2 &= wm2 - 1u;
-      const bool hit = (hm >> o) & 1u;
-      const unsigned long long m = __ballot(hit);
-      if (hit) {
-        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), pw[o]};
-      }
-      base += (uint32_t)__popcll(m);
+  if (!total) return;
+  uint32_t base = 0;
+  if (lane == 0) base = (uint32_t)atomicAdd(count, (int)total);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  while (wm2) {
+    const int o = __builtin_ctz(wm2);  // wave-uniform
+    wm2 &= wm2 - 1u;
+    const bool hit = (hm >> o) & 1u;
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (pos < args.hit_region) region[pos] = ScnDevHit{bin_i(o), pw[o]};
     }
+    base += (uint32_t)__popcll(m);
   }
 }
 
-// The per-lane form of the above (same decisions, same records, other order of work): every lane collects ITS candidate
-// outputs in a bit mask with straight-line VALU work (no wave-wide test per output index), then the wave takes one candidate
-// per lane per trip -- the value comes out of the registers through a select tree, not a register-indexed move -- until no lane
-// has one left.  Trips = the largest number of candidates any one lane holds (a tone's main lobe sits in neighbouring lanes of
-// one output index: 1; noise hits at the bench's threshold: 2..3) instead of the number of output indices that hold one.
+// scn_record_hits_lanes: the form for a counter in LDS (the fused kernels: one workgroup per buffer).  Every lane collects ITS
+// candidate outputs in a bit mask with straight-line VALU work (no wave-wide test per output index), then the wave takes one
+// candidate per lane per trip -- the value comes out of the registers through a select tree, not a register-indexed move --
+// until no lane has one left.  Trips = the largest number of candidates any one lane holds (a tone's main lobe sits in
+// neighbouring lanes of one output index: 1; noise hits at the bench's threshold: 2..3).  (The form it replaced walked the
+// output indices that held a candidate anywhere in the wave -- a dozen of 32 on a hit-dense 16384-point launch: 101 us
+// against 86; profiles/r03_experiments.md section 6.)
+// IS_DB: `pw` already holds the dB values (the 16384-point spectrum kernel); otherwise the powers, and the value is formed
+// here: by db_of_power (PURE), or by the 16384-point kernel's rule -- the exact half of the map for the strong maximum of
+// the thread's group of outputs only.
 // (v_cndmask_b32 spelled out: written as C++ selects, hipcc recognises "element o of a vector" and lowers THAT as a chain of
 // 32 compares + selects, several times over -- 1400 instructions per trip)
 __device__ __forceinline__ float scn_cndmask(float a, float b, unsigned long long m) {  // lane in m ? b : a
@@ -324,9 +283,6 @@ __device__ __forceinline__ float scn_select_output(const VEC &pw, uint32_t o) { 
   return t[0];
 }
 
-#ifndef SCN_HITS_SCAN
-#define SCN_HITS_SCAN 1
-#endif
 // HAVE_MASK: the caller collected the candidate bits (`cand`, before the keep mask) while it produced the outputs.
 template <int NB, bool IS_DB, bool PURE = false, bool HAVE_MASK = false, typename VEC, typename ARGS, typename BINI>
 __device__ __forceinline__ void scn_record_hits_lanes(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count, uint32_t buf,
@@ -344,10 +300,7 @@ __device__ __forceinline__ void scn_record_hits_lanes(VEC &pw, const float (&gma
   }
   hm &= keepmask;
   ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-#if SCN_EXP_HITCUT == 2
-  if (hm != 0xdeadbeefu) return;
-#endif
-  if constexpr (IS_DB && SCN_HITS_SCAN) {
+  if constexpr (IS_DB) {
     // the outputs ARE the dB values: every candidate bit is a hit, the wave's count is known before the first record -- one
     // prefix sum over the lanes' counts, ONE counter atomic, then the trips carry no wave-wide step at all
     const uint32_t cnt = (uint32_t)__builtin_popcount(hm);

@@ -53,13 +53,10 @@ struct ScnFftArgs {
 };
 // which wire formats pull their buffers from the queue (the compute-bound integer ones; the float path is
 // memory-bound and measurably better off with the static assignment)
-#ifndef SCN_DYNAMIC_WORK
-#define SCN_DYNAMIC_WORK 1
-#endif
 // ... and only from 4096 points up: a launch of the same sample count makes 4x / 2x as many dequeues at 1024 / 2048
 // points, and the queue heads then become the bottleneck (1024-pt int16: 64.7 us static, 90.7 us with the queue)
 static constexpr bool scn_uses_queue(int kind, uint32_t n) {
-  return SCN_DYNAMIC_WORK != 0 && kind != SCN_K_FLOAT_COMPLEX && n >= 4096 && n <= 8192;  // (16384: static, one workgroup per CU)
+  return kind != SCN_K_FLOAT_COMPLEX && n >= 4096 && n <= 8192;  // (16384: static, one workgroup per CU)
 }
 // number of buffers b < n_buffers with b % 8 == shard
 static inline uint32_t scn_work_shard_count(uint32_t n_buffers, uint32_t shard) {
@@ -89,7 +86,6 @@ struct ScnWelchArgs {
   float inv_k;
 };
 hipError_t scn_launch_welch(const ScnWelchArgs &args, int num_cus, hipStream_t stream);
-hipError_t scn_launch_welch_split(const ScnWelchArgs &args, int num_cus, hipStream_t s_cols, hipStream_t s_rows, hipEvent_t ev);  // experiment
 
 // Ordered hit list (scn_hits.hip): exclusive scan of the per-buffer counts, then one wave per buffer with hits ranks
 // its records by bin (a bitmap in LDS) and writes the completed scn_hit records [first, first + out_cap) of the

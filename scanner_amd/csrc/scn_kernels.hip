@@ -26,79 +26,22 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "scn_kernels.h"
-
-
 #include "scn_device.h"
-// The hit path of the narrow / 8192 / 16384-point kernels: the per-lane form (scn_record_hits_lanes, product) or, with 0, the
-// per-output-index form (scn_record_hits; with SCN_ONE_ATOMIC_* its two-pass variant) -- profiles/r03_experiments.md section 6
-#ifndef SCN_HITS_LANES_N
-#define SCN_HITS_LANES_N 1
-#endif
-#ifndef SCN_HITS_LANES_W
-#define SCN_HITS_LANES_W 1
-#endif
-#ifndef SCN_HITS_LANES_S
-#define SCN_HITS_LANES_S 1
-#endif
-#ifndef SCN_HITS_LANES_16K
-#define SCN_HITS_LANES_16K 1
-#endif
-#ifndef SCN_HITS_MASK_16K
-#define SCN_HITS_MASK_16K 1  // the 16384-point HITS-ONLY kernel collects the candidate bits while it produces the powers (with the
-                             // spectrum's stores in the same loop that cost 1-3 us instead of saving 3: profiles/r03_experiments.md section 6)
-#endif
-#ifndef SCN_ONE_ATOMIC_N
-#define SCN_ONE_ATOMIC_N false
-#endif
-#ifndef SCN_ONE_ATOMIC_W
-#define SCN_ONE_ATOMIC_W false
-#endif
-#ifndef SCN_ONE_ATOMIC_16K
-#define SCN_ONE_ATOMIC_16K false
-#endif
-
+#include "scn_kernels.h"
 
 namespace {
 
 // ---- global memory access through buffer descriptors ---------------------------------
 // A raw buffer resource (SGPR descriptor, wave-uniform base) + one per-lane VGPR offset
 // + scalar/immediate offsets: the 16 strided accesses of a thread cost no address VGPRs.
-// Timing-only experiments (never in the product build): a zero-record descriptor makes the range
-// check drop every access through it while the instruction stream is unchanged.
-#ifndef SCN_EXP_NO_LOADS
-#define SCN_EXP_NO_LOADS 0
-#endif
-#ifndef SCN_EXP_NO_STORES
-#define SCN_EXP_NO_STORES 0
-#endif
-
-// Tunables (compile-time; scripts/build_variants.py builds one library per setting).
+//
 // Cache-policy immediates of the buffer instructions on gfx950: bit0 = sc0, bit1 = nt, bit4 = sc1.
 // Both streams are touched exactly once, so both are non-temporal: measured with inputs AND outputs
 // rotated over 1.5 GiB (nothing can live in the 256 MiB Infinity Cache), a no-compute skeleton
 // of this kernel's traffic moves 5.66 TB/s with the default policy and 6.40 TB/s with nt on both
 // (scripts/membw.hip); the FFT kernel itself gains 4-5 %.
-#ifndef SCN_AUX_LD
-#define SCN_AUX_LD 2
-#endif
-#ifndef SCN_AUX_ST
-#define SCN_AUX_ST 2
-#endif
-#ifndef SCN_PREFETCH
-#define SCN_PREFETCH 1 // fetch the next buffer's raw samples into registers during the FFT passes: reads are
-                       // latency/MLP-bound otherwise (~32 KiB in flight per CU).  Costs 32 VGPRs for float
-                       // input (-> 3 waves per SIMD), 16 for the integer formats; worth 3-4 % on C2.
-                       // (A "touch-ahead" of the next buffer into L2/Infinity Cache was measured too: -5 %.)
-#endif
-#ifndef SCN_PF32_INT
-#define SCN_PF32_INT 0  // experiment: register prefetch in the 512-thread 8192-point form for the 4-byte and 2-byte formats (16 registers;
-                       // 13 VGPRs spill at the 128 of four waves per SIMD).  C3 shape, us per step: wide kernel 65.8, 512-thread form 73.9,
-                       // with this prefetch 77.8 (scripts/narrow8k_check.sh)
-#endif
-#ifndef SCN_WAVES_PER_SIMD_PF
-#define SCN_WAVES_PER_SIMD_PF 3  // VGPR budget 168 with the prefetch registers
-#endif
+constexpr int SCN_AUX_LD = 2;
+constexpr int SCN_AUX_ST = 2;
 
 template <int KIND>
 struct RawLoader;
@@ -210,73 +153,50 @@ struct RawLoader<SCN_K_SHORT> {
 }  // namespace
 
 // ------------------------------------------------------------------------------------
-// Fused kernel for N = 256*M points, M in {4, 8, 16, 32, 64} (N = 1024 / 2048 / 4096 / 8192 / 16384; the product uses the
-// wide kernel further down for 8192).
+// Fused kernel for N = 256*M points, M in {4, 8, 16} (N = 1024 / 2048 / 4096).
 // One workgroup of T = 16*M threads per buffer, persistent over buffers, 16 points per thread.
 //
 //   n = T*a + M*b + c          k = p + 16q + 256r         a,b,p,q in [0,16), c,r in [0,M)
 //   pass 1  thread t = M*b + c:  16-pt DFT over a of x[T*a + t]*w[T*a + t] -> *W_N^{t p} -> LDS row p
 //   pass 2  thread (p, c):       16-pt DFT over b                          -> *W_{16M}^{c q} -> LDS
-//   pass 3  M-pt DFT over c for each (p,q):
-//       M <= 16: thread t does the 16/M butterflies kl = t + T*u, outputs k = kl + 256 r
-//       M == 32: two lanes (l, l+32) share a butterfly: each does the 16-pt DFT over c = 2c'+e
-//                of its parity e, the odd one applies W_32^{r'}, one cross-half exchange
-//                (radix 2) finishes it; lane half e outputs r = r' + 16e
-//       M == 64: FOUR lanes (l, l+16, l+32, l+48) share a butterfly: lane row e does the 16-pt DFT over
-//                c = 4c'+e, applies W_64^{e r'}, and a radix-4 step made of two lane exchanges
-//                (v_permlane32_swap across the halves, v_permlane16_swap across the rows of a half)
-//                leaves output r = r' + 16 s in the lane with s = 2 (e & 1) + (e >> 1)
+//   pass 3  M-pt DFT over c for each (p,q): thread t does the 16/M butterflies kl = t + T*u, outputs k = kl + 256 r
 //
 // LDS (complex = 8 B slots, every address = per-thread base + immediate, all four access patterns
 // bank-conflict-free -- checked with SQ_LDS_BANK_CONFLICT and the bank model of the guide):
-//   exchange 1   L1(p, col) = p*P1 + col,   P1 = T + (M < 32 ? M : 0)
+//   exchange 1   L1(p, col) = p*P1 + col,   P1 = T + M
 //       write (pass 1): fixed p, lanes col = t                -> consecutive slots
 //       read  (pass 2): thread (p, c), fixed b: p*P1 + b*M + c -> the 32/M rows a 32-lane group
 //                       touches sit 8M bytes apart in bank space
-//   exchange 2   L2(c, kl) = c*P2 + kl,     P2 = 256 + (M <= 16 ? 16/M : 1)
+//   exchange 2   L2(c, kl) = c*P2 + kl,     P2 = 256 + 16/M
 //       write (pass 2): thread (p, c), fixed q: c*P2 + p + 16q -> 16 lanes on 16 distinct bank pairs
 //       read  (pass 3): fixed c, lanes kl consecutive
 //   then the pass-2 twiddle table [q][c] (16*M entries), DC-sum scratch, the hit counter.
-// ------------------------------------------------------------------------------------
-// Experiment build (-DSCN_STAMPS=1, scripts/stamp_profile.py): every wave reads the shader clock at the
-// phase boundaries of the buffer loop; wave 0 of each workgroup leaves the per-phase cycle totals in the
-// first 12 floats of its first buffer's spectrum.  Never defined in the product build.
-#ifndef SCN_STAMPS
-#define SCN_STAMPS 0
-#endif
-// Where the next buffer's 16 loads are issued: 0 all before pass 1; 1 all after barrier 1; 2 8/8 over those
-// two points; 3 4/4/4/4 over the four barrier-separated phases; 4 (product) 6/5/5 over the first three; 5 8/4/4.
-// Measured (profiles/r01_floors.md): 0 -> 4 is -3..-5 us per launch; 3, 4, 5 are within noise of each other.
-#ifndef SCN_PF_SPLIT
-#define SCN_PF_SPLIT 4
-#endif
-// Work distribution over the persistent workgroups.  1 (product): every workgroup starts on buffer blockIdx.x and
-// then takes buffers from a device-scope queue, one iteration ahead so that the prefetch knows its target.
-// 0: static grid-stride assignment (buf = blockIdx.x + k*gridDim.x).  With the static form the workgroups of one
-// launch finish far apart (dispatch order, 10 or 11 buffers each, uneven speeds: 36..55 us in a 55 us int16
-// launch).  For the memory-bound float path that tail is not idle capacity (the remaining workgroups run faster:
-// measured neutral); for the compute-bound integer formats and the 8192-point kernel (8 buffers per workgroup) it is.
+//
+// The next buffer's 16 loads are issued in three groups (6 / 5 / 5) over the first three barrier-separated phases of the
+// current buffer: all 16 in front of pass 1 stalled the wave ~1600 cycles at issue whenever the memory pipeline was backed
+// up (-3 .. -5 us per launch, profiles/r01_floors.md; 4/4/4/4 and 8/4/4 are within noise of 6/5/5).
+//
+// Work distribution over the persistent workgroups.  Float input: static grid-stride assignment (buf = blockIdx.x +
+// k*gridDim.x).  The integer formats from 4096 points up (scn_uses_queue, scn_kernels.h): every workgroup starts on buffer
+// blockIdx.x and then takes buffers from a device-scope queue, one iteration ahead so that the prefetch knows its target.
+// With the static form the workgroups of one launch finish far apart (dispatch order, 10 or 11 buffers each, uneven
+// speeds: 36..55 us in a 55 us int16 launch).  For the memory-bound float path that tail is not idle capacity (the
+// remaining workgroups run faster: measured neutral); for the compute-bound integer formats and the 8192-point kernel
+// (8 buffers per workgroup) it is.
 // The queue is sharded 8 ways: one returning device-scope atomic saturates at ~88 per us on one word, so 8192
 // dequeues on one head would take longer than the launch (measured: 74 -> 115 us).  Workgroups land on XCD
 // blockIdx.x % 8, so a shard is pulled by one XCD; shard x owns the buffers b = 8 j + x.  The launcher never
 // starts more workgroups than buffers, so workgroup g takes buffer g statically (shard g % 8, j = g / 8) and
 // head x hands out j = j0, j0 + 1, ... with j0 = the number of workgroups in shard x.  Heads are never reset:
 // work_base[x] is head x's value before the launch (host-tracked; a launch adds exactly the number of buffers of
-// shard x, because every workgroup stops at its first index past the end).  (The one take whose answer is needed at
-// once is the prologue's; giving every workgroup a second static buffer instead, so that no take is ever waited for,
-// was built and measured: C3 shape 66.4 -> 67.2 us, 4096-pt int16 58.8 -> 58.4 -- nothing, so the simpler form stays.)
+// shard x, because every workgroup stops at its first index past the end).
 // Measured per wire format (one box, single stream, us per launch static -> queue): int16 4096-pt 64.1 -> 61.2,
-// int8 63.9 -> 59.4, 8192-pt int16 98.5 -> 89.9, float 4096-pt 76.1 -> 77.0, 8192-pt float 83.8 -> 85.8: the
-// queue is compiled in for the integer formats from 4096 points up (scn_uses_queue, scn_kernels.h).
-#ifndef SCN_DYNAMIC_WORK
-#define SCN_DYNAMIC_WORK 1
-#endif
+// int8 63.9 -> 59.4, 8192-pt int16 98.5 -> 89.9, float 4096-pt 76.1 -> 77.0, 8192-pt float 83.8 -> 85.8.
 // The dequeue must stay ONE plain global_atomic_add whose result is collected an iteration later.  LLVM's AMDGPU
 // atomic optimizer rewrites any atomic with a provably uniform address into a wave reduction followed at once
 // by s_waitcnt vmcnt(0) + readfirstlane (wave 0 then sits out the atomic's ~3 us round trip on every buffer:
-// 74 -> 116 us), so the address gets an opaque per-lane zero offset.  (Switching the pass off globally,
-// -amdgpu-atomic-optimizer-strategy=None, is not an option: it is what aggregates the hit path's overflow
-// atomics per wave -- without it the int16 C3-shaped launch went from 64 to 97 us.)
+// 74 -> 116 us), so the address gets an opaque per-lane zero offset.
+// ------------------------------------------------------------------------------------
 #define SCN_WORK_QUEUE_SETUP()                                                                         \
   const uint32_t wq_shard = blockIdx.x & 7u;                                                           \
   uint32_t *const wq_head = args.work_counter + 32u * wq_shard; /* one 128-byte line per head */       \
@@ -287,32 +207,18 @@ struct RawLoader<SCN_K_SHORT> {
   auto wq_take = [&]() -> uint32_t { return atomicAdd(wq_head + wq_zero, 1u); };                       \
   auto wq_buffer = [&](uint32_t taken) -> uint32_t { return 8u * (wq_j0 + (taken - wq_base)) + wq_shard; }
 
-#if SCN_STAMPS
-#define SCN_STAMP(i)                                             \
-  do {                                                           \
-    __builtin_amdgcn_sched_barrier(0);                           \
-    const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); \
-    stamp_acc[i] += now_ - stamp_prev;                           \
-    stamp_prev = now_;                                           \
-    __builtin_amdgcn_sched_barrier(0);                           \
-  } while (0)
-#else
-#define SCN_STAMP(i)
-#endif
-
 template <int M>
 struct Geo {
+  static_assert(M == 4 || M == 8 || M == 16, "1024, 2048 or 4096 points");
   static constexpr uint32_t N = 256u * M;
   static constexpr uint32_t T = 16u * M;
-  static constexpr uint32_t P1 = T + (M < 32 ? M : 0);
-  static constexpr uint32_t P2 = 256u + (M <= 16 ? 16u / M : 1u);
+  static constexpr uint32_t P1 = T + M;
+  static constexpr uint32_t P2 = 256u + 16u / M;
   static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots
-  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 2u * 4u + 64u * 4u + 8u + (M == 64 ? 64u * 8u : 0u);
-  static constexpr uint32_t WAVES = T >= 64 ? T / 64 : 1;
-  // Register prefetch costs a wave per SIMD (4 -> 3).  At 8192 points a workgroup is 8 waves, so
-  // 3 waves per SIMD would leave ONE workgroup per CU: no prefetch there, two workgroups instead.
-  static constexpr bool PREFETCH = SCN_PREFETCH != 0 && M <= 16;
-  static constexpr uint32_t WAVES_PER_SIMD = PREFETCH ? SCN_WAVES_PER_SIMD_PF : 4;
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T * 8u + 16u * 4u + 2u * 4u + 64u * 4u + 8u;
+  static constexpr uint32_t WAVES = T / 64;
+  // the register prefetch of the next buffer costs a wave per SIMD (4 -> 3): VGPR budget 168
+  static constexpr uint32_t WAVES_PER_SIMD = 3;
   static constexpr uint32_t WG_PER_CU = (WAVES_PER_SIMD * 4u) / WAVES;
 };
 
@@ -333,7 +239,6 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   typedef Geo<M> G;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
-  constexpr bool PF = G::PREFETCH || (SCN_PF32_INT != 0 && M == 32 && KIND != SCN_K_FLOAT_COMPLEX);
   constexpr bool DYN = scn_uses_queue(KIND, G::N);
   constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
   typedef RawLoader<KIND> L;
@@ -343,31 +248,16 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T);      // [32] DC-sum scratch (re[16], im[16]: up to 16 waves)
   int *lds_hits = lds_cnt + 32;                             // [2] hit counters, alternating per buffer
   uint32_t *lds_next = reinterpret_cast<uint32_t *>(lds_hits + 2);  // [1] the buffer this workgroup takes after the next one
-  v2f *lds_w64 = reinterpret_cast<v2f *>(smem_raw + G::LDS_BYTES - 64u * 8u);  // M == 64 only: W_64^m, m < 64
 
-#if SCN_STAMPS
-  const uint32_t stamp_entry = (uint32_t)wall_clock64();  // first instruction of the workgroup
-#endif
   const uint32_t t = threadIdx.x;
   const uint32_t p2 = t / M, c2 = t % M;  // pass-2 identity (p, c); also the (q, c) of the table entry below
   const uint32_t lane = t & 63, wave = t >> 6;
-  // pass-3 identity for M == 32: parity e = lane half, butterfly kl;  for M == 64: e = lane row (16 lanes), 16 butterflies per wave
-  const uint32_t e = (M == 64) ? (t >> 4) & 3u : (t >> 5) & 1u;
-  const uint32_t kl32 = (M == 64) ? (t & 15u) + 16u * (t >> 6) : (t & 31u) + 32u * (t >> 6);
-  // the output block this lane ends up holding: r = r' + 16 s
-  const uint32_t s_out = (M == 64) ? 2u * (e & 1u) + (e >> 1) : e;
 
   // the first buffer's samples go out before anything else: their latency then overlaps the
   // ~31 table loads below instead of following them
-  // (Sizes without the register prefetch load at the top of the iteration.  Letting the next buffer's loads leave behind this
-  // buffer's stores, before the end-of-buffer barrier and the hit recording -- free in registers, and at 16384 points, one
-  // workgroup per CU, everything after the stores is dead time for the memory system: 5.9 k cycles at barrier 4 + 2 k of
-  // recording per 30 k-cycle buffer -- was measured twice and is worse both times: 8192 points, 512-thread form, 85.9 -> 89.8 us
-  // (round 1); 16384 points 109.7 -> 126.2 us cfloat, 94.2 -> 102.2 int16 (round 2).)
   typename L::raw_t raw[16];
-  if (PF && blockIdx.x < args.n_buffers) {
-    __amdgpu_buffer_rsrc_t r0 =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+  if (blockIdx.x < args.n_buffers) {
+    __amdgpu_buffer_rsrc_t r0 = make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), L::kBufBytes(N));
 #pragma unroll
     for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(r0, N, t, T * a);
   }
@@ -383,7 +273,6 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t] * args.scale;
   // pass-2 twiddles W_{16M}^(c*q) = W_N^(16 c q), table [q][c] shared by the workgroup
   lds_tw2[t] = args.twiddle[(16 * p2 * c2) & (N - 1)];
-  if (M == 64 && t < 64) lds_w64[t] = args.twiddle[t * (N / 64u)];
   SCN_WORK_QUEUE_SETUP();
   if (t == 0) {
     lds_hits[0] = lds_hits[1] = 0;
@@ -394,19 +283,18 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   v2f *w1 = lds + t;                      // + p*P1
   v2f *r1 = lds + p2 * P1 + c2;           // + b*M
   v2f *w2 = lds + c2 * P2 + p2;           // + 16*q
-  v2f *r3 = (M >= 32) ? lds + e * P2 + kl32 : lds + t;  // + 2c'*P2 (M = 32), + 4c'*P2 (M = 64)   |   + c*P2 + T*u
+  v2f *r3 = lds + t;                      // + c*P2 + T*u
   const v2f *tw2 = lds_tw2 + c2;          // + q*M
-  // global store offset of output o: voffset (per lane) + scalar part
-  const uint32_t st_voff = (M >= 32) ? (kl32 + 4096u * s_out) * 4u : t * 4u;
+  const uint32_t st_voff = t * 4u;        // global store offset of output o: voffset (per lane) + scalar part
 
+  // output o = u*M + r of this thread is bin j = t + T*u + 256*r
+  auto joff_of = [](int o) -> uint32_t { return T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M); };
   // K5 mask of this thread's 16 output bins (process.cpp:46-52): depends on (t, o) only
-  const uint32_t jbase = (M >= 32) ? kl32 + 4096u * s_out : t;
   uint32_t keepmask = 0;
   if (HITS) {
 #pragma unroll
     for (int o = 0; o < 16; o++) {
-      const uint32_t joff = (M >= 32) ? 256u * o : T * (o / M) + 256u * (o % M);
-      const uint32_t j = jbase + joff;
+      const uint32_t j = t + joff_of(o);
       const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
       const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
       keepmask |= keep ? (1u << o) : 0u;
@@ -415,29 +303,11 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
   uint32_t par = 0;             // which of the two LDS hit counters the buffer in flight uses
   uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running (none yet)
 
-  // output o of this thread is bin j = jbase + joff(o):  M <= 16: o = u*M + r, j = t + T*u + 256*r;  M == 32: o = r', j = kl + 4096*e + 256*r'
-  auto joff_of = [](int o) -> uint32_t { return (M >= 32) ? 256u * o : T * ((uint32_t)o / M) + 256u * ((uint32_t)o % M); };
-#if SCN_STAMPS
-  uint32_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t stamp_hit_cyc = 0, stamp_hit_n = 0;  // cycles wave 0 spent in scn_record_hits, and how often it went in
-  uint32_t stamp_prev = (uint32_t)__builtin_readcyclecounter();
-  const uint32_t stamp_t0 = (uint32_t)wall_clock64();  // 100 MHz
-  uint32_t stamp_hw;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(stamp_hw));
-#endif
   uint32_t buf = blockIdx.x;
   uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
   while (buf < args.n_buffers) {
-    SCN_STAMP(0);  // previous buffer's hit recording + loop back
     const bool more = nxt < args.n_buffers;
-    // ---- K1 + K2: load, convert, window ----
-    if (!PF) {
-      __amdgpu_buffer_rsrc_t rin =
-          make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
-#pragma unroll
-      for (int a = 0; a < 16; a++) raw[a] = L::template load<AUX_LD>(rin, N, t, T * a);
-    }
-
+    // ---- K1 + K2: convert, window (the samples were fetched during the previous buffer's passes) ----
     int dc_re = 0, dc_im = 0;
     if (DC) {
       // integer mean with the reference's int32 /= uint32 quirk (utility.cpp:77-78)
@@ -469,7 +339,6 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     cf v[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, 1.0f) * win[a];
-    SCN_STAMP(1);  // wait for this buffer's samples (+ convert, window)
     // Take the buffer after the next one; the answer is only needed at the end of this iteration.  Issued here,
     // behind the convert: a grab ahead of it sits in a divergent branch and the merged wait count then makes
     // wave 0 sit out the atomic's round trip where it waits for the samples.
@@ -478,26 +347,16 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     // The raw registers are free again: fetch the next buffer of this workgroup while this one is
     // transformed.  Branch-free (past the last buffer the descriptor has zero records: the loads return
     // zeros without touching memory), so every load sits in the same basic block as the butterflies and
-    // can be issued between them: a burst of 16 loads stalls the wave at issue for ~1600 cycles when the
-    // memory pipeline is backed up (profiles/r01_floors.md, stamp profile), spread out they do not.
+    // can be issued between them.
     const __amdgpu_buffer_rsrc_t rn =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N),
-                  (more && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N), more ? L::kBufBytes(N) : 0u);
     auto prefetch = [&](int a_lo, int a_hi) {
 #pragma unroll
       for (int a = 0; a < 16; a++)
         if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(rn, N, t, T * a);
     };
-    // issue points: 0 before pass 1, 1 after barrier 1, 2 after barrier 2, 3 after barrier 3;
-    // pf_cut[k] .. pf_cut[k+1] = the loads issued at point k
-    constexpr int pf_cut[5] = {0,
-                               SCN_PF_SPLIT == 0 ? 16 : SCN_PF_SPLIT == 1 ? 0 : SCN_PF_SPLIT == 2 ? 8 : SCN_PF_SPLIT == 3 ? 4 : SCN_PF_SPLIT == 4 ? 6 : 8,
-                               SCN_PF_SPLIT <= 2 ? 16 : SCN_PF_SPLIT == 3 ? 8 : SCN_PF_SPLIT == 4 ? 11 : 12,
-                               SCN_PF_SPLIT <= 2 ? 16 : SCN_PF_SPLIT == 3 ? 12 : 16,
-                               16};
-    if (PF) prefetch(pf_cut[0], pf_cut[1]);
+    prefetch(0, 6);
 
-    SCN_STAMP(2);  // issue of the next buffer's loads
     // ---- pass 1: DFT over a, twiddle W_N^(t p), scatter to row p ----
     fft16(v);
 #pragma unroll
@@ -506,9 +365,7 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
       if (p) y = cmul(y, tw1[p]);
       w1[p * P1] = to_v2f(y);
     }
-    SCN_STAMP(3);  // pass 1 + exchange-1 writes
-    __syncthreads();
-    SCN_STAMP(4);  // barrier 1
+    __syncthreads();  // barrier 1
     if (HITS) {
       // every wave has passed the barrier above, so the previous buffer's recorders are done
       if (t == 0 && prev != 0xffffffffu) {
@@ -521,97 +378,39 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
     // ---- pass 2: thread (p, c): DFT over b, twiddle W_{16M}^(c q) ----
 #pragma unroll
     for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * M]);
-    if (PF) prefetch(pf_cut[1], pf_cut[2]);
+    prefetch(6, 11);
     fft16(v);
 #pragma unroll
     for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * M]));
-    SCN_STAMP(5);  // exchange-1 reads + pass 2 + twiddles
-    __syncthreads();  // every exchange-1 read done before the area is re-used
-    SCN_STAMP(6);  // barrier 2
-    if (PF) prefetch(pf_cut[2], pf_cut[3]);
+    __syncthreads();  // barrier 2: every exchange-1 read done before the area is re-used
+    prefetch(11, 16);
 #pragma unroll
     for (int q = 0; q < 16; q++) w2[q * 16] = to_v2f(v[OUT16(q)]);
-    SCN_STAMP(7);  // exchange-2 writes
-    __syncthreads();
-    SCN_STAMP(8);  // barrier 3
-    if (PF) prefetch(pf_cut[3], pf_cut[4]);
+    __syncthreads();  // barrier 3
 
     // ---- pass 3: M-point DFT over c ----
-    if constexpr (M == 64) {
 #pragma unroll
-      for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[4 * c * P2]);
-      fft16(v);
-      // radix 4 across the four rows of the wave: T_e = W_64^(e r') Y_e[r'], then
-      //   halves:  A_e0 = T_e0 + T_(e0+2) (rows 0, 1)     B_e0 = T_e0 - T_(e0+2) (rows 2, 3)
-      //   rows:    X_0 = A_0 + A_1, X_2 = A_0 - A_1 (rows 0, 1)     X_1 = B_0 - i B_1, X_3 = B_0 + i B_1 (rows 2, 3)
-      // Both exchanges use the swap instructions on two copies of the value, which leaves the pair's two values in both
-      // lanes (see M == 32 below); the signs are per-lane constants, so every lane runs the same instructions.
-      const bool upper = (e & 2u) != 0, odd = (e & 1u) != 0;
-      const float sgn_h = upper ? -1.0f : 1.0f, sgn_r = odd ? -1.0f : 1.0f;
-      const v2f *wtab = lds_w64;
+    for (int u = 0; u < 16 / M; u++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        cf y = v[OUT16(r)];
-        if (r) y = cmul(y, from_v2f(wtab[(e * (uint32_t)r) & 63u]));  // W_64^(e r); row 0 multiplies by 1
-        auto hx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.x), false, false);
-        auto hy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y.y), __builtin_bit_cast(unsigned, y.y), false, false);
-        const cf ab = cf{__builtin_fmaf(__builtin_bit_cast(float, (unsigned)hx[1]), sgn_h, __builtin_bit_cast(float, (unsigned)hx[0])),
-                         __builtin_fmaf(__builtin_bit_cast(float, (unsigned)hy[1]), sgn_h, __builtin_bit_cast(float, (unsigned)hy[0]))};
-        auto rx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ab.x), __builtin_bit_cast(unsigned, ab.x), false, false);
-        auto ry = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ab.y), __builtin_bit_cast(unsigned, ab.y), false, false);
-        const cf s0 = cf{__builtin_bit_cast(float, (unsigned)rx[0]), __builtin_bit_cast(float, (unsigned)ry[0])};  // even row of the pair
-        const cf s1 = cf{__builtin_bit_cast(float, (unsigned)rx[1]), __builtin_bit_cast(float, (unsigned)ry[1])};  // odd row
-        const cf tt = upper ? cf{s1.y, -s1.x} : s1;  // -i B_1 in the upper half, A_1 in the lower
-        v[OUT16(r)] = cf{__builtin_fmaf(tt.x, sgn_r, s0.x), __builtin_fmaf(tt.y, sgn_r, s0.y)};
-      }
-    } else if constexpr (M == 32) {
+      for (int c = 0; c < M; c++) v[u * M + c] = from_v2f(r3[c * P2 + T * u]);
+    if constexpr (M == 16) fft16(v);
+    if constexpr (M == 8) {
+      fft8(v);
+      fft8(v + 8);
+    }
+    if constexpr (M == 4) {
 #pragma unroll
-      for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[2 * c * P2]);
-      fft16(v);
-      // radix 2 across the wave's two halves: X[r'] = Y0 + W32^r' Y1, X[r'+16] = Y0 - W32^r' Y1.
-      // v_permlane32_swap exchanges the upper half of one register with the lower half of another:
-      // applied to two copies of y it leaves (Y0, W Y1) in BOTH halves, so the butterfly is one
-      // FMA with a per-half sign -- no LDS crossbar (ds_bpermute) traffic.
-      const float sel = e ? 1.0f : 0.0f, sgn = e ? -1.0f : 1.0f;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        cf y = v[OUT16(r)];
-        if (r) {
-          // W_32^r for the odd half, 1 for the even half (branch-free: both halves run the same code)
-          const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
-          const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
-          cf w = cf{e ? cr : 1.0f, -sr * sel};
-          y = cmul(y, w);
-        }
-        auto sx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.x), false, false);
-        auto sy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y.y), __builtin_bit_cast(unsigned, y.y), false, false);
-        v[OUT16(r)] = cf{__builtin_fmaf(__builtin_bit_cast(float, (unsigned)sx[1]), sgn, __builtin_bit_cast(float, (unsigned)sx[0])),
-                         __builtin_fmaf(__builtin_bit_cast(float, (unsigned)sy[1]), sgn, __builtin_bit_cast(float, (unsigned)sy[0]))};
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 16 / M; u++)
-#pragma unroll
-        for (int c = 0; c < M; c++) v[u * M + c] = from_v2f(r3[c * P2 + T * u]);
-      if constexpr (M == 16) fft16(v);
-      if constexpr (M == 8) {
-        fft8(v);
-        fft8(v + 8);
-      }
-      if constexpr (M == 4) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) radix4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
-      }
+      for (int u = 0; u < 4; u++) radix4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
     }
 
     // ---- K4 + K5 ----
-    // The thread's 16 LINEAR powers stay in `pw` (a true vector: the recording path indexes it with a wave-uniform o,
-    // s_set_gpr_idx) for the hit path; the spectrum gets the dB map of scn_device.h: its product form inline, and -- only in
-    // waves that hold a bin from SCN_P_EXACT_FROM up -- the exact form stored over it for those bins (the other lanes' stores
-    // go to an out-of-range offset and are dropped by the descriptor's range check: no branch per bin).
+    // The thread's 16 LINEAR powers stay in `pw` for the hit path; the spectrum gets the dB map of scn_device.h: its product
+    // form inline, and -- only in waves that hold a bin from SCN_P_EXACT_FROM up -- the exact form stored over it for those
+    // bins (the other lanes' stores go to an out-of-range offset and are dropped by the descriptor's range check: no branch
+    // per bin).
     v16f pw;
     float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the largest power of each group of four outputs (max ignores NaN)
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db) ? 4u * N : 0u);
 #pragma unroll
     for (int o = 0; o < 16; o++) {
       const float q = power_of(v[out_reg<M>(o)]);
@@ -641,57 +440,21 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
         }
       }
     }
-    SCN_STAMP(9);  // exchange-2 reads + pass 3 + dB + stores issued
     if (t == 0) lds_next[0] = !more ? 0xffffffffu : DYN ? wq_buffer(taken) : nxt + gridDim.x;
-    __syncthreads();  // exchange area free again; lds_next visible (it is rewritten three barriers from now)
-    SCN_STAMP(10);  // barrier 4
+    __syncthreads();  // barrier 4: exchange area free again; lds_next visible (it is rewritten three barriers from now)
     const uint32_t after = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
-#if SCN_STAMPS
-    stamp_acc[11] += 1;
-#endif
     if (HITS) {
       // Recording runs AFTER the barrier: a wave that holds detections does not stall the other
       // waves of its workgroup, they go on to the next buffer and meet it at that buffer's first
       // barrier (its loads are in flight meanwhile).  Only such a wave evaluates the per-bin test.
-      if (__ballot(pmax > args.p_lo)) {
-#if SCN_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        const uint32_t h0_ = (uint32_t)__builtin_readcyclecounter();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#if SCN_HITS_LANES_N
-        scn_record_hits_lanes<16, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
-#else
-        scn_record_hits<16, false, true, SCN_ONE_ATOMIC_N>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (jbase + joff_of(o)) ^ (N / 2); });
-#endif
-#if SCN_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        stamp_hit_cyc += (uint32_t)__builtin_readcyclecounter() - h0_;
-        stamp_hit_n += 1;
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
+      if (__ballot(pmax > args.p_lo))
+        scn_record_hits_lanes<16, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int o) -> uint32_t { return (t + joff_of(o)) ^ (N / 2); });
       prev = buf;
       par ^= 1;
     }
     buf = nxt;
     nxt = after;
   }
-#if SCN_STAMPS
-  if (t == 0 && blockIdx.x < args.n_buffers && args.power_db) {
-    __builtin_amdgcn_s_waitcnt(0);
-    for (int i = 0; i < 12; i++) args.power_db[(size_t)blockIdx.x * N + i] = (float)stamp_acc[i];
-    // start / end of this workgroup on the 100 MHz wall clock (low 24 bits: exact in a float) and where it ran
-    args.power_db[(size_t)blockIdx.x * N + 12] = (float)(stamp_t0 & 0xffffffu);
-    args.power_db[(size_t)blockIdx.x * N + 13] = (float)((uint32_t)wall_clock64() & 0xffffffu);
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    args.power_db[(size_t)blockIdx.x * N + 14] = (float)(((xcc & 0xfu) << 8) | ((stamp_hw >> 8) & 0xffu));  // xcc, se/sh/cu
-    args.power_db[(size_t)blockIdx.x * N + 15] = (float)(stamp_entry & 0xffffffu);
-    args.power_db[(size_t)blockIdx.x * N + 16] = (float)stamp_hit_cyc;
-    args.power_db[(size_t)blockIdx.x * N + 17] = (float)stamp_hit_n;
-  }
-#endif
   if (HITS) {
     __syncthreads();  // last buffer's recorders done
     if (t == 0 && prev != 0xffffffffu) {
@@ -750,7 +513,7 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
   auto in_rsrc = [&](uint32_t first) {
     const bool ok = first < args.n_buffers;
     const uint32_t nb = ok ? (args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS) : 0u;
-    return make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(ok ? first : 0u) * buf_bytes, SCN_EXP_NO_LOADS ? 0u : nb * buf_bytes);
+    return make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(ok ? first : 0u) * buf_bytes, nb * buf_bytes);
   };
   // planar int16 reads I and Q of a buffer n samples apart: the loader takes the buffer's own sample count, the slot offset
   // goes into the index (in samples of the loader's element size)
@@ -856,7 +619,7 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
     v16f pw;
     float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t nvalid = args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS;
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? nvalid * 4u * N : 0u);
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, (SPEC && args.power_db) ? nvalid * 4u * N : 0u);
     const uint32_t st_voff = (slot * N + t) * 4u;
 #pragma unroll
     for (int o = 0; o < 16; o++) {
@@ -891,7 +654,6 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
         for (int o = 0; o < 16; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
         cand &= valid ? keepmask : 0u;
         ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-#if SCN_HITS_LANES_S
         while (__ballot(cand != 0u)) {  // one candidate per lane per trip (scn_record_hits_lanes; here a lane's counter is its slot's)
           const bool act = cand != 0u;
           const uint32_t o = act ? (uint32_t)__builtin_ctz(cand) : 0u;
@@ -904,20 +666,6 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
             if (pos < args.hit_region) region[pos] = ScnDevHit{(t + joff_of((int)o)) ^ (N / 2), d};
           }
         }
-#else
-        uint32_t wm = wave_or_u32(cand);
-        while (wm) {
-          const int o = __builtin_ctz(wm);  // wave-uniform
-          wm &= wm - 1u;
-          const float q = pw[o];
-          float d = db_fast(q);
-          if (__ballot(q >= SCN_P_EXACT_FROM)) d = q >= SCN_P_EXACT_FROM ? db_exact(q) : d;
-          if (((cand >> o) & 1u) && d > args.threshold) {  // strict >, process.cpp:54
-            const uint32_t pos = (uint32_t)atomicAdd(&lds_hits[slot], 1);
-            if (pos < args.hit_region) region[pos] = ScnDevHit{(t + joff_of(o)) ^ (N / 2), d};
-          }
-        }
-#endif
       }
     }
     __syncthreads();  // exchange areas free again; the slots' hit counters final
@@ -932,80 +680,34 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
 }
 
 // ------------------------------------------------------------------------------------
-// 8192 points, wide form: ONE workgroup of 256 threads per buffer, 32 points per thread.
+// 8192 points: ONE workgroup of 256 threads per buffer, 32 points per thread (scn_fft8k_kernel).
 //
-// Same decomposition as above (n = 512a + 32b + c, k = p + 16q + 256r, passes 16 x 16 x 32), but every
-// thread plays two of the 512 "virtual threads" of passes 1 and 2 (tau and tau + 256) and owns one whole
-// 32-point DFT in pass 3 (in registers: two 16-point DFTs + one radix-2 step, no cross-lane exchange).
+// The decomposition of the kernel above with M = 32 (n = 512a + 32b + c, k = p + 16q + 256r, passes 16 x 16 x 32), but every
+// thread plays two of the 512 "virtual threads" of passes 1 and 2 and owns one whole 32-point DFT in pass 3 (in registers:
+// two 16-point DFTs + one radix-2 step, no cross-lane exchange).
 // Why: with 512 threads a workgroup is 8 waves, two workgroups per CU are 4 waves per SIMD = 128 VGPRs,
-// which leaves no registers to prefetch the next buffer -- the stamp profile of that form shows the load
+// which leaves no registers to prefetch the next buffer -- the stamp profile of that form showed the load
 // latency fully exposed (19 % waiting for samples, 20 % at barrier 1, 13 % at barrier 4).  256 threads x
 // 2 workgroups per CU (LDS: 2 x 70 KiB) are 2 waves per SIMD = 256 VGPRs: room for the next buffer's
 // 32 samples per thread, fetched in three groups spread over the passes like the smaller sizes.
-// LDS layouts and bank behaviour are those of Geo<32> (P1 = 512, P2 = 257): each wave touches the same
-// slots per instruction as a wave of the 512-thread form does.
+// LDS layouts: L1(p, tau) = 512 p + tau, L2(c, kl) = 257 c + kl (all four access patterns conflict-free).
+// In pass 1 a thread plays the NEIGHBOURS tau = 2t and 2t + 1: their inputs 512a + 2t (+1) are adjacent in memory and
+// their exchange-1 slots adjacent in LDS, so a buffer is fetched in 16 loads of two samples (16 / 8 / 4 bytes per lane)
+// and exchange 1 is written in 16 ds_write_b128; in pass 2 it plays (p, c) and (p + 8, c).
 // ------------------------------------------------------------------------------------
-#ifndef SCN_WIDE_8192
-#define SCN_WIDE_8192 1
-#endif
-#ifndef SCN_16K_FLOAT_PFN
-#define SCN_16K_FLOAT_PFN 8
-#endif
-#ifndef SCN_8K_FLOAT_PFN
-#define SCN_8K_FLOAT_PFN 16  // (8192-pt cfloat, 16 / 14 / 12 / 8 prefetched: 77.5 / 76.7 / 77.5 / 77.7 us -- flat)
-#endif
-#ifndef SCN_16K_INT_PFN
-#define SCN_16K_INT_PFN 16
-#endif
-#ifndef SCN_WIDE_16384_FLOAT
-#define SCN_WIDE_16384_FLOAT 1  // float input at 16384 points in the wide form with a partial prefetch (0: scn_fft_kernel<64>)
-#endif
-#ifndef SCN_WIDE_16384
-#define SCN_WIDE_16384 1  // 16384 points: 512 threads x 32 points with a register prefetch instead of scn_fft_kernel<64>
-#endif
-#ifndef SCN_16K_P3_DOUBLE
-// Pass 3 of the 16384-point kernel in double (scn_fft16k2_body).  Measured on MI355X, 3072 strong-tone buffers per run
-// (scripts/acc16k.py) and us per 2048-buffer launch, float pass 3 -> double: parity metric max 4.9e-6 .. 7.5e-6 -> 2.9e-6 .. 4.0e-6,
-// p99 4.0e-6 -> 2.2e-6, median 1.11e-6 -> 0.88e-6 (the float quantisation of the dB value itself); cfloat 93.5 -> 100.2 us,
-// int16 75.6 -> 88.1 (+7 % / +16 %: 128 conversions and 1.2 .. 1.4x on a third of the arithmetic).  Round 2's kernel of this
-// size (16 x 16 x 64 with a lane-pair last pass, float) took 100.6 / 95.7 us on the same box and reached 1.05e-5: the bar.
-// Parity comes first, so double is the product; -DSCN_16K_P3_DOUBLE=0 is the float build.  (In the round-2 form of the
-// kernel the same change cost +38 % and spilled: the lane exchange doubles, and its registers do not fit.)
-#define SCN_16K_P3_DOUBLE 1
-#endif
-#ifndef SCN_8K_PAIR
-#define SCN_8K_PAIR 1  // the wide kernel's threads play neighbouring virtual threads (two-sample loads, 16-byte exchange-1 writes)
-#endif
-// (16384 points run as scn_fft_kernel<64>: 1024 threads x 16 points, four waves per SIMD, lane-quad radix-4 in pass 3.
-// The first form -- 256 threads x 64 points, one wave per SIMD, modelled on the wide kernel below -- was 1.5-1.8x slower:
-// 195 / 191 Gsamples/s against 296 / 344 for cfloat / int16 at batch 2048.)
 namespace {
-// the wide form for N = 256*M2, M2 = 32 (8192 points: the kernel described above) or 64 (16384 points): 8*M2 threads play
-// the 16*M2 virtual threads of passes 1 and 2, two each, and hold 32 points each; two waves per SIMD either way
-template <int M2>
-struct GeoWide {
-  static constexpr uint32_t N = 256u * M2, T = 8u * M2, TV = 16u * M2, P1 = TV, P2 = 257;
-  static constexpr uint32_t EXCH = (16u * P1 > M2 * P2) ? 16u * P1 : M2 * P2;  // slots
+struct Geo8k {
+  static constexpr uint32_t N = 8192, T = 256, TV = 512, P1 = TV, P2 = 257;
+  static constexpr uint32_t EXCH = (16u * P1 > 32u * P2) ? 16u * P1 : 32u * P2;  // slots
   static constexpr uint32_t LDS_BYTES = EXCH * 8u + TV * 8u + 16u * 4u + 2u * 4u + 8u;
-  static constexpr uint32_t WG_PER_CU = M2 == 32 ? 2 : 1;  // 70 KiB / 140 KiB of LDS
+  static constexpr uint32_t WG_PER_CU = 2;  // 70 KiB of LDS each
 };
-typedef GeoWide<32> Geo8k;
 typedef float v32f __attribute__((ext_vector_type(32)));
 
-// 16384 points in the wide form (M2 = 64).  The 1024-thread form (scn_fft_kernel<64>: four waves per SIMD, 128 VGPRs, no room
-// to prefetch) has ONE workgroup per CU, so nothing covers its loads: its stamp profile shows 13 k of a buffer's 30 k cycles
-// waiting for the samples (and letting the next buffer's loads leave behind the stores makes it worse, see there).  512 threads
-// x 32 points are two waves per SIMD = 256 VGPRs: the next buffer is prefetched in three groups spread over the passes, as
-// at 8192 points.  Pass 3 is a 64-point DFT per kl shared by TWO lanes (l, l + 32): lane half e does the 16-point DFTs over
-// c = 4c' + e and c = 4c' + e + 2, joins them in registers (U, V = Y_e +- W_32^r' Y_(e+2): the 8192-point kernel's last step),
-// the odd half multiplies by W_64^r', and one v_permlane32_swap per register finishes the radix-4 step:
-//   X[r']      = U_0 + W U_1 (lower half)      X[r' + 32] = U_0 - W U_1 (upper half)
-//   X[r' + 16] = V_0 - i W V_1 (lower half)    X[r' + 48] = V_0 + i W V_1 (upper half)
-template <int M2, int KIND, bool DC, bool HITS, bool SPEC>
-__device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
+template <int KIND, bool DC, bool HITS, bool SPEC>
+__device__ __forceinline__ void scn_fft8k_body(const ScnFftArgs &args) {
   static_assert(HITS || SPEC, "a kernel that reports nothing");
-  typedef GeoWide<M2> G;
-  constexpr bool P3D = M2 == 64 && SCN_16K_P3_DOUBLE != 0;  // pass 3 in double (see there)
+  typedef Geo8k G;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
   constexpr uint32_t N = G::N, T = G::T, TV = G::TV, P1 = G::P1, P2 = G::P2;
@@ -1013,69 +715,41 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-  v2f *lds_tw2 = lds + G::EXCH;                              // [16][M2]: W_(16 M2)^(c q) at q*M2 + c
+  v2f *lds_tw2 = lds + G::EXCH;                              // [16][32]: W_512^(c q) at 32 q + c
   int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + TV);     // [16] DC-sum scratch (re[8], im[8])
   int *lds_hits = lds_cnt + 16;                             // [2] hit counters, alternating per buffer
   uint32_t *lds_next = reinterpret_cast<uint32_t *>(lds_hits + 2);  // [1] the buffer this workgroup takes after the next one
 
-#if SCN_STAMPS
-  const uint32_t stamp_entry = (uint32_t)wall_clock64();
-#endif
   const uint32_t t = threadIdx.x;
   const uint32_t lane = t & 63, wave = t >> 6;
-  const uint32_t c2 = t % M2, p2 = t / M2;   // pass-2 identities of this thread: (p2, c2) and (p2 + 8, c2), p2 < 8
-  // pass-3 identity.  M2 = 32: one whole 32-point DFT, kl = t.  M2 = 64: half e of the 64-point DFT of kl (lanes l, l + 32)
-  const uint32_t e = (M2 == 64) ? (t >> 5) & 1u : 0u;
-  const uint32_t kl = (M2 == 64) ? (t & 31u) + 32u * (t >> 6) : t;
-  // Which two of the 512 pass-1 virtual threads this thread plays.  PAIR (product): tau = 2t and 2t + 1 -- their inputs
-  // 512a + 2t (+1) are neighbours in memory and their exchange-1 slots neighbours in LDS, so a buffer is fetched in 16
-  // loads of two samples instead of 32 of one (16 / 8 / 4 bytes per lane) and exchange 1 is written in 16 ds_write_b128
-  // instead of 32 ds_write_b64.  !PAIR: tau = t and t + 256 (the first form).
-  constexpr bool PAIR = SCN_8K_PAIR != 0;
-  // how many of a buffer's 16 two-sample loads are prefetched during the previous buffer's passes (in three groups); the rest
-  // is fetched at the top of its own iteration.  16 everywhere except float input at 16384 points, whose 64 prefetch registers
-  // do not fit beside the lane-pair step of pass 3 (22 VGPRs spilled, slower than the 1024-thread form): there 12 (48 registers)
-  constexpr int PFN = M2 != 64 ? (KIND == SCN_K_FLOAT_COMPLEX ? SCN_8K_FLOAT_PFN : 16) : KIND == SCN_K_FLOAT_COMPLEX ? SCN_16K_FLOAT_PFN : SCN_16K_INT_PFN;
-  constexpr int PF0 = PFN == 16 ? 6 : PFN / 3 + 1, PF1 = PFN == 16 ? 11 : 2 * PFN / 3 + 1;
-  const uint32_t tau0 = PAIR ? 2u * t : t, tau1 = PAIR ? 2u * t + 1u : t + T;
+  const uint32_t c2 = t % 32u, p2 = t / 32u;   // pass-2 identities of this thread: (p2, c2) and (p2 + 8, c2), p2 < 8
+  const uint32_t tau0 = 2u * t;                // pass-1 identities: tau0 and tau0 + 1
 
-  // first buffer's samples first: raw[2a + h] = x[512 a + tau_h]
+  // first buffer's samples first: raw[2a + h] = x[512 a + tau0 + h]
   typename L::raw_t raw[32];
   auto load_group = [&](const __amdgpu_buffer_rsrc_t &r, int a_lo, int a_hi) {  // inputs a_lo .. a_hi - 1 of both virtual threads
 #pragma unroll
     for (int a = 0; a < 16; a++)
-      if (a >= a_lo && a < a_hi) {
-        if (PAIR) {
-          L::template load2<AUX_LD>(r, N, t, TV * a, raw[2 * a], raw[2 * a + 1]);
-        } else {
-          raw[2 * a] = L::template load<AUX_LD>(r, N, t, TV * a);
-          raw[2 * a + 1] = L::template load<AUX_LD>(r, N, t, TV * a + T);
-        }
-      }
+      if (a >= a_lo && a < a_hi) L::template load2<AUX_LD>(r, N, t, TV * a, raw[2 * a], raw[2 * a + 1]);
   };
   if (blockIdx.x < args.n_buffers) {
-    __amdgpu_buffer_rsrc_t r0 =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
-    load_group(r0, 0, PFN);
+    __amdgpu_buffer_rsrc_t r0 = make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), L::kBufBytes(N));
+    load_group(r0, 0, 16);
   }
   // persistent constants: pass-1 twiddles of both virtual threads (table rows of TV), window taps
-  // (16384 points with pass 3 in double: the second virtual thread's twiddles are NOT kept -- tau1 = tau0 + 1, so
-  // W_N^(tau1 p) = W_N^(tau0 p) W_N^p with W_N^p a compile-time constant: one more complex multiply per p and buffer buys the
-  // 30 registers pass 3 needs for its double-precision values)
-  constexpr bool TW1B = !(P3D && PAIR);
-  cf tw1a[16], tw1b[TW1B ? 16 : 1];
+  cf tw1a[16], tw1b[16];
 #pragma unroll
   for (int p = 1; p < 16; p++) {
     tw1a[p] = from_v2f(args.tw1_table[(p - 1) * TV + tau0]);
-    if (TW1B) tw1b[p] = from_v2f(args.tw1_table[(p - 1) * TV + tau1]);
+    tw1b[p] = from_v2f(args.tw1_table[(p - 1) * TV + tau0 + 1u]);
   }
   float win[32];
 #pragma unroll
   for (int a = 0; a < 16; a++) {
     win[2 * a] = args.window[TV * a + tau0] * args.scale;
-    win[2 * a + 1] = args.window[TV * a + tau1] * args.scale;
+    win[2 * a + 1] = args.window[TV * a + tau0 + 1u] * args.scale;
   }
-  // pass-2 twiddles W_(16 M2)^(c q) = W_N^(16 c q), entry q*M2 + c: this thread fills entries t (q = p2) and t + T (q = p2 + 8)
+  // pass-2 twiddles W_512^(c q) = W_N^(16 c q), entry 32 q + c: this thread fills entries t (q = p2) and t + T (q = p2 + 8)
   lds_tw2[t] = args.twiddle[(16u * p2 * c2) & (N - 1)];
   lds_tw2[t + T] = args.twiddle[(16u * (p2 + 8u) * c2) & (N - 1)];
   SCN_WORK_QUEUE_SETUP();
@@ -1085,20 +759,18 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
   }
   __syncthreads();
 
-  v2f *w1 = lds + tau0;                    // + p*P1 (the second virtual thread: + (tau1 - tau0))
-  v2f *r1 = lds + p2 * P1 + c2;            // + b*M2 (+ 8*P1 for the second)
+  v2f *w1 = lds + tau0;                    // + p*P1: slots tau0, tau0 + 1
+  v2f *r1 = lds + p2 * P1 + c2;            // + 32 b (+ 8*P1 for the second)
   v2f *w2 = lds + c2 * P2 + p2;            // + 16*q (+ 8 for the second)
-  v2f *r3 = lds + e * P2 + kl;             // M2 = 32: + c*P2;  M2 = 64: + (4c')*P2 and + (4c' + 2)*P2
-  const v2f *tw2 = lds_tw2 + c2;           // + q*M2
-  // output o of this thread is bin j = jbase + 256 o  (M2 = 64: o = r' + 16 h is block r = o + 32 e)
-  const uint32_t jbase = kl + 8192u * e;
-  const uint32_t st_voff = jbase * 4u;
+  v2f *r3 = lds + t;                       // + c*P2
+  const v2f *tw2 = lds_tw2 + c2;           // + 32 q
+  const uint32_t st_voff = t * 4u;         // output r of this thread is bin j = t + 256 r
 
   uint32_t keepmask = 0;  // K5 mask of this thread's 32 bins (process.cpp:46-52)
   if (HITS) {
 #pragma unroll
     for (int r = 0; r < 32; r++) {
-      const uint32_t j = jbase + 256u * r;
+      const uint32_t j = t + 256u * r;
       const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
       const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
       keepmask |= keep ? (1u << r) : 0u;
@@ -1107,24 +779,10 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
   uint32_t par = 0;
   uint32_t prev = 0xffffffffu;  // the buffer whose recorders may still be running
 
-#if SCN_STAMPS
-  uint32_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t stamp_hit_cyc = 0, stamp_hit_n = 0;  // cycles wave 0 spent in scn_record_hits, and how often it went in
-  uint32_t stamp_prev = (uint32_t)__builtin_readcyclecounter();
-  const uint32_t stamp_t0 = (uint32_t)wall_clock64();  // 100 MHz
-  uint32_t stamp_hw;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(stamp_hw));
-#endif
   uint32_t buf = blockIdx.x;
   uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
   while (buf < args.n_buffers) {
-    SCN_STAMP(0);  // previous buffer's hit recording + loop back
     const bool more = nxt < args.n_buffers;
-    if (PFN < 16) {  // the part of this buffer that was not prefetched (float input at 16384 points: registers)
-      const __amdgpu_buffer_rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N),
-                                                  SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
-      load_group(rc, PFN, 16);
-    }
     // ---- K1 + K2 ----
     int dc_re = 0, dc_im = 0;
     if (DC) {
@@ -1158,57 +816,28 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
       va[a] = L::conv(raw[2 * a], dc_re, dc_im, 1.0f) * win[2 * a];
       vb[a] = L::conv(raw[2 * a + 1], dc_re, dc_im, 1.0f) * win[2 * a + 1];
     }
-    SCN_STAMP(1);  // wait for this buffer's samples (+ convert, window)
     // take the buffer after the next one (behind the convert, see scn_fft_kernel); needed at the end of the iteration
     uint32_t taken = 0;
     if (DYN && t == 0 && more) taken = wq_take();
     // next buffer of this workgroup, branch-free (zero records past the end), in three groups
     const __amdgpu_buffer_rsrc_t rn =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N),
-                  (more && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
-    auto prefetch = [&](int a_lo, int a_hi) { load_group(rn, a_lo, a_hi); };  // groups of inputs a: two samples each
-    prefetch(0, PF0);
-    SCN_STAMP(2);  // issue of the first group of the next buffer's loads
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N), more ? L::kBufBytes(N) : 0u);
+    load_group(rn, 0, 6);
 
-    // ---- pass 1: virtual threads t and t + 256 ----
-    if (PAIR) {
-      fft16(va);
-      fft16(vb);
+    // ---- pass 1: virtual threads tau0 and tau0 + 1 ----
+    fft16(va);
+    fft16(vb);
 #pragma unroll
-      for (int p = 0; p < 16; p++) {
-        cf ya = va[OUT16(p)], yb = vb[OUT16(p)];
-        if (p) {
-          ya = cmul(ya, tw1a[p]);
-          if constexpr (TW1B) {
-            yb = cmul(yb, tw1b[p]);
-          } else {
-            const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * p / (double)N);
-            const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * p / (double)N);
-            yb = cmul(yb, cmul(tw1a[p], cf{cr, -sr}));
-          }
-        }
-        typedef float v4f_t __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<v4f_t *>(w1 + p * P1) = v4f_t{ya.x, ya.y, yb.x, yb.y};  // slots tau0, tau0 + 1: 16-byte aligned (P1 even)
+    for (int p = 0; p < 16; p++) {
+      cf ya = va[OUT16(p)], yb = vb[OUT16(p)];
+      if (p) {
+        ya = cmul(ya, tw1a[p]);
+        yb = cmul(yb, tw1b[p]);
       }
-    } else {
-      fft16(va);
-#pragma unroll
-      for (int p = 0; p < 16; p++) {
-        cf y = va[OUT16(p)];
-        if (p) y = cmul(y, tw1a[p]);
-        w1[p * P1] = to_v2f(y);
-      }
-      fft16(vb);
-#pragma unroll
-      for (int p = 0; p < 16; p++) {
-        cf y = vb[OUT16(p)];
-        if (p) y = cmul(y, tw1b[p]);
-        w1[p * P1 + T] = to_v2f(y);
-      }
+      typedef float v4f_t __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<v4f_t *>(w1 + p * P1) = v4f_t{ya.x, ya.y, yb.x, yb.y};  // slots tau0, tau0 + 1: 16-byte aligned (P1 even)
     }
-    SCN_STAMP(3);  // pass 1 + exchange-1 writes
-    __syncthreads();
-    SCN_STAMP(4);  // barrier 1
+    __syncthreads();  // barrier 1
     if (HITS) {
       if (t == 0 && prev != 0xffffffffu) {  // every wave is past the barrier: the previous buffer's recorders are done
         args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
@@ -1216,159 +845,62 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
         lds_hits[par ^ 1] = 0;
       }
     }
-    prefetch(PF0, PF1);
+    load_group(rn, 6, 11);
 
     // ---- pass 2: virtual threads (p2, c2) and (p2 + 8, c2) ----
 #pragma unroll
     for (int b = 0; b < 16; b++) {
-      va[b] = from_v2f(r1[b * M2]);
-      vb[b] = from_v2f(r1[b * M2 + 8 * P1]);
+      va[b] = from_v2f(r1[b * 32]);
+      vb[b] = from_v2f(r1[b * 32 + 8 * P1]);
     }
     fft16(va);
     fft16(vb);
 #pragma unroll
     for (int q = 1; q < 16; q++) {
-      const cf w = from_v2f(tw2[q * M2]);
+      const cf w = from_v2f(tw2[q * 32]);
       va[OUT16(q)] = cmul(va[OUT16(q)], w);
       vb[OUT16(q)] = cmul(vb[OUT16(q)], w);
     }
-    SCN_STAMP(5);  // exchange-1 reads + pass 2 + twiddles (+ second load group)
-    __syncthreads();  // every exchange-1 read done before the area is re-used
-    SCN_STAMP(6);  // barrier 2
-    prefetch(PF1, PFN);
+    __syncthreads();  // barrier 2: every exchange-1 read done before the area is re-used
+    load_group(rn, 11, 16);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       w2[q * 16] = to_v2f(va[OUT16(q)]);
       w2[q * 16 + 8] = to_v2f(vb[OUT16(q)]);
     }
-    SCN_STAMP(7);  // exchange-2 writes (+ third load group)
-    __syncthreads();
-    SCN_STAMP(8);  // barrier 3
+    __syncthreads();  // barrier 3
 
-    // K4: the thread's 32 LINEAR powers stay in `pw` (bin j = jbase + 256 r at index r) for the hit path; the spectrum gets the
-    // dB map of scn_device.h -- product form inline, exact form stored over it for the strong bins in the waves that hold one
-    // (see scn_fft_kernel)
+    // ---- pass 3: one 32-point DFT over c per thread: even c -> va, odd c -> vb.  K4: the thread's 32 LINEAR powers stay in
+    // `pw` (bin j = t + 256 r at index r) for the hit path; the spectrum gets the dB map of scn_device.h -- product form
+    // inline, exact form stored over it for the strong bins in the waves that hold one (see scn_fft_kernel) ----
     v32f pw;
     float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the largest power of each group of eight outputs (max ignores NaN)
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
-    if constexpr (P3D) {
-      // ---- pass 3 in DOUBLE (16384 points).  A strong tone's partial sums are largest in the last pass, and their float
-      // rounding errors land on the 63 other bins of the tone's 64-point column (k = kl + 256 r): with peak / mean power of
-      // 3e3 .. 7e3 that is the 0.7e-5 .. 1.05e-5 tail of the parity metric at this size -- ANY float32 FFT shows it
-      // (scripts/emul_fused.py: this decomposition and pocketfft's have the same tail).  Evaluated in double from the float
-      // exchange-2 values, the last six of the fourteen radix-2 levels stop contributing: the tail shrinks 3x.  v_add_f64 /
-      // v_fma_f64 issue at 0.85x / 0.7x the float rate on gfx950 (scripts/ubench/f64_rate.hip), so the price is the
-      // conversions and ~1.3x on a third of the arithmetic.
-      // Lane half e holds the 32 values x[c''] = L2(c = 2c'' + e, kl).  Decimation in frequency, so that only 16 double
-      // values are live at a time: A[c''] = x[c''] + x[c''+16] -> DFT16 -> Y_e[2 rho];  B[c''] = (x[c''] - x[c''+16]) W_32^c''
-      // -> DFT16 -> Y_e[2 rho + 1].  Then X[r''] = Y_0[r''] + W_64^r'' Y_1[r''] (lower half), X[r'' + 32] = Y_0 - W Y_1 (upper):
-      // only |X|^2 is needed, so BOTH halves rotate by half the angle -- Y_0 conj(W_128^r'') and Y_1 W_128^r'' (same cosine,
-      // the sine's sign by lane half) -- and one v_permlane32_swap per 32-bit half of each component finishes it.
-      // (every twiddle below is a wave-uniform compile-time constant -- scalar operands, no registers: the lane halves differ
-      // by ONE sign flip per value instead.  |conj(h) Y_0 +- h Y_1| = |conj(h conj(Y_0)) +- h Y_1|: the lower half conjugates
-      // its value, both halves multiply by h = W_128^r'', and the conjugation of the lower half's product is folded into the
-      // signs of the last step.)
-      const unsigned conj_lo = e ? 0u : 0x80000000u;  // xor mask of the imaginary part's high word: lower half conjugates
-      const double sgn_x = e ? -1.0 : 1.0;             // upper half holds X[r'' + 32] = Y_0 - W Y_1
-      const double sgn_y = -sgn_x;
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db) ? 4u * N : 0u);
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        cd vd[16];
+    for (int c = 0; c < 16; c++) {
+      va[c] = from_v2f(r3[(2 * c) * P2]);
+      vb[c] = from_v2f(r3[(2 * c + 1) * P2]);
+    }
+    fft16(va);
+    fft16(vb);
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-          const cd x0 = to_cd(r3[(2 * c) * P2]), x1 = to_cd(r3[(2 * (c + 16)) * P2]);
-          if (h == 0) {
-            vd[c] = x0 + x1;
-          } else {
-            const cd dlt = x0 - x1;
-            const double cr = __builtin_cos(6.283185307179586476925286766559 * c / 32.0), sr = __builtin_sin(6.283185307179586476925286766559 * c / 32.0);
-            vd[c] = c ? cmul_d(dlt, cr, -sr) : dlt;
-          }
-        }
-        fft16_d(vd);
-#pragma unroll
-        for (int rho = 0; rho < 16; rho++) {
-          const int r = 2 * rho + h;  // r'': this lane's output block is r + 32 e
-          cd y = vd[OUT16(rho)];
-          unsigned long long by = __builtin_bit_cast(unsigned long long, y.y);
-          if (r) {
-            by ^= (unsigned long long)conj_lo << 32;
-            y.y = __builtin_bit_cast(double, by);
-            const double cr = __builtin_cos(6.283185307179586476925286766559 * r / 128.0), sr = __builtin_sin(6.283185307179586476925286766559 * r / 128.0);
-            y = cmul_d(y, cr, -sr);
-            by = __builtin_bit_cast(unsigned long long, y.y);
-          }
-          // both halves' values into both halves: [0] = the lower half's (A = h conj(Y_0); r'' = 0: Y_0 itself), [1] = the upper half's (B = h Y_1)
-          const unsigned long long bx = __builtin_bit_cast(unsigned long long, y.x);
-          auto sxl = __builtin_amdgcn_permlane32_swap((unsigned)bx, (unsigned)bx, false, false);
-          auto sxh = __builtin_amdgcn_permlane32_swap((unsigned)(bx >> 32), (unsigned)(bx >> 32), false, false);
-          auto syl = __builtin_amdgcn_permlane32_swap((unsigned)by, (unsigned)by, false, false);
-          auto syh = __builtin_amdgcn_permlane32_swap((unsigned)(by >> 32), (unsigned)(by >> 32), false, false);
-          const double ax = __builtin_bit_cast(double, ((unsigned long long)(unsigned)sxh[0] << 32) | (unsigned)sxl[0]);
-          const double bxx = __builtin_bit_cast(double, ((unsigned long long)(unsigned)sxh[1] << 32) | (unsigned)sxl[1]);
-          const double ay = __builtin_bit_cast(double, ((unsigned long long)(unsigned)syh[0] << 32) | (unsigned)syl[0]);
-          const double byy = __builtin_bit_cast(double, ((unsigned long long)(unsigned)syh[1] << 32) | (unsigned)syl[1]);
-          // X = conj(A) +- B (r'' = 0: A +- B): real parts A.x +- B.x; imaginary parts -A.y +- B.y, whose overall sign |X|^2 does not see
-          const double xr = __builtin_fma(bxx, sgn_x, ax), xi = __builtin_fma(byy, r ? sgn_y : sgn_x, ay);
-          const float q = (float)__builtin_fma(xi, xi, xr * xr);
-          pw[r] = q;
-          gmax[r >> 3] = fmaxf(gmax[r >> 3], q);
-          if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 1024u * r, AUX_ST);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads and conversions out of the first half's live range
+    for (int r = 0; r < 16; r++) {  // X[r], X[r + 16] = E[r] +- W_32^r O[r]
+      const cf ev = va[OUT16(r)];
+      cf od = vb[OUT16(r)];
+      if (r) {
+        const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
+        const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
+        od = cmul(od, cf{cr, -sr});
       }
-    } else {
-      // ---- pass 3.  M2 = 32: one 32-point DFT over c per thread: even c -> va, odd c -> vb.
-      //             M2 = 64: this lane's half of a 64-point DFT: c = 4c' + e -> va, c = 4c' + e + 2 -> vb ----
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        va[c] = from_v2f(r3[(M2 == 64 ? 4 * c : 2 * c) * P2]);
-        vb[c] = from_v2f(r3[(M2 == 64 ? 4 * c + 2 : 2 * c + 1) * P2]);
-      }
-      fft16(va);
-      fft16(vb);
-      // U, V = E[r'] +- W_32^r' O[r']: the outputs X[r'], X[r' + 16] themselves (M2 = 32), or this lane's share of them
-      // (M2 = 64: one exchange across the wave's halves finishes the radix-4 step)
-      const float sel = e ? 1.0f : 0.0f, sgn = e ? -1.0f : 1.0f;  // (M2 = 64)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const cf ev = va[OUT16(r)];
-        cf od = vb[OUT16(r)];
-        if (r) {
-          const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
-          const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
-          od = cmul(od, cf{cr, -sr});
-        }
-        cf x0 = ev + od, x1 = ev - od;
-        if constexpr (M2 == 64) {
-          if (r) {  // W_64^r' in the odd half, 1 in the even half (branch-free: both halves run the same code)
-            const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 64.0);
-            const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 64.0);
-            const cf w = cf{e ? cr : 1.0f, -sr * sel};
-            x0 = cmul(x0, w);
-            x1 = cmul(x1, w);
-          }
-          // v_permlane32_swap on two copies of a register leaves the lower half's value in [0] and the upper half's in [1], in BOTH halves
-          auto ax = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0.x), __builtin_bit_cast(unsigned, x0.x), false, false);
-          auto ay = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0.y), __builtin_bit_cast(unsigned, x0.y), false, false);
-          auto bx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x1.x), __builtin_bit_cast(unsigned, x1.x), false, false);
-          auto by = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x1.y), __builtin_bit_cast(unsigned, x1.y), false, false);
-          const cf u0 = cf{__builtin_bit_cast(float, (unsigned)ax[0]), __builtin_bit_cast(float, (unsigned)ay[0])};
-          const cf u1 = cf{__builtin_bit_cast(float, (unsigned)ax[1]), __builtin_bit_cast(float, (unsigned)ay[1])};
-          const cf v0 = cf{__builtin_bit_cast(float, (unsigned)bx[0]), __builtin_bit_cast(float, (unsigned)by[0])};
-          const cf v1 = cf{__builtin_bit_cast(float, (unsigned)bx[1]), __builtin_bit_cast(float, (unsigned)by[1])};
-          x0 = cf{__builtin_fmaf(u1.x, sgn, u0.x), __builtin_fmaf(u1.y, sgn, u0.y)};    // U_0 +- W U_1
-          x1 = cf{__builtin_fmaf(v1.y, sgn, v0.x), __builtin_fmaf(v1.x, -sgn, v0.y)};   // V_0 -+ i W V_1
-        }
-        const float p0 = power_of(x0), p1 = power_of(x1);
-        pw[r] = p0;
-        pw[r + 16] = p1;
-        gmax[r >> 3] = fmaxf(gmax[r >> 3], p0);
-        gmax[2 + (r >> 3)] = fmaxf(gmax[2 + (r >> 3)], p1);
-        if constexpr (SPEC) {
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p0)), rout, st_voff, 1024u * r, AUX_ST);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p1)), rout, st_voff, 1024u * (r + 16), AUX_ST);
-        }
+      const cf x0 = ev + od, x1 = ev - od;
+      const float p0 = power_of(x0), p1 = power_of(x1);
+      pw[r] = p0;
+      pw[r + 16] = p1;
+      gmax[r >> 3] = fmaxf(gmax[r >> 3], p0);
+      gmax[2 + (r >> 3)] = fmaxf(gmax[2 + (r >> 3)], p1);
+      if constexpr (SPEC) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p0)), rout, st_voff, 1024u * r, AUX_ST);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p1)), rout, st_voff, 1024u * (r + 16), AUX_ST);
       }
     }
 
@@ -1390,53 +922,18 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
         }
       }
     }
-    SCN_STAMP(9);  // exchange-2 reads + pass 3 + dB + stores issued
     if (t == 0) lds_next[0] = !more ? 0xffffffffu : DYN ? wq_buffer(taken) : nxt + gridDim.x;
-    __syncthreads();  // exchange area free again; lds_next visible
-    SCN_STAMP(10);  // barrier 4
-#if SCN_STAMPS
-    stamp_acc[11] += 1;
-#endif
+    __syncthreads();  // barrier 4: exchange area free again; lds_next visible
     const uint32_t after = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_next[0]);
     if (HITS) {
-      if (__ballot(pmax > args.p_lo)) {
-#if SCN_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        const uint32_t h0_ = (uint32_t)__builtin_readcyclecounter();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#if SCN_HITS_LANES_W
-        scn_record_hits_lanes<32, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
-#else
-        scn_record_hits<32, false, true, SCN_ONE_ATOMIC_W>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (jbase + 256u * (uint32_t)r) ^ (N / 2); });
-#endif
-#if SCN_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        stamp_hit_cyc += (uint32_t)__builtin_readcyclecounter() - h0_;
-        stamp_hit_n += 1;
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
+      if (__ballot(pmax > args.p_lo))
+        scn_record_hits_lanes<32, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 256u * (uint32_t)r) ^ (N / 2); });
       prev = buf;
       par ^= 1;
     }
     buf = nxt;
     nxt = after;
   }
-#if SCN_STAMPS
-  if (t == 0 && blockIdx.x < args.n_buffers && args.power_db) {
-    __builtin_amdgcn_s_waitcnt(0);
-    for (int i = 0; i < 12; i++) args.power_db[(size_t)blockIdx.x * N + i] = (float)stamp_acc[i];
-    args.power_db[(size_t)blockIdx.x * N + 12] = (float)(stamp_t0 & 0xffffffu);
-    args.power_db[(size_t)blockIdx.x * N + 13] = (float)((uint32_t)wall_clock64() & 0xffffffu);
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    args.power_db[(size_t)blockIdx.x * N + 14] = (float)(((xcc & 0xfu) << 8) | ((stamp_hw >> 8) & 0xffu));
-    args.power_db[(size_t)blockIdx.x * N + 15] = (float)(stamp_entry & 0xffffffu);
-    args.power_db[(size_t)blockIdx.x * N + 16] = (float)stamp_hit_cyc;
-    args.power_db[(size_t)blockIdx.x * N + 17] = (float)stamp_hit_n;
-  }
-#endif
   if (HITS) {
     __syncthreads();  // last buffer's recorders done
     if (t == 0 && prev != 0xffffffffu) {
@@ -1445,10 +942,16 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
     }
   }
 }
+
 }  // namespace
 
+template <int KIND, bool DC, bool HITS, bool SPEC>
+__global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
+  scn_fft8k_body<KIND, DC, HITS, SPEC>(args);
+}
+
 // ------------------------------------------------------------------------------------
-// 16384 points as 32 x 16 x 32 (round 3): 512 threads x 32 points, one workgroup per CU.
+// 16384 points as 32 x 16 x 32: 512 threads x 32 points, one workgroup per CU (scn_fft16k2_kernel).
 //
 //   n = 512 a + 32 b + c          k = p + 32 q + 512 r          a, p, c, r in [0, 32)   b, q in [0, 16)
 //   pass 1  thread tau = 32 b + c:  32-pt DFT over a of x[512 a + tau] w[..] (two 16-pt DFTs + one radix-2 step, in
@@ -1456,27 +959,21 @@ __device__ __forceinline__ void scn_fft_wide_body(const ScnFftArgs &args) {
 //   pass 2  threads (p, c) and (p + 16, c):  16-pt DFT over b -> * W_512^(c q) -> LDS    L2(c, kl) = 513 c + kl, kl = p + 32 q
 //   pass 3  thread kl:  32-pt DFT over c -> X[kl + 512 r], r = 0 .. 31 -- a WHOLE DFT per thread
 //
-// The first form (scn_fft_wide_body<64>: 16 x 16 x 64) shares its 64-point last pass between two lanes: a twiddle multiply
-// of every value by W_64^r', a v_permlane32_swap per register and a combining step -- 280 of its ~1700 VALU operations per
-// thread and buffer.  Here pass 1 takes the extra radix-2 level instead (one more twiddle-free step on values that are in
-// registers anyway): ~150 operations fewer, no cross-lane traffic, every output bin of a lane 512 apart.  All four LDS access
+// The first form (16 x 16 x 64, rounds 1-2; profiles/r03_experiments.md section 2) shared its 64-point last pass between two
+// lanes: a twiddle multiply of every value by W_64^r', a v_permlane32_swap per register and a combining step -- 280 of its
+// ~1700 VALU operations per thread and buffer.  Here pass 1 takes the extra radix-2 level instead (one more twiddle-free step
+// on values that are in registers anyway): ~150 operations fewer, no cross-lane traffic, every output bin of a lane 512 apart.  All four LDS access
 // patterns are conflict-free in the 16-lane groups a ds_*_b64 is served in (row pitch 513 on the transposed side).
 // Price: one virtual thread per lane in pass 1, so the samples arrive one per load (32 loads of 8 / 4 / 2 bytes per
 // lane instead of 16 of twice that).
-// With SCN_16K_P3_DOUBLE pass 3 runs in double (decimation in frequency, 16 double values live at a time): the parity
-// metric's tail at this size is the float rounding of a strong tone's partial sums in the LAST pass, which lands on the 31
-// other bins of the tone's column -- any float32 FFT shows it (scripts/emul_fused.py) -- and goes away 3x when the last five
-// radix-2 levels are exact.  v_add_f64 / v_fma_f64 issue at 0.85x / 0.7x the float rate (scripts/ubench/f64_rate.hip).
+// Pass 3 runs in DOUBLE (decimation in frequency, 16 double values live at a time): the parity metric's tail at this size
+// is the float rounding of a strong tone's partial sums in the LAST pass, which lands on the 31 other bins of the tone's
+// column -- any float32 FFT shows it (scripts/emul_fused.py) -- and goes away 3x when the last five radix-2 levels are exact.
+// v_add_f64 / v_fma_f64 issue at 0.85x / 0.7x the float rate (scripts/ubench/f64_rate.hip).  Measured on MI355X, 3072
+// strong-tone buffers per run (scripts/acc16k.py) and us per 2048-buffer launch, float pass 3 -> double: parity metric max
+// 4.9e-6 .. 7.5e-6 -> 2.9e-6 .. 4.0e-6, p99 4.0e-6 -> 2.2e-6, median 1.11e-6 -> 0.88e-6 (the float quantisation of the dB value
+// itself); cfloat 93.5 -> 100.2 us, int16 75.6 -> 88.1.  Parity comes first, so double is the product.
 // ------------------------------------------------------------------------------------
-#ifndef SCN_16K_V2
-#define SCN_16K_V2 1
-#endif
-#ifndef SCN_16K2_FLOAT_PFN
-#define SCN_16K2_FLOAT_PFN 16  // float input: how many of a buffer's 32 loads are prefetched across the previous buffer's passes
-#endif
-#ifndef SCN_16K2_INT_PFN
-#define SCN_16K2_INT_PFN 32
-#endif
 namespace {
 struct Geo16k2 {
   static constexpr uint32_t N = 16384, T = 512, P1 = 512, P2 = 513;
@@ -1485,11 +982,11 @@ struct Geo16k2 {
   static constexpr uint32_t WG_PER_CU = 1;
 };
 
+
 template <int KIND, bool DC, bool HITS, bool SPEC>
 __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
   static_assert(HITS || SPEC, "a kernel that reports nothing");
   typedef Geo16k2 G;
-  constexpr bool P3D = SCN_16K_P3_DOUBLE != 0;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
   constexpr uint32_t N = G::N, T = G::T, P1 = G::P1, P2 = G::P2;
@@ -1503,8 +1000,9 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
   const uint32_t t = threadIdx.x;
   const uint32_t lane = t & 63, wave = t >> 6;
   const uint32_t c2 = t & 31u, p2 = t >> 5;  // pass 2: (p2, c2) and (p2 + 16, c2), p2 < 16
-  // loads prefetched, in three groups (planar int16 is two loads and a pack per sample: beside the double-precision pass 3 only half)
-  constexpr int PFN = KIND == SCN_K_FLOAT_COMPLEX ? SCN_16K2_FLOAT_PFN : (P3D && KIND == SCN_K_SHORT) ? 16 : SCN_16K2_INT_PFN;
+  // how many of a buffer's 32 loads are prefetched across the previous buffer's passes, in three groups (float input: the
+  // registers; planar int16 is two loads and a pack per sample: beside the double-precision pass 3 only half)
+  constexpr int PFN = (KIND == SCN_K_FLOAT_COMPLEX || KIND == SCN_K_SHORT) ? 16 : 32;
   constexpr int PF0 = (3 * PFN) / 8, PF1 = (11 * PFN) / 16;
 
   // first buffer's samples first: raw[a] = x[512 a + t]
@@ -1516,14 +1014,14 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
   };
   if (blockIdx.x < args.n_buffers) {
     __amdgpu_buffer_rsrc_t r0 =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)blockIdx.x * L::kBufBytes(N), L::kBufBytes(N));
     load_group(r0, 0, PFN);
   }
-  // persistent constants: W_N^(t p), p = 1 .. 31 (table rows of 512, scn_tw1_layout), window taps.  With pass 3 in double only
-  // p = 1 .. 16 are kept and W_N^(t (p' + 16)) = W_N^(t p') W_N^(16 t) is formed per buffer: 15 more complex multiplies
-  // (+3 % of the kernel's arithmetic) buy the 30 registers the double-precision values of pass 3 need -- spilled instead,
-  // they cost 30 .. 90 % (scratch reloads at the top of every buffer).
-  constexpr int TWN = P3D ? 17 : 32;
+  // persistent constants: W_N^(t p) (table rows of 512, scn_tw1_layout), window taps.  Only p = 1 .. 16 are kept and
+  // W_N^(t (p' + 16)) = W_N^(t p') W_N^(16 t) is formed per buffer: 15 more complex multiplies (+3 % of the kernel's
+  // arithmetic) buy the 30 registers the double-precision values of pass 3 need -- spilled instead, they cost 30 .. 90 %
+  // (scratch reloads at the top of every buffer).
+  constexpr int TWN = 17;
   cf tw1[TWN];
 #pragma unroll
   for (int p = 1; p < TWN; p++) tw1[p] = from_v2f(args.tw1_table[(p - 1) * 512 + t]);
@@ -1559,7 +1057,7 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     const bool more = nxt < args.n_buffers;
     if (PFN < 32) {  // the part of this buffer that was not prefetched
       const __amdgpu_buffer_rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N),
-                                                  SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+                                                  L::kBufBytes(N));
       load_group(rc, PFN, 32);
     }
     // ---- K1 + K2 ----
@@ -1598,14 +1096,14 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     // next buffer of this workgroup, branch-free (zero records past the end), in three groups
     const __amdgpu_buffer_rsrc_t rn =
         make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(more ? nxt : buf) * L::kBufBytes(N),
-                  (more && !SCN_EXP_NO_LOADS) ? L::kBufBytes(N) : 0u);
+                  more ? L::kBufBytes(N) : 0u);
     load_group(rn, 0, PF0);
 
     // ---- pass 1: 32-point DFT over a: E, O = DFT16 of the even / odd samples, A[p'] = E + W_32^p' O, A[p' + 16] = E - W_32^p' O ----
     fft16(va);
     fft16(vb);
     cf tw16 = tw1[16];
-    if constexpr (P3D) asm volatile("" : "+v"(tw16.x), "+v"(tw16.y));  // opaque per buffer: or hipcc hoists the 15 products out of the loop and keeps them in registers
+    asm volatile("" : "+v"(tw16.x), "+v"(tw16.y));  // opaque per buffer: or hipcc hoists the 15 products out of the loop and keeps them in registers
 #pragma unroll
     for (int p = 0; p < 16; p++) {
       const cf ev = va[OUT16(p)];
@@ -1617,8 +1115,7 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
       }
       cf y0 = ev + od, y1 = ev - od;
       if (p) y0 = cmul(y0, tw1[p]);
-      if constexpr (P3D) y1 = cmul(y1, p ? cmul(tw1[p], tw16) : tw16);
-      else y1 = cmul(y1, tw1[p + 16]);
+      y1 = cmul(y1, p ? cmul(tw1[p], tw16) : tw16);
       w1[p * P1] = to_v2f(y0);
       w1[(p + 16) * P1] = to_v2f(y1);
     }
@@ -1660,73 +1157,39 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     v32f pw;
     float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t cand = 0;  // (HITS) this lane's candidate outputs, collected as they are produced
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db && !SCN_EXP_NO_STORES) ? 4u * N : 0u);
-    if constexpr (P3D) {
-      // decimation in frequency: A[c''] = x[c''] + x[c''+16] -> DFT16 -> X[2 rho];  B[c''] = (x[c''] - x[c''+16]) W_32^c'' -> DFT16 -> X[2 rho + 1]
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db) ? 4u * N : 0u);
+    // decimation in frequency: A[c''] = x[c''] + x[c''+16] -> DFT16 -> X[2 rho];  B[c''] = (x[c''] - x[c''+16]) W_32^c'' -> DFT16 -> X[2 rho + 1]
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        cd vd[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-          const cd x0 = to_cd(r3[c * P2]), x1 = to_cd(r3[(c + 16) * P2]);
-          if (h == 0) {
-            vd[c] = x0 + x1;
-          } else {
-            const cd dlt = x0 - x1;
-            const double cr = __builtin_cos(6.283185307179586476925286766559 * c / 32.0), sr = __builtin_sin(6.283185307179586476925286766559 * c / 32.0);
-            vd[c] = c ? cmul_d(dlt, cr, -sr) : dlt;
-          }
-        }
-        fft16_d(vd);
-#pragma unroll
-        for (int rho = 0; rho < 16; rho++) {
-          const int r = 2 * rho + h;
-          const cd x = vd[OUT16(rho)];
-          const float q = (float)__builtin_fma(x.y, x.y, x.x * x.x);
-          gmax[r >> 3] = fmaxf(gmax[r >> 3], q);
-          if constexpr (SPEC) {
-            const float d = db_fast(q);
-            pw[r] = d;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 2048u * r, AUX_ST);
-          } else {
-            pw[r] = q;
-            if constexpr (HITS && SCN_HITS_MASK_16K) cand |= q > args.p_lo ? (1u << r) : 0u;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads and conversions out of the first half's live range
-      }
-    } else {
+    for (int h = 0; h < 2; h++) {
+      cd vd[16];
 #pragma unroll
       for (int c = 0; c < 16; c++) {
-        va[c] = from_v2f(r3[(2 * c) * P2]);
-        vb[c] = from_v2f(r3[(2 * c + 1) * P2]);
-      }
-      fft16(va);
-      fft16(vb);
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const cf ev = va[OUT16(r)];
-        cf od = vb[OUT16(r)];
-        if (r) {
-          const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
-          const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
-          od = cmul(od, cf{cr, -sr});
-        }
-        const float p0 = power_of(ev + od), p1 = power_of(ev - od);
-        gmax[r >> 3] = fmaxf(gmax[r >> 3], p0);
-        gmax[2 + (r >> 3)] = fmaxf(gmax[2 + (r >> 3)], p1);
-        if constexpr (SPEC) {
-          const float d0 = db_fast(p0), d1 = db_fast(p1);
-          pw[r] = d0;
-          pw[r + 16] = d1;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d0), rout, st_voff, 2048u * r, AUX_ST);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), rout, st_voff, 2048u * (r + 16), AUX_ST);
+        const cd x0 = to_cd(r3[c * P2]), x1 = to_cd(r3[(c + 16) * P2]);
+        if (h == 0) {
+          vd[c] = x0 + x1;
         } else {
-          pw[r] = p0;
-          pw[r + 16] = p1;
-          if constexpr (HITS && SCN_HITS_MASK_16K) cand |= (p0 > args.p_lo ? (1u << r) : 0u) | (p1 > args.p_lo ? (1u << (r + 16)) : 0u);
+          const cd dlt = x0 - x1;
+          const double cr = __builtin_cos(6.283185307179586476925286766559 * c / 32.0), sr = __builtin_sin(6.283185307179586476925286766559 * c / 32.0);
+          vd[c] = c ? cmul_d(dlt, cr, -sr) : dlt;
         }
       }
+      fft16_d(vd);
+#pragma unroll
+      for (int rho = 0; rho < 16; rho++) {
+        const int r = 2 * rho + h;
+        const cd x = vd[OUT16(rho)];
+        const float q = (float)__builtin_fma(x.y, x.y, x.x * x.x);
+        gmax[r >> 3] = fmaxf(gmax[r >> 3], q);
+        if constexpr (SPEC) {
+          const float d = db_fast(q);
+          pw[r] = d;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 2048u * r, AUX_ST);
+        } else {
+          pw[r] = q;
+          if constexpr (HITS) cand |= q > args.p_lo ? (1u << r) : 0u;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads and conversions out of the first half's live range
     }
     const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
     if constexpr (SPEC) {
@@ -1751,11 +1214,7 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     __syncthreads();  // barrier 4: exchange area free again
     if (HITS) {
       if (__ballot(pmax > args.p_lo))
-#if SCN_HITS_LANES_16K
-        scn_record_hits_lanes<32, SPEC, false, !SPEC && SCN_HITS_MASK_16K != 0>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); }, cand);
-#else
-        scn_record_hits<32, SPEC, false, SCN_ONE_ATOMIC_16K>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); });
-#endif
+        scn_record_hits_lanes<32, SPEC, false, !SPEC>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 512u * (uint32_t)r) ^ (N / 2); }, cand);
       prev = buf;
       par ^= 1;
     }
@@ -1768,21 +1227,12 @@ __device__ __forceinline__ void scn_fft16k2_body(const ScnFftArgs &args) {
     }
   }
 }
+
 }  // namespace
 
 template <int KIND, bool DC, bool HITS, bool SPEC>
 __global__ __launch_bounds__(512, 2) void scn_fft16k2_kernel(ScnFftArgs args) {
   scn_fft16k2_body<KIND, DC, HITS, SPEC>(args);
-}
-
-template <int KIND, bool DC, bool HITS, bool SPEC>
-__global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
-  scn_fft_wide_body<32, KIND, DC, HITS, SPEC>(args);
-}
-
-template <int KIND, bool DC, bool HITS, bool SPEC>
-__global__ __launch_bounds__(512, 2) void scn_fft16k_kernel(ScnFftArgs args) {
-  scn_fft_wide_body<64, KIND, DC, HITS, SPEC>(args);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1801,7 +1251,7 @@ __global__ __launch_bounds__(256) void scn_time_domain_kernel(ScnTdArgs args) {
   const uint32_t N = args.n;
   for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
     __amdgpu_buffer_rsrc_t rin =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), SCN_EXP_NO_LOADS ? 0u : L::kBufBytes(N));
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), L::kBufBytes(N));
     int dc_re = 0, dc_im = 0;
     if (DC) {
       int sr = 0, si = 0;
@@ -1858,9 +1308,6 @@ __global__ __launch_bounds__(256) void scn_time_domain_kernel(ScnTdArgs args) {
 // per-sample form above (one workgroup per buffer, one sample per lane per load) left a pure streaming reduction at
 // 46-51 us per 33.5 M int16 samples and 77-93 us at 1024 points; this is the product path whenever N is a multiple
 // of 8 (every supported size).  Same arithmetic, sample by sample, through RawLoader<KIND>::ints / conv.
-#ifndef SCN_TD_WAVE
-#define SCN_TD_WAVE 1
-#endif
 template <int KIND, bool DC>
 __global__ __launch_bounds__(256) void scn_time_domain_wave_kernel(ScnTdArgs args) {
   typedef RawLoader<KIND> L;
@@ -1874,7 +1321,7 @@ __global__ __launch_bounds__(256) void scn_time_domain_wave_kernel(ScnTdArgs arg
   const uint32_t chunks = stream_bytes / 16u;
   for (uint32_t buf = gw; buf < args.n_buffers; buf += nw) {
     const __amdgpu_buffer_rsrc_t rin =
-        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * bytes, SCN_EXP_NO_LOADS ? 0u : bytes);
+        make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * bytes, bytes);
     // calls f(raw sample) for every sample of the buffer this lane is responsible for
     auto for_each_sample = [&](auto &&f) {
       for (uint32_t c0 = 0; c0 < chunks; c0 += 256u) {
@@ -1955,7 +1402,7 @@ hipError_t scn_launch_time_domain(int kind, bool dc, const ScnTdArgs &a, int num
     case SCN_K_BYTE_COMPLEX: k = dc ? scn_time_domain_kernel<SCN_K_BYTE_COMPLEX, true> : scn_time_domain_kernel<SCN_K_BYTE_COMPLEX, false>; break;
     default: return hipErrorInvalidValue;
   }
-  if (SCN_TD_WAVE && a.n % 8u == 0) {  // one wave per buffer, 16-byte loads
+  if (a.n % 8u == 0) {  // one wave per buffer, 16-byte loads
     switch (kind) {
       case SCN_K_FLOAT_COMPLEX: k = scn_time_domain_wave_kernel<SCN_K_FLOAT_COMPLEX, false>; break;
       case SCN_K_SHORT_COMPLEX: k = dc ? scn_time_domain_wave_kernel<SCN_K_SHORT_COMPLEX, true> : scn_time_domain_wave_kernel<SCN_K_SHORT_COMPLEX, false>; break;
@@ -2046,145 +1493,78 @@ static void (*pick_mode(bool dc, bool hits, bool spec))(ScnFftArgs) {
   if (spec) return dc ? K<true, true, true>::fn : K<false, true, true>::fn;
   return dc ? K<true, true, false>::fn : K<false, true, false>::fn;
 }
-template <int M, int KIND>
-struct NarrowK {
-  template <bool DC, bool HITS, bool SPEC>
-  struct T {
-    static constexpr void (*fn)(ScnFftArgs) = scn_fft_kernel<M, KIND, DC, HITS, SPEC>;
+// the kernel families: FAMILY<KIND>::T<DC, HITS, SPEC>::fn, with the family's geometry (threads, LDS, workgroups per CU,
+// buffers per workgroup iteration)
+template <int M>
+struct NarrowFamily {
+  typedef Geo<M> G;
+  static constexpr uint32_t THREADS = G::T, SLOTS = 1;
+  template <int KIND>
+  struct K {
+    template <bool DC, bool HITS, bool SPEC>
+    struct T {
+      static constexpr void (*fn)(ScnFftArgs) = scn_fft_kernel<M, KIND, DC, HITS, SPEC>;
+    };
   };
 };
-template <int KIND>
-struct Wide8K {
-  template <bool DC, bool HITS, bool SPEC>
-  struct T {
-    static constexpr void (*fn)(ScnFftArgs) = scn_fft8k_kernel<KIND, DC, HITS, SPEC>;
+template <int M>
+struct SmallFamily {
+  typedef GeoSmall<M> G;
+  static constexpr uint32_t THREADS = 256, SLOTS = G::SLOTS;
+  template <int KIND>
+  struct K {
+    template <bool DC, bool HITS, bool SPEC>
+    struct T {
+      static constexpr void (*fn)(ScnFftArgs) = scn_fft_small_kernel<M, KIND, DC, HITS, SPEC>;
+    };
   };
 };
-template <int KIND>
-struct Wide16K {
-  // (no hits-only specialisation at 16384 points: without the store instructions hipcc's allocation of this kernel's 256
-  // registers falls apart -- 42 .. 75 VGPRs of persistent twiddles and window taps spilled and reloaded per buffer -- so a
-  // hits-only plan runs the spectrum + hits kernel with a zero-record store descriptor, as all sizes did before round 3)
-  template <bool DC, bool HITS, bool SPEC>
-  struct T {
-    static constexpr void (*fn)(ScnFftArgs) = scn_fft16k_kernel<KIND, DC, HITS, HITS ? true : SPEC>;
+struct Family8k {
+  typedef Geo8k G;
+  static constexpr uint32_t THREADS = G::T, SLOTS = 1;
+  template <int KIND>
+  struct K {
+    template <bool DC, bool HITS, bool SPEC>
+    struct T {
+      static constexpr void (*fn)(ScnFftArgs) = scn_fft8k_kernel<KIND, DC, HITS, SPEC>;
+    };
+  };
+};
+struct Family16k {
+  typedef Geo16k2 G;
+  static constexpr uint32_t THREADS = G::T, SLOTS = 1;
+  template <int KIND>
+  struct K {
+    template <bool DC, bool HITS, bool SPEC>
+    struct T {
+      static constexpr void (*fn)(ScnFftArgs) = scn_fft16k2_kernel<KIND, DC, HITS, SPEC>;
+    };
   };
 };
 
-template <int M, int KIND>
+template <class F, int KIND>
 static hipError_t launch_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
-  typedef Geo<M> G;
-  void (*k)(ScnFftArgs) = pick_mode<NarrowK<M, KIND>::template T>(dc, hits, spec);
+  typedef typename F::G G;
+  void (*k)(ScnFftArgs) = pick_mode<F::template K<KIND>::template T>(dc, hits, spec);
   if (G::LDS_BYTES > 65536u) {
     // > 64 KiB of dynamic LDS needs the opt-in; it is per function AND per device, and a process may
     // drive several GPUs (one plan per consumer thread), so it is simply set on every launch
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)G::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
   }
+  const uint32_t groups = (a.n_buffers + F::SLOTS - 1u) / F::SLOTS;
   int grid = num_cus * (int)G::WG_PER_CU;  // one resident wave of persistent workgroups
-  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
-  return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
-}
-
-template <int M>
-static hipError_t launch_size(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
-  switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_kind<M, SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT_COMPLEX: return launch_kind<M, SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_kind<M, SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_kind<M, SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-template <int M2, void (*(*PICK)(bool, bool, bool))(ScnFftArgs)>
-static hipError_t launch_wide(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
-  typedef GeoWide<M2> G;
-  void (*k)(ScnFftArgs) = PICK(dc, hits, spec);
-  // > 64 KiB of dynamic LDS: opt-in per function and per device, set on every launch (see launch_kind)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  int grid = num_cus * (int)G::WG_PER_CU;
-  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
-  return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
-}
-template <int KIND>
-static hipError_t launch_8k_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
-  return launch_wide<32, pick_mode<Wide8K<KIND>::template T>>(a, dc, hits, spec, num_cus, s, stop);
-}
-template <int KIND>
-struct Wide16K2 {
-  template <bool DC, bool HITS, bool SPEC>
-  struct T {
-    static constexpr void (*fn)(ScnFftArgs) = scn_fft16k2_kernel<KIND, DC, HITS, SPEC>;
-  };
-};
-template <int KIND>
-static hipError_t launch_16k_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
-#if SCN_16K_V2
-  typedef Geo16k2 G;
-  void (*k)(ScnFftArgs) = pick_mode<Wide16K2<KIND>::template T>(dc, hits, spec);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  int grid = num_cus * (int)G::WG_PER_CU;
-  if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
-  return launch_with_stop(k, grid, G::T, G::LDS_BYTES, s, stop, a);
-#else
-  return launch_wide<64, pick_mode<Wide16K<KIND>::template T>>(a, dc, hits, spec, num_cus, s, stop);
-#endif
-}
-static hipError_t launch_16k(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
-  switch (kind) {
-    // us per 2048-buffer launch, scn_fft_kernel<64> -> wide form: integer formats 94.8 -> 88.5 (scripts/wide16k_check.sh); float
-    // input 111.5 -> 101.8 with HALF of a buffer prefetched (its 64 prefetch registers do not fit beside the lane-pair step:
-    // 113 us with all 16 two-sample loads prefetched and 22 VGPRs spilled; 0 / 4 / 6 / 8 / 10 / 12 / 14 / 16 prefetched:
-    // 110.9 / 107.3 / 105.9 / 101.8 / 105.7 / 108.5 / 107.1 / 113.1, scripts/wide16k_float_check.sh)
-#if SCN_WIDE_16384_FLOAT
-    case SCN_K_FLOAT_COMPLEX: return launch_16k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
-#else
-    case SCN_K_FLOAT_COMPLEX: return launch_size<64>(kind, false, hits, spec, args, num_cus, stream, stop);
-#endif
-    case SCN_K_SHORT_COMPLEX: return launch_16k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_16k_kind<SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_16k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    default: return hipErrorInvalidValue;
-  }
-}
-static hipError_t launch_8k(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
-  switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_8k_kind<SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT_COMPLEX: return launch_8k_kind<SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_8k_kind<SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_8k_kind<SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-template <int M, int KIND>
-struct SmallK {
-  template <bool DC, bool HITS, bool SPEC>
-  struct T {
-    static constexpr void (*fn)(ScnFftArgs) = scn_fft_small_kernel<M, KIND, DC, HITS, SPEC>;
-  };
-};
-template <int M, int KIND>
-static hipError_t launch_small_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
-  typedef GeoSmall<M> G;
-  void (*k)(ScnFftArgs) = pick_mode<SmallK<M, KIND>::template T>(dc, hits, spec);
-  const uint32_t groups = (a.n_buffers + G::SLOTS - 1u) / G::SLOTS;
-  int grid = num_cus * (int)G::WG_PER_CU;
   if ((uint32_t)grid > groups) grid = (int)groups;
-  return launch_with_stop(k, grid, 256u, G::LDS_BYTES, s, stop, a);
+  return launch_with_stop(k, grid, F::THREADS, G::LDS_BYTES, s, stop, a);
 }
-template <int M>
-static hipError_t launch_small(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
-  if ((uint64_t)args.n_buffers * 256u * M * 8u > 0xffffffffull) return hipErrorInvalidValue;  // (one descriptor spans SLOTS buffers only: never near)
+
+template <class F>
+static hipError_t launch_family(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_small_kind<M, SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT_COMPLEX: return launch_small_kind<M, SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_small_kind<M, SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_small_kind<M, SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_FLOAT_COMPLEX: return launch_kind<F, SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_kind<F, SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_kind<F, SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_kind<F, SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }
@@ -2193,22 +1573,16 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, bool spec, c
                           hipStream_t stream, hipEvent_t stop) {
   if (!hits && !spec) return hipErrorInvalidValue;
   if (args.n_buffers == 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
+  // (256 / 512 points: one descriptor spans a workgroup's SLOTS buffers only, but the per-lane offsets are 32-bit)
+  if (n < 1024 && (uint64_t)args.n_buffers * n * 8u > 0xffffffffull) return hipErrorInvalidValue;
   switch (n) {
-    case 256: return launch_small<1>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 512: return launch_small<2>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 1024: return launch_size<4>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 2048: return launch_size<8>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 4096: return launch_size<16>(kind, dc, hits, spec, args, num_cus, stream, stop);
-#if SCN_WIDE_8192
-    case 8192: return launch_8k(kind, dc, hits, spec, args, num_cus, stream, stop);
-#else
-    case 8192: return launch_size<32>(kind, dc, hits, spec, args, num_cus, stream, stop);  // the 512-thread form (variant build)
-#endif
-#if SCN_WIDE_16384
-    case 16384: return launch_16k(kind, dc, hits, spec, args, num_cus, stream, stop);
-#else
-    case 16384: return launch_size<64>(kind, dc, hits, spec, args, num_cus, stream, stop);  // the 1024-thread form (variant build)
-#endif
+    case 256: return launch_family<SmallFamily<1>>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 512: return launch_family<SmallFamily<2>>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 1024: return launch_family<NarrowFamily<4>>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 2048: return launch_family<NarrowFamily<8>>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 4096: return launch_family<NarrowFamily<16>>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 8192: return launch_family<Family8k>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 16384: return launch_family<Family16k>(kind, dc, hits, spec, args, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }
@@ -2218,7 +1592,6 @@ bool scn_fft_size_supported(uint32_t n) { return n == 256 || n == 512 || n == 10
 // layout of ScnFftArgs::tw1_table for size n: `rows` rows of `threads` entries, row p-1 = W_n^(t p): 15 rows of n/16 for the
 // 16 x 16 x M kernels, 31 rows of 512 for the 32 x 16 x 32 form of 16384 points
 void scn_tw1_layout(uint32_t n, uint32_t *rows, uint32_t *threads) {
-  const bool v2 = n == 16384 && SCN_16K_V2 != 0 && SCN_WIDE_16384 != 0;
-  *rows = v2 ? 31u : 15u;
-  *threads = v2 ? 512u : n / 16u;
+  *rows = n == 16384 ? 31u : 15u;
+  *threads = n == 16384 ? 512u : n / 16u;
 }

@@ -24,29 +24,13 @@
 
 #include "scn_device.h"
 
-#ifndef SCN_WELCH_AUX_IN
-#define SCN_WELCH_AUX_IN 0  // cache policy of the input stream loads (each sample is read by two overlapping segments)
-#endif
-
-#ifndef SCN_EXP_WELCH_NO_ST
-#define SCN_EXP_WELCH_NO_ST 0  // timing experiments only: zero-record descriptors drop the column kernel's stores / loads
-#endif
-#ifndef SCN_EXP_WELCH_NO_LD
-#define SCN_EXP_WELCH_NO_LD 0
-#endif
-#ifndef SCN_WELCH_PF_CUT
-#define SCN_WELCH_PF_CUT 8  // how many of the next segment's 16 loads the column kernel issues before pass 1 (the rest after the barrier)
-#endif
-#ifndef SCN_WELCH_ROWS_WPS
-#define SCN_WELCH_ROWS_WPS 3  // waves per SIMD the row kernel is compiled for
-#endif
-#ifndef SCN_WELCH_AUX_WK_ST
-#define SCN_WELCH_AUX_WK_ST 0  // cache policy of the work-buffer stores (columns) ...
-#endif
-#ifndef SCN_WELCH_AUX_WK_LD
-#define SCN_WELCH_AUX_WK_LD 2  // ... and loads (rows): read once, non-temporal (measured 152 -> 140 us per 32-PSD step; the store policy and
-                               // the input-stream policy change nothing: scripts/welch_variants.sh)
-#endif
+// tunables, each measured (scripts in git history: welch_variants.sh; profiles/r02_experiments.md, r03_experiments.md section 5)
+constexpr int SCN_WELCH_AUX_IN = 0;     // cache policy of the input stream loads (each sample is read by two overlapping segments)
+constexpr int SCN_WELCH_PF_CUT = 8;     // how many of the next segment's 16 loads the column kernel issues before pass 1 (the rest after the barrier)
+#define SCN_WELCH_ROWS_WPS 3            // waves per SIMD the row kernel is compiled for
+constexpr int SCN_WELCH_AUX_WK_ST = 0;  // cache policy of the work-buffer stores (columns) ...
+constexpr int SCN_WELCH_AUX_WK_LD = 2;  // ... and loads (rows): read once, non-temporal (measured 152 -> 140 us per 32-PSD step; the store
+                                        // policy and the input-stream policy change nothing)
 
 namespace {
 constexpr uint32_t WN = 65536;
@@ -87,7 +71,7 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
   // the end gets a zero-record descriptor)
   auto in_rsrc = [&](uint32_t seg) {
     const bool ok = seg < args.n_segments;
-    return make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)(ok ? seg : 0u) * args.hop * 8u, (ok && !SCN_EXP_WELCH_NO_LD) ? WN * 8u : 0u);
+    return make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)(ok ? seg : 0u) * args.hop * 8u, ok ? WN * 8u : 0u);
   };
   v2f raw[16];
   {
@@ -96,7 +80,7 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
     for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
   }
   for (uint32_t seg = g; seg < args.n_segments; seg += G) {
-    __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)seg * WN * 8u + j * 2048u, SCN_EXP_WELCH_NO_ST ? 0u : WN * 8u - j * 2048u);
+    __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)seg * WN * 8u + j * 2048u, WN * 8u - j * 2048u);
     cf v[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) v[a] = from_v2f(raw[a]) * win[a];
@@ -240,22 +224,5 @@ hipError_t scn_launch_welch(const ScnWelchArgs &a, int num_cus, hipStream_t s) {
   e = hipGetLastError();
   if (e != hipSuccess || a.parts == 1) return e;
   hipLaunchKernelGGL(scn_welch_combine_kernel, dim3(std::min<uint32_t>(a.n_psd * 64u, 2048u)), dim3(256), 0, s, a);
-  return hipGetLastError();
-}
-
-// Experiment (SCN_EXP_WELCH_CHUNK, scn_api.hip): columns on `s_cols`, rows on `s_rows` behind an event, so that consecutive
-// chunks' row and column kernels overlap.
-hipError_t scn_launch_welch_split(const ScnWelchArgs &a, int num_cus, hipStream_t s_cols, hipStream_t s_rows, hipEvent_t ev) {
-  if (a.n_segments == 0) return hipSuccess;
-  const size_t lds = 16 * WP * sizeof(v2f);
-  uint32_t G = (uint32_t)(num_cus * 3) / 16u;
-  if (G < 1) G = 1;
-  if (G > a.n_segments) G = a.n_segments;
-  hipLaunchKernelGGL(scn_welch_cols_kernel, dim3(16 * G), dim3(256), lds, s_cols, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if ((e = hipEventRecord(ev, s_cols)) != hipSuccess) return e;
-  if ((e = hipStreamWaitEvent(s_rows, ev, 0)) != hipSuccess) return e;
-  hipLaunchKernelGGL(scn_welch_rows_kernel, dim3(16 * a.n_psd * a.parts), dim3(256), lds, s_rows, a);
   return hipGetLastError();
 }

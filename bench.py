@@ -341,6 +341,32 @@ def dry_run_main(args):
         dist.destroy_process_group()
 
 
+def abi_bench_legs(n, nb, kind, threshold, steps, depth):
+    """The records legs from a C++ process (scanner_amd/host/abi_bench: the C-ABI's step loop with the system HIP runtime).
+    Why: a torch process runs on the HIP runtime torch bundles (ROCm 7.0 here), which executes device-to-host copies as blit
+    KERNELS; the system runtime (ROCm 7.2) a C++ consumer links -- the reference's ProcessSamples is C++ -- uses an SDMA
+    engine, and only that leaves the FFT launch beside the copy alone (scripts/ubench/pcie_beside.hip, d2h_engine.hip).
+    Returns {mode/depth: result dict} or {"error": ...}; a child process, started after this one's own legs are done."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "scanner_amd", "host", "abi_bench")
+    if not os.path.exists(exe):
+        return {"error": "scanner_amd/host/abi_bench has not been built (python -m scanner_amd.build)"}
+    out = {}
+    for mode, d in (("view", depth), ("copy", depth), ("view", 2), ("counts", 2)):
+        cmd = [exe, "--n", str(n), "--batch", str(nb), "--kind", kind, "--threshold", str(threshold), "--steps", str(steps),
+               "--depth", str(d), "--mode", mode]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                return {"error": f"abi_bench --mode {mode} exited {r.returncode}: {r.stderr[-300:]}"}
+            out[f"{mode}_depth{d}"] = json.loads(line[-1])
+        except Exception as e:  # a missing leg must not cost the run its line
+            return {"error": str(e)[:300]}
+    return out
+
+
 def kernel_name(n, kind, hits=True, spectrum=True):
     """the kernel's name as rocprofv3 prints it: template arguments <.., KIND, DC, HITS, SPEC> (scn_kernels.hip)"""
     k = {"cfloat": "SCN_K_FLOAT_COMPLEX", "int16": "SCN_K_SHORT_COMPLEX", "int8": "SCN_K_BYTE_COMPLEX"}[kind]
@@ -837,6 +863,31 @@ def main():
             "final_sweep_collect_gather_ms": round(gather_ms, 3),
             "gather": gather_info,
         }
+        # the records legs again, from a C++ process on the system HIP runtime: the product's consumer (N = 1 only)
+        if records is not None and world == 1:
+            legs = abi_bench_legs(n, nb, args.kind, args.threshold, leg_steps, min(args.records_depth, 3))
+            if "error" in legs:
+                records = {"error": legs["error"], "python_torch_runtime": records}
+            else:
+                v = legs[f"view_depth{min(args.records_depth, 3)}"]
+                c = legs[f"copy_depth{min(args.records_depth, 3)}"]
+                records = {
+                    "value": v["value"], "unit": "Msamples/s", "steps": v["steps"], "ms_per_step": v["ms_per_step"],
+                    "hits_per_step": v["hits_per_step"], "submits_in_flight": v["submits_in_flight"],
+                    "path": "C++ consumer (scanner_amd/host/abi_bench, a child process on the system HIP runtime): scn_submit_device, "
+                            "scn_collect for counts + trigger flags, the ordered records read in place through scn_hits_view -- what "
+                            "ProcessSamples::ThreadWorker does (scanner_amd/host/process.cpp)",
+                    "hip_runtime_version": v["hip_runtime_version"],
+                    "two_in_flight": {"value": legs["view_depth2"]["value"], "ms_per_step": legs["view_depth2"]["ms_per_step"]},
+                    "copied_out_by_scn_collect": {"value": c["value"], "ms_per_step": c["ms_per_step"], "collect_call_avg_us": c["collect_call_avg_us"],
+                                                  "note": "the same loop with scn_collect copying the records into the caller's buffer (one core's memcpy "
+                                                          "of ~1.6 MB out of pinned memory per step)"},
+                    "counts_only_same_harness": {"value": legs["counts_depth2"]["value"], "ms_per_step": legs["counts_depth2"]["ms_per_step"]},
+                    "python_torch_runtime": records,
+                    "note": "value = the records loop of a C++ caller.  python_torch_runtime = the same loops driven from this Python "
+                            "process, whose HIP runtime (the one torch bundles) runs every device-to-host copy as a blit kernel beside "
+                            "the FFT launch instead of on an SDMA engine",
+                }
         rc = 0
         if c4:
             want = synth.c4_expected_hits(plan.window(), fc_all, centres, i0, n, FS, args.threshold)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 2
+#define SCN_ABI_VERSION 3 /* 3: SCN_NUM_SLOTS 4, scn_gather_hits_device, scn_gather_fetch, scn_size_path */
 
 /* status codes */
 enum {
@@ -87,9 +87,10 @@ typedef struct scn_hit {
 typedef struct scn_plan_desc {
   uint32_t struct_size;
   uint32_t n;              /* sampleCount = FFT size (scan.cpp:85; the reference plans any count, fft.cpp:4-11): any size from
-                              16 to 65536.  256 ... 16384 (powers of two) run in fused single-pass LDS kernels, 65536 in a
-                              four-step pair of kernels (with DC removal: the staged path); the other sizes through a
-                              staged, slower path (Bluestein for the sizes that are not powers of two) with the same outputs */
+                              16 to 65536.  256 ... 16384 (powers of two) run in fused single-pass LDS kernels, 32768 and
+                              65536 in a four-step pair of kernels (integer DC removal included); the other sizes through
+                              a staged, slower path (Bluestein for the sizes that are not powers of two) with the same
+                              outputs.  scn_size_path tells which. */
   uint32_t sample_rate;    /* Hz (scan.cpp:92) */
   uint32_t sample_kind;    /* SCN_KIND_* */
   uint32_t enob;           /* effective bits (scan.cpp:138,183) */
@@ -121,6 +122,17 @@ const char *scn_last_error(void);
 uint32_t scn_abi_version(void);
 /* Number of HIP devices visible to this process (0 and SCN_E_NO_DEVICE if none). */
 int scn_device_count(int *count);
+
+/* Which implementation a frequency-domain plan of n points runs (needs no device): what a caller sizing its batches
+ * wants to know, and what the parity tests walk so that no fused specialisation goes untested. */
+enum {
+  SCN_PATH_UNSUPPORTED = 0,
+  SCN_PATH_FUSED = 1,     /* one launch, the FFT staged in LDS (256 ... 16384) */
+  SCN_PATH_FOUR_STEP = 2, /* two launches around a work buffer (32768, 65536) */
+  SCN_PATH_STAGED = 3,    /* one launch per radix stage through HBM, in double (the other powers of two from 16 up) */
+  SCN_PATH_BLUESTEIN = 4  /* the staged path around a chirp-z convolution (sizes that are not powers of two) */
+};
+int scn_size_path(uint32_t n, uint32_t *path);
 
 int scn_plan_create(const scn_plan_desc *desc, scn_plan **out);
 int scn_plan_destroy(scn_plan *plan);

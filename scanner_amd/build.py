@@ -74,6 +74,7 @@ def build(force=False, verbose=False, defines=(), out=None):
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libscanner_host.so")
 HOST_DEMO = os.path.join(HOST, "scan_synth")
+ABI_BENCH = os.path.join(HOST, "abi_bench")
 HOST_SOURCES = ["frequencyTable.cpp", "messageQueue.cpp", "signalSource.cpp", "syntheticSource.cpp", "fileSource.cpp",
                 "processInterface.cpp", "sampleBuffer.cpp", "process.cpp"]
 
@@ -95,6 +96,16 @@ def build_host(force=False, verbose=False):
             max(os.path.getmtime(demo_src), os.path.getmtime(HOST_LIB)) > os.path.getmtime(HOST_DEMO):
         cmd = ["g++", "-std=gnu++11", "-O2", "-g", "-Wall", "-pthread", "-o", HOST_DEMO, demo_src, "-L" + HERE,
                "-lscanner_host", "-lscanner_hip", "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    # abi_bench: the C-ABI's step loop from a C++ process (the system HIP runtime, not the one torch bundles)
+    bench_src = os.path.join(HOST, "abi_bench.cpp")
+    if force or not os.path.exists(ABI_BENCH) or os.path.getmtime(bench_src) > os.path.getmtime(ABI_BENCH) or \
+            os.path.getmtime(os.path.join(HERE, "..", "include", "scanner_hip.h")) > os.path.getmtime(ABI_BENCH):
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        cmd = ["g++", "-std=gnu++11", "-O2", "-g", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-o", ABI_BENCH,
+               bench_src, "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-ldl", "-Wl,-rpath," + os.path.join(rocm, "lib")]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -20,7 +20,8 @@ OUT_SPECTRUM, OUT_HITS = 1, 2
 PLAN_OVERLAP_SLOTS = 4  # each slot on its own compute stream (scanner_hip.h)
 DC_IGNORE_NONE = 0xFFFFFFFF
 NUM_SLOTS = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
+PATH_UNSUPPORTED, PATH_FUSED, PATH_FOUR_STEP, PATH_STAGED, PATH_BLUESTEIN = range(5)
 COMM_ID_BYTES = 128
 
 BYTES_PER_SAMPLE = {KIND_BYTE_COMPLEX: 2, KIND_SHORT: 4, KIND_SHORT_COMPLEX: 4, KIND_FLOAT_COMPLEX: 8}
@@ -73,6 +74,7 @@ SYMBOLS = {
     "scn_last_error": (C.c_char_p, []),
     "scn_abi_version": (C.c_uint32, []),
     "scn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "scn_size_path": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint32)]),
     "scn_plan_create": (C.c_int, [C.POINTER(PlanDesc), C.POINTER(_vp)]),
     "scn_plan_destroy": (C.c_int, [_vp]),
     "scn_buffer_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
@@ -149,6 +151,13 @@ def check(status, where):
     if status != OK:
         L = lib()
         raise ScannerError(status, where, f"{L.scn_error_name(status).decode()}: {L.scn_last_error().decode()}")
+
+
+def size_path(n):
+    """PATH_* of a frequency-domain plan of n points (scn_size_path; needs no device)."""
+    out = C.c_uint32()
+    check(lib().scn_size_path(int(n), C.byref(out)), "scn_size_path")
+    return out.value
 
 
 def frequency_table(sample_rate, start, stop, use_bandwidth=0.75, dc_ignore_width=0.0, shard=0, n_shards=1):

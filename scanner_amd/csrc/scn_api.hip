@@ -277,16 +277,30 @@ hipStream_t topup_stream_of(const scn_plan *p, const Slot &s) { return s.own_str
 // Scan + compaction of the slot's pending / last submit into d_list, behind everything already queued on the list's
 // stream; with `prefetch`, followed by a DMA of the expected number of records into the pinned h_list (the size of a
 // copy has to be known when it is queued, long before this batch's own total is: the plan predicts it from the last
-// one, and fetch_list tops up whatever is missing).
+// one, and fetch_list tops up whatever is missing).  The DMA goes on the D2H stream behind an event, not behind the list
+// kernels on their own stream: scan + compaction + copy in series took longer per submit (~90 us for a C2 list) than the FFT
+// launch they run beside (73 us), so the records loop was bound by the list stream; split, each stream has < 50 us of work
+// per submit (round 4, profiles/r04_experiments.md section 1: 310 -> 378 Gsamples/s through scn_hits_view from a C++ caller).
+// What the copy runs on is the HIP runtime's choice: an SDMA engine with the system runtime (ROCm 7.2), a blit KERNEL with the
+// runtime a torch process brings along (ROCm 7.0) -- and a shader that writes host memory beside an HBM-streaming kernel
+// stalls it by the PCIe time of its bytes (scripts/ubench/pcie_beside.hip: 70 -> 95 us), which is also why the compaction
+// kernel does not store the list into pinned memory itself (measured: 335 Gsamples/s against 378).
 int build_list(scn_plan *p, Slot &s, bool prefetch) {
   hipStream_t aux = list_stream_of(p, s);
   ScnCompactArgs c = compact_args(p, s, 0, p->d.max_hits, s.d_list);
   SCN_HIP(scn_launch_hit_scan(c, aux));
   SCN_HIP(scn_launch_hit_compact(c, aux));
   s.prefetched = prefetch ? std::min(p->predict, p->d.max_hits) : 0u;
-  if (s.prefetched)
-    SCN_HIP(hipMemcpyAsync(s.h_list, s.d_list, sizeof(scn_hit) * (size_t)s.prefetched, hipMemcpyDeviceToHost, aux));
-  SCN_HIP(hipEventRecord(s.list_done[s.gen], aux));
+  hipStream_t last = aux;
+  if (s.prefetched) {
+    if (!s.own_stream) {  // (a slot with a stream of its own keeps its whole chain there: its next kernel is several submits away)
+      SCN_HIP(hipEventRecord(s.list_done[s.gen], aux));
+      SCN_HIP(hipStreamWaitEvent(p->d2h_stream, s.list_done[s.gen], 0));
+      last = p->d2h_stream;
+    }
+    SCN_HIP(hipMemcpyAsync(s.h_list, s.d_list, sizeof(scn_hit) * (size_t)s.prefetched, hipMemcpyDeviceToHost, last));
+  }
+  SCN_HIP(hipEventRecord(s.list_done[s.gen], last));
   s.list_used[s.gen] = true;
   s.list_built = true;
   return SCN_OK;
@@ -444,7 +458,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     // (a hits-only plan handed a caller's spectrum destination runs the full kernel)
     SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, d_power != nullptr, a, p->num_cus, s.stream, in_packet ? after : nullptr));
   }
-  if (scn_uses_queue((int)p->d.sample_kind, p->d.n))
+  if (!p->generic && !p->big && scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
   if (hits && nb) {
     if (after && !in_packet) SCN_HIP(hipEventRecord(after, s.stream));
@@ -523,6 +537,16 @@ int scn_device_count(int *count) {
     return fail(SCN_E_NO_DEVICE, "no HIP device visible");
   }
   *count = n;
+  return SCN_OK;
+}
+
+int scn_size_path(uint32_t n, uint32_t *path) {
+  if (!path) return fail(SCN_E_INVALID, "null argument");
+  *path = scn_fft_size_supported(n) ? SCN_PATH_FUSED
+          : scn_big_size_supported(n) ? SCN_PATH_FOUR_STEP
+          : scn_generic_size_supported(n) ? SCN_PATH_STAGED
+          : scn_bluestein_size_supported(n) ? SCN_PATH_BLUESTEIN
+                                            : SCN_PATH_UNSUPPORTED;
   return SCN_OK;
 }
 

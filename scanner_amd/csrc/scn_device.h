@@ -38,9 +38,11 @@ namespace {
 // evaluate the exact form only in waves that hold such a bin (strong signals), under wave-uniform branches.
 // ONE exception, the 16384-point kernel: it keeps the dB values (not the powers) for its hit path -- at that size a
 // threshold near the noise floor makes every wave a hit wave, and re-deriving the values cost 15 % -- and so has the power
-// only of each thread-group's maximum at hand: there a bin gets the exact form iff it is at least SCN_P_EXACT_FROM AND its
-// group's maximum (a tone's strongest bins, one per thread); a second strong bin in the same group of the same thread keeps
-// the product form's <= 2.2 ulp.  Its three output modes apply the same rule (identical thread layout).
+// only of each thread-group's maximum at hand.  Its map, in all three output modes (identical thread layout): a bin of a
+// group of eight outputs of a thread whose maximum power gm is at least SCN_P_EXACT_FROM gets db_exact(gm) iff its
+// product-form value equals db_fast(gm) -- i.e. the group's strongest bin (a tone's strongest bins, one per thread), plus
+// any bin of the group within the product form's resolution of it; every other bin keeps the product form's <= 2.2 ulp.
+// Spectrum + hits and hits-only plans therefore report bit-identical records (tests/test_dispatch_gpu.py).
 #define SCN_P_EXACT_FROM 1584.8932f
 __device__ __forceinline__ float db_fast(float p) { return 1.50514997831990597607f * __builtin_amdgcn_logf(p); }
 __device__ __forceinline__ float db_exact(float p) {
@@ -334,12 +336,18 @@ __device__ __forceinline__ void scn_record_hits_lanes(VEC &pw, const float (&gma
     float d = p;
     if constexpr (!IS_DB) {
       d = db_fast(p);
-      bool ex = p >= SCN_P_EXACT_FROM;
-      if constexpr (!PURE) {  // the exact form for each thread-group's strong maximum only (the 16384-point kernel's map)
+      if constexpr (PURE) {
+        const bool ex = p >= SCN_P_EXACT_FROM;
+        if (__ballot(act && ex)) d = ex ? db_exact(p) : d;  // = db_of_power(p)
+      } else {
+        // the 16384-point kernel's map, EXACTLY as its spectrum kernel applies it (which holds dB values, not powers, at this
+        // point): a bin whose product-form value equals that of its thread-group's strong maximum gets the exact form of that
+        // maximum -- so the two output modes report the same float for every bin, also when two distinct powers of a group
+        // share a product-form value
         const float gm = (o / GS) & 2u ? ((o / GS) & 1u ? gmax[3] : gmax[2]) : ((o / GS) & 1u ? gmax[1] : gmax[0]);
-        ex = ex && p == gm;
+        const bool ex = gm >= SCN_P_EXACT_FROM && d == db_fast(gm);
+        if (__ballot(act && ex)) d = ex ? db_exact(gm) : d;
       }
-      if (__ballot(act && ex)) d = ex ? db_exact(p) : d;
     }
     const bool hit = act && d > args.threshold && (IS_DB || p > args.p_lo);  // strict >, process.cpp:54
     const unsigned long long m = __ballot(hit);

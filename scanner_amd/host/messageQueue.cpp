@@ -18,8 +18,8 @@ SampleQueue::SampleQueue(SampleKind kind, uint32_t enob, uint32_t sampleCount, u
                          bool correctDCOffset, bool doWrite)
     : m_kind(kind), m_enob(enob), m_sampleCount(sampleCount), m_bufferCount(bufferCount),
       m_correctDCOffset(correctDCOffset), m_doWrite(doWrite), m_bufferBytes(bytesPerSample(kind) * sampleCount),
-      m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_nextSequenceId(0),
-      m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0),
+      m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_stagingCapacity(0), m_fillSlot(0),
+      m_nextSequenceId(0), m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0),
       m_writeShutdown(false), m_writeErrors(0) {
   assert(kind > Illegal && kind <= FloatComplex);  // messageQueue.h:163
   assert(bufferCount > 0);
@@ -75,14 +75,56 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
   if (m_iterationCount < 2) return;  // the first (warm-up) sweep is discarded
   MessageType *message = Allocate();
   assert(aBytes + bBytes == m_bufferBytes);
-  memcpy(message->GetRawData(), a, aBytes);
-  if (bBytes) memcpy(static_cast<unsigned char *>(message->GetRawData()) + aBytes, b, bBytes);
+  message->m_staged = nullptr;
+  message->m_slot = -1;
   MessageHeader &h = message->GetHeader();
   h.m_time = time;
   h.m_frequency = centerFrequency;
   h.m_kind = MessageHeader::ProcessData;
   h.m_referenceCount = 0;
   std::unique_lock<std::mutex> lock(m_mutex);
+  bool staged = false;
+  if (!m_staging.empty()) {
+    // a place in the consumer's pinned slot: wait for room in the queue AND in a slot (the one being filled, or -- once that
+    // one is full or has been taken -- the next in the ring, as soon as the consumer has released it)
+    while (!m_staging.empty()) {
+      if (m_buffer.size() >= m_bufferCount) {
+        m_notFull.wait(lock);
+        continue;
+      }
+      StagingSlot &fs = m_staging[m_fillSlot];
+      if (fs.state == StagingSlot::Free) {
+        fs.state = StagingSlot::Open;
+        fs.fill = 0;
+      }
+      if (fs.state == StagingSlot::Open && fs.fill < m_stagingCapacity) {
+        message->m_slot = m_fillSlot;
+        message->m_staged = fs.base + (size_t)fs.fill * m_bufferBytes;
+        fs.fill++;
+        staged = true;
+        break;
+      }
+      if (fs.state == StagingSlot::Open) {  // full and still queued: on to the next slot of the ring, once the consumer has released it
+        const int next = (m_fillSlot + 1) % (int)m_staging.size();
+        if (m_staging[next].state == StagingSlot::Free) {
+          m_fillSlot = next;
+          continue;
+        }
+      }
+      m_notFull.wait(lock);  // (the fill slot, or the one after a full one, is still in flight; ReleaseStaging and DetachStaging signal this too)
+    }
+  }
+  if (staged) {
+    // The copy runs under the queue's lock: the consumer seals a slot by what is QUEUED, so a buffer must not be half-way
+    // into a slot when that happens (2-3 us for a 32 KiB buffer; the consumer takes a whole batch per lock round trip).
+    memcpy(message->m_staged, a, aBytes);
+    if (bBytes) memcpy(message->m_staged + aBytes, b, bBytes);
+  } else {
+    lock.unlock();
+    memcpy(message->GetRawData(), a, aBytes);
+    if (bBytes) memcpy(static_cast<unsigned char *>(message->GetRawData()) + aBytes, b, bBytes);
+    lock.lock();
+  }
   h.m_sequenceId = m_nextSequenceId++;
   while (m_buffer.size() >= m_bufferCount) m_notFull.wait(lock);
   bool wake = m_buffer.empty();
@@ -129,8 +171,56 @@ SampleQueue::MessageType *SampleQueue::TryGetNextSamples() {
   return m;
 }
 
+bool SampleQueue::AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot) {
+  if (m_doWrite || nSlots < 2 || buffersPerSlot == 0) return false;  // (the capture writer's history needs storage of its own)
+  std::unique_lock<std::mutex> lock(m_mutex);
+  if (!m_staging.empty() || !m_buffer.empty()) return false;  // one consumer, attached before anything is queued
+  for (uint32_t i = 0; i < nSlots; i++) m_staging.push_back(StagingSlot{static_cast<unsigned char *>(slotBases[i]), 0, StagingSlot::Free});
+  m_stagingCapacity = buffersPerSlot;
+  m_fillSlot = 0;
+  return true;
+}
+
+void SampleQueue::DetachStaging() {
+  std::unique_lock<std::mutex> lock(m_mutex);
+  m_staging.clear();
+  m_notFull.notify_all();  // a producer waiting for a slot goes on with the messages' own storage
+}
+
+uint32_t SampleQueue::TakeStagedBatch(std::vector<MessageType *> &out, int *slot, bool block) {
+  std::unique_lock<std::mutex> lock(m_mutex);
+  while (block && !m_done && m_buffer.empty()) m_notEmpty.wait(lock);
+  if (m_buffer.empty()) return 0;
+  const int s = m_buffer.back()->m_slot;
+  uint32_t n = 0;
+  while (!m_buffer.empty() && m_buffer.back()->m_slot == s && (s >= 0 || n == 0)) {  // (an unstaged message travels alone)
+    out.push_back(m_buffer.back());
+    m_buffer.pop_back();
+    n++;
+  }
+  if (s >= 0 && (size_t)s < m_staging.size()) {
+    m_staging[s].state = StagingSlot::InFlight;  // sealed: the producer moves on -- strictly in ring order, which is the
+    if (s == m_fillSlot) m_fillSlot = (s + 1) % (int)m_staging.size();  // order the consumer submits its slots in
+  }
+  *slot = s;
+  m_notFull.notify_all();
+  return n;
+}
+
+void SampleQueue::ReleaseStaging(int slot) {
+  std::unique_lock<std::mutex> lock(m_mutex);
+  if (slot >= 0 && (size_t)slot < m_staging.size()) m_staging[slot].state = StagingSlot::Free;
+  m_notFull.notify_all();
+}
+
 void SampleQueue::MessageProcessed(MessageType *message) {
   assert(message->GetHeader().m_kind != MessageHeader::Illegal);
+  if (message->m_staged) {  // its samples live in the consumer's slot, which is about to be refilled: nothing to keep
+    message->m_staged = nullptr;
+    message->m_slot = -1;
+    Free(message);
+    return;
+  }
   std::unique_lock<std::mutex> lock(m_historyMutex);
   if (m_historyCapacity == 0) {  // (the reference's zero-capacity ring would misbehave; recycle at once)
     Free(message);

@@ -38,15 +38,19 @@ class SampleQueue {
   class MessageType {  // Buffer<MessageHeader, T> of memoryPool.h:7-30
    public:
     MessageHeader m_header;
-    explicit MessageType(size_t bytes) : m_header(), m_raw(bytes) {}
+    explicit MessageType(size_t bytes) : m_header(), m_raw(bytes), m_staged(nullptr), m_slot(-1) {}
     MessageHeader &GetHeader() { return m_header; }
-    void *GetRawData() { return m_raw.data(); }
+    void *GetRawData() { return m_staged ? static_cast<void *>(m_staged) : static_cast<void *>(m_raw.data()); }
     size_t GetRawBytes() const { return m_raw.size(); }
     // Valid for FloatComplex queues only (raw == converted); integer kinds are converted on the GPU.
-    fftwf_complex *GetData() { return reinterpret_cast<fftwf_complex *>(m_raw.data()); }
+    fftwf_complex *GetData() { return reinterpret_cast<fftwf_complex *>(GetRawData()); }
+    int GetStagingSlot() const { return m_slot; }  // -1: the samples live in the message itself
 
    private:
+    friend class SampleQueue;
     std::vector<unsigned char> m_raw;
+    unsigned char *m_staged;  // staged queues: the samples' place in the consumer's pinned submit slot (AttachStaging)
+    int m_slot;
   };
 
   SampleKind m_kind;
@@ -78,6 +82,20 @@ class SampleQueue {
   // round trip for the integer formats) starts a second job instead of closing a file in use.
   typedef std::function<void(const void *raw, uint32_t nBuffers, float *out)> Converter;
   void SetConverter(Converter c);  // install before the consumers start; the writer calls a copy taken under the lock
+
+  // Zero-copy staging (sampleBuffer.cpp's host staging "replaced by pinned double-buffered hipMemcpyAsync", BASELINE.json): a
+  // single consumer lends the queue the pinned submit slots of its scn_plan (scn_host_buffer).  AppendSamples then writes a
+  // buffer straight into the next free place of the slot being filled -- the producer's one copy lands in pinned memory --
+  // and the consumer submits a slot as it is, without copying: TakeStagedBatch hands out every queued message of the oldest
+  // slot (buffers 0 .. n-1 of it, in order) and seals that slot, so that the producer moves on to the next one; the slot
+  // returns to the producer with ReleaseStaging, after the consumer has collected its results.  Sequence ids, the discarded
+  // warm-up sweep (messageQueue.h:67-72), the queue's bound and its blocking behaviour are unchanged; a staged message is
+  // recycled as soon as it is processed (the history ring of the capture writer needs storage of its own: a queue built
+  // with doWrite refuses staging and keeps the copying path).
+  bool AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot);
+  void DetachStaging();  // the consumer is leaving: appends fall back to the messages' own storage
+  uint32_t TakeStagedBatch(std::vector<MessageType *> &out, int *slot, bool block);
+  void ReleaseStaging(int slot);
 
   void SetIsDone();
   bool GetIsDone();
@@ -111,6 +129,15 @@ class SampleQueue {
   uint32_t m_poolSize;
   std::mutex m_mutex, m_poolMutex, m_historyMutex;
   std::condition_variable m_notEmpty, m_notFull, m_poolNotEmpty;
+  // staging slots (guarded by m_mutex): Free -> Open (being filled / holding queued messages) -> InFlight (taken) -> Free
+  struct StagingSlot {
+    unsigned char *base;
+    uint32_t fill;
+    enum { Free, Open, InFlight } state;
+  };
+  std::vector<StagingSlot> m_staging;
+  uint32_t m_stagingCapacity;
+  int m_fillSlot;
   uint64_t m_nextSequenceId;
   uint32_t m_iterationCount;
   std::atomic<bool> m_done;

@@ -43,7 +43,7 @@ ProcessSamples::ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_
     : m_writeData(false), m_sampleCount(numSamples), m_sampleRate(sampleRate), m_enob(enob), m_fileCounter(0),
       m_preTrigger(preTrigger), m_postTrigger(postTrigger), m_endSequenceId(0), m_writing(false), m_mode(mode),
       m_fileNameBase(fileNameBase), m_threshold(threshold), m_useBandWidth(useBandWidth), m_windowType(windowType),
-      m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_firstDevice(0), m_hitCount(0),
+      m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_pipeDepth(3), m_firstDevice(0), m_hitCount(0),
       m_bufferCount(0), m_failed(false) {
   (void)dcIgnoreWidth;  // the reference ignores it too and hard-codes 4 bins (process.cpp:86-88)
   assert(mode > Illegal && mode <= FrequencyDomain);  // process.cpp:99
@@ -117,6 +117,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   d.flags = SCN_OUT_HITS;  // the reference reports hits only; the spectra never leave the GPU
   // a worker that cannot go on still has to empty the queue, or the producer blocks on a full one forever
   auto abandon = [&](scn_plan *plan) {
+    q.DetachStaging();  // (the producer may be waiting for a slot of this plan)
     if (plan) scn_plan_destroy(plan);
     while (SampleQueue::MessageType *m = q.GetNextSamples()) q.MessageProcessed(m);
   };
@@ -127,12 +128,11 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   if (!Ok(scn_plan_create(&d, &plan), "scn_plan_create")) return abandon(nullptr);
 
   // Batches in flight.  This consumer prints every record of every batch (process.cpp:57), so a submit's chain is kernel ->
-  // list kernels -> DMA -> the copy in scn_collect, longer than one kernel: three in flight keep the GPU fed where two left it
-  // idle between launches (the records pipeline); a batch's lines still appear as soon as the queue runs
-  // empty, and always in submit order.
-  constexpr int kPipe = 3;
-  static_assert(kPipe <= SCN_NUM_SLOTS, "plan slots");
-  unsigned char *stage[kPipe];
+  // list kernels -> DMA, longer than one kernel: three in flight keep the GPU fed where two left it idle between launches
+  // (the records pipeline); a batch's lines still appear as soon as the queue runs empty, and always in
+  // submit order.
+  const int kPipe = (int)std::min<uint32_t>(std::max<uint32_t>(m_pipeDepth, 1u), (uint32_t)SCN_NUM_SLOTS);
+  unsigned char *stage[SCN_NUM_SLOTS];
   size_t stageBytes = 0, bufBytes = 0;
   for (int s = 0; s < kPipe; s++)
     if (!Ok(scn_host_buffer(plan, s, (void **)&stage[s], &stageBytes), "scn_host_buffer")) return abandon(plan);
@@ -142,28 +142,34 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
          " (sample kind or count mismatch)");
     return abandon(plan);
   }
+  // One consumer: the queue writes the producer's buffers straight into the plan's pinned slots and a slot is submitted as
+  // it is -- no copy in this thread (the reference's ThreadWorker copies every buffer, process.cpp:293; so did rounds 1-3 here).
+  // Several consumers (or a capturing queue, whose history ring needs storage of its own) keep the copying path.
+  const bool staged = m_threadCount == 1 && kPipe >= 2 && q.AttachStaging((void *const *)stage, (uint32_t)kPipe, d.max_batch);
 
   std::vector<double> fc(d.max_batch);
   std::vector<uint64_t> seq(d.max_batch);
   std::vector<uint8_t> trig(d.max_batch);
   std::vector<float> tdMax(d.max_batch), tdMin(d.max_batch);
-  std::vector<scn_hit> hits((size_t)d.max_batch * 64u);
-  std::vector<SampleQueue::MessageType *> inflight[kPipe];
-  bool pending[kPipe] = {};
+  std::vector<scn_hit> window;  // records beyond the plan's pinned list (a wideband burst), fetched window by window
+  std::vector<SampleQueue::MessageType *> inflight[SCN_NUM_SLOTS];
+  bool pending[SCN_NUM_SLOTS] = {};
   uint64_t lastSequenceId = 0;
   double lastFrequency = 0;
 
   auto drain = [&](int s) {
     uint32_t nHits = 0, have = 0;
+    const scn_hit *hits = nullptr;  // the batch's ordered records, read IN PLACE from the plan's pinned list (scn_hits_view)
     int st = SCN_OK;
-    if (timeDomain)
+    if (timeDomain) {
       st = scn_collect_time_domain(plan, s, tdMax.data(), tdMin.data(), trig.data());
-    else
-      st = scn_collect(plan, s, nullptr, hits.data(), (uint32_t)hits.size(), &nHits, trig.data());
-    // More detections than `hits` holds (a wideband burst: every triggered buffer alone has > 1047): the list on the
-    // GPU is complete and ordered, so the rest is fetched window by window below -- the reference prints every line.
-    bool failed = st != SCN_OK && st != SCN_E_TRUNCATED && !Ok(st, "scn_collect");
-    have = (uint32_t)std::min<size_t>(nHits, hits.size());
+    } else {
+      st = scn_collect(plan, s, nullptr, nullptr, 0, &nHits, trig.data());
+      if (st == SCN_OK && nHits) st = scn_hits_view(plan, s, &hits, &have);
+    }
+    // More detections than the plan's pinned list holds (a wideband burst: every triggered buffer alone has > 1047): the
+    // list on the GPU is complete and ordered, so the rest is fetched window by window below -- the reference prints every line.
+    bool failed = !Ok(st, timeDomain ? "scn_collect_time_domain" : "scn_collect / scn_hits_view");
     uint32_t first = 0;  // index, in the batch's ordered hit list, of hits[0]
     size_t k = 0;
     for (size_t b = 0; b < inflight[s].size(); b++) {
@@ -188,10 +194,12 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
       while (!timeDomain && first + k < nHits) {  // hits arrive ordered by (buffer, i)
         if (k == have) {                          // window exhausted: fetch the next one
           first += have;
-          if (!Ok(scn_collect_more(plan, s, first, hits.data(), (uint32_t)hits.size(), &have), "scn_collect_more") || !have) {
+          window.resize(std::min<size_t>(nHits - first, (size_t)d.max_batch * 64u));
+          if (!Ok(scn_collect_more(plan, s, first, window.data(), (uint32_t)window.size(), &have), "scn_collect_more") || !have) {
             nHits = first;  // give up on the rest of this batch's lines
             break;
           }
+          hits = window.data();
           k = 0;
         }
         if (hits[k].seq_id != h.m_sequenceId) break;
@@ -209,6 +217,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
     m_bufferCount += inflight[s].size();
     inflight[s].clear();
     pending[s] = false;
+    if (staged) q.ReleaseStaging(s);  // the slot goes back to the producer
   };
 
   // A ring of kPipe slots: `head` is filled next, the oldest submit in flight is `inFlight` behind it.  Results are
@@ -222,7 +231,27 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
       inFlight--;
     }
     uint32_t n = 0;
-    if (more) {
+    if (more && staged) {
+      // every queued message of the queue's oldest slot -- which is `head`: the queue fills its slots in ring order and a
+      // slot is sealed by being taken.  Block only while nothing is in flight.
+      int slot = -1;
+      n = q.TakeStagedBatch(inflight[head], &slot, inFlight == 0);
+      if (!n && !inFlight) more = false;
+      if (n && slot != head) {
+        Fail("ProcessSamples: the queue handed out staging slot " + std::to_string(slot) + ", the worker expected " + std::to_string(head));
+        for (SampleQueue::MessageType *m : inflight[head]) q.MessageProcessed(m);
+        inflight[head].clear();
+        while (inFlight) {
+          drain(oldest());
+          inFlight--;
+        }
+        return abandon(plan);
+      }
+      for (uint32_t b = 0; b < n; b++) {
+        fc[b] = inflight[head][b]->GetHeader().m_frequency;
+        seq[b] = inflight[head][b]->GetHeader().m_sequenceId;
+      }
+    } else if (more) {
       // block for the first message only while nothing is in flight; then take what is queued
       SampleQueue::MessageType *m = inFlight ? q.TryGetNextSamples() : q.GetNextSamples();
       if (!m && !inFlight) more = false;
@@ -258,6 +287,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   // Shutdown writing gracefully (process.cpp:311-313).
   UpdateEndSequenceId(lastSequenceId);
   ProcessWrite(false, lastFrequency, lastSequenceId);
+  q.DetachStaging();
   scn_plan_destroy(plan);
 }
 

@@ -1,8 +1,9 @@
 // process.h -- ProcessSamples: the consumer side.  Same constructor, modes and entry points
 // as the reference (process.h:24-93); the per-buffer CPU work of ThreadWorker
 // (process.cpp:293-299: memcpy, FFTWindow::apply, FFT::process, process_fft) is replaced by
-// one scn_plan per consumer thread: each thread drains up to a batch of queued messages into
-// a pinned staging slot, submits it to the GPU and, while that runs, fills the other slot.
+// one scn_plan per consumer thread: each thread submits up to a batch of queued messages at a time from a
+// pinned staging slot and, while that runs on the GPU, the next slots fill.  With ONE consumer thread the queue
+// writes the producer's buffers straight into those slots (SampleQueue::AttachStaging: no copy in the worker).
 // The stdout protocol ("Start scan at", "freq %lu power_db %f", thread start/stop lines) and
 // the ack / trigger bookkeeping per message follow the reference.
 #pragma once
@@ -43,6 +44,10 @@ class ProcessSamples {
   // knobs the reference hard-codes; set before StartProcessing
   void SetMaxBatch(uint32_t maxBatch) { m_maxBatch = maxBatch; }
   void SetDevice(int firstDevice) { m_firstDevice = firstDevice; }
+  // Submits a consumer thread keeps in flight (1 .. SCN_NUM_SLOTS, default 3).  Each slot in use holds its pinned staging
+  // (max_batch buffers), two generations of hit regions (8 B x evaluated bins x max_batch each: 2 x 201 MB for a 8192 x
+  // 4096-point batch) and its record lists: a host short of GPU memory trades depth for footprint here.
+  void SetPipelineDepth(uint32_t depth) { m_pipeDepth = depth; }
   uint64_t GetHitCount() const { return m_hitCount; }
   uint64_t GetBufferCount() const { return m_bufferCount; }
 
@@ -70,7 +75,7 @@ class ProcessSamples {
   gr::fft::window::win_type m_windowType;
   SampleQueue *m_sampleQueue;
   uint32_t m_threadCount;
-  uint32_t m_maxBatch;
+  uint32_t m_maxBatch, m_pipeDepth;
   int m_firstDevice;
   std::atomic<uint64_t> m_hitCount, m_bufferCount;
   std::atomic<bool> m_failed;

@@ -58,14 +58,16 @@ near_misses = []   # (max_rel_power, case description, what the worst buffer loo
 worst_by_n = {}    # size -> the largest value of the parity metric any of its spectra showed in the last run()
 
 
-def run(budget, seed):
-    """Returns (plans, launches); raises on the first discrepancy (the failing case is printed to stderr)."""
+def run(budget, seed, plans=None):
+    """Returns (plans, launches); raises on the first discrepancy (the failing case is printed to stderr).
+    budget: seconds of wall clock (the long runs of this script), or -- with `plans` -- exactly that many plans whatever the
+    box's speed (the slice in the GPU suite: the same cases on every box)."""
     rng = np.random.default_rng(seed)
-    t_end = time.time() + budget
+    t_end = time.time() + (budget if plans is None else 1e9)
     cases = launches = 0
     near_misses.clear()
     worst_by_n.clear()
-    while time.time() < t_end:
+    while time.time() < t_end and (plans is None or cases < plans):
         # 256 / 512: several buffers per workgroup; 65536, 32768: the four-step pairs; 1000: the staged path (Bluestein)
         sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else \
             [1024, 2048, 4096, 8192, 16384, 16384, 256, 512, 65536, 32768, 1000]

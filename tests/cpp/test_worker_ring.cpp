@@ -139,6 +139,15 @@ int scn_collect(scn_plan *plan, int slot, float *, scn_hit *hits, uint32_t cap, 
   if (hits) memcpy(hits, s.list.data(), sizeof(scn_hit) * c);
   return (hits && c < *n_hits) ? SCN_E_TRUNCATED : SCN_OK;
 }
+int scn_hits_view(scn_plan *plan, int slot, const scn_hit **hits, uint32_t *n) {
+  FakePlan *p = P(plan);
+  FakeSlot &s = p->slot[slot];
+  std::lock_guard<std::mutex> g(g_m);
+  if (s.pending) g_violations.push_back("hits_view on a pending slot");
+  *n = (uint32_t)std::min<size_t>(s.list.size(), p->d.max_hits);  // the plan's pinned list holds max_hits records; the rest through scn_collect_more
+  *hits = s.list.data();
+  return SCN_OK;
+}
 int scn_collect_more(scn_plan *plan, int slot, uint32_t first, scn_hit *hits, uint32_t cap, uint32_t *n_written) {
   FakeSlot &s = P(plan)->slot[slot];
   std::lock_guard<std::mutex> g(g_m);

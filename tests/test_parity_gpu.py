@@ -675,6 +675,24 @@ def test_hit_capacity_truncation(torch_cuda, oracle_mod):
         assert plan.last_n_hits == 0 and len(h) == 0 and len(plan.hits_view(0)) == 0
 
 
+def test_long_hit_list_through_every_fetch_path(torch_cuda, oracle_mod):
+    """100 buffers with every evaluated bin a hit = 306 600 records: the first submit's list is built on demand and copied at
+    collect time, the second one's eagerly with a prefetch of the predicted size; then the zero-copy view and a window in
+    the middle of the list."""
+    n, nb = 4096, 100
+    x = synth.cfloat_batch(n, nb, seed=77)
+    fc = 100e6 + 6e6 * np.arange(nb)
+    _, h_ref, _ = oracle_mod.Oracle(n, FS, -200.0).run(x, fc, threads=8)
+    assert len(h_ref) == nb * 3066
+    with Plan(n, FS, -200.0, max_batch=nb, max_hits=len(h_ref) + 10, flags=capi.OUT_HITS) as plan:
+        for rounds in range(2):
+            plan.submit_device(rounds, _to_dev(torch_cuda, x), nb, fc)
+            _, h, _ = plan.collect(rounds, hit_cap=len(h_ref) + 10)
+            _assert_hits_equal(h, h_ref)
+        _assert_hits_equal(plan.hits_view(1), h_ref)
+        _assert_hits_equal(plan.collect_more(1, (1 << 18) - 5, 10), h_ref[(1 << 18) - 5:(1 << 18) + 5])
+
+
 def test_hit_list_eager_prefetch_and_top_up(torch_cuda, oracle_mod):
     """A caller that asks for records gets the list built beside the next launch and a DMA of the PREDICTED number of
     records (last total + 25 %); when a batch holds many more than predicted the rest is copied at collect time, and a

@@ -104,10 +104,12 @@ def pick_threshold(db_ref, n, start, use_bandwidth=0.75, dc_ignore_bins=4):
     reference spectrum, so bit-exact hit indices are a fair demand."""
     m = evaluated_mask(n, use_bandwidth, dc_ignore_bins)
     vals = np.asarray(db_ref, np.float64)[..., m].ravel()
-    vals = vals[np.isfinite(vals)]
+    vals = np.sort(vals[np.isfinite(vals)])   # (sorted once: a step is two binary searches, also on 5 M bins)
     thr = np.float32(start)
     for _ in range(10000):
-        if not np.any(np.abs(vals - float(thr)) < GUARD_DB):
+        lo = np.searchsorted(vals, float(thr) - GUARD_DB, side="right")    # first value > thr - GUARD
+        hi = np.searchsorted(vals, float(thr) + GUARD_DB, side="left")     # first value >= thr + GUARD
+        if lo >= hi:
             return float(thr)
         thr = np.float32(thr + np.float32(0.01))
     raise AssertionError("no guard-band-free threshold found")

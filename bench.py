@@ -864,7 +864,7 @@ def main():
             "gather": gather_info,
         }
         # the records legs again, from a C++ process on the system HIP runtime: the product's consumer (N = 1 only)
-        if records is not None and world == 1:
+        if records is not None and world == 1 and not c4:  # (abi_bench generates the C2 recipe's input, not the C4 sweep)
             legs = abi_bench_legs(n, nb, args.kind, args.threshold, leg_steps, min(args.records_depth, 3))
             if "error" in legs:
                 records = {"error": legs["error"], "python_torch_runtime": records}

@@ -94,7 +94,7 @@ class SampleQueue {
   // with doWrite refuses staging and keeps the copying path).
   bool AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot);
   void DetachStaging();  // the consumer is leaving: appends fall back to the messages' own storage
-  uint32_t TakeStagedBatch(std::vector<MessageType *> &out, int *slot, bool block);
+  uint32_t TakeStagedBatch(std::vector<MessageType *> &out, int *slot, bool block, uint32_t lingerMicros = 0);
   void ReleaseStaging(int slot);
 
   void SetIsDone();
@@ -112,6 +112,8 @@ class SampleQueue {
   uint64_t GetWriteStartSequenceId() const { return m_writeStart; }
   uint64_t GetWriteEndSequenceId() const { return m_writeEnd; }
   uint32_t GetWriteErrorCount() const { return m_writeErrors; }  // files that could not be opened / short writes
+  // seconds the producer has spent blocked in AppendSamples (queue full / no free staging slot): where a slow pipeline shows
+  double GetProducerWaitSeconds() const { return m_producerWaitNs.load() * 1e-9; }
 
  private:
   void SynchronizedAppend(const void *a, size_t aBytes, const void *b, size_t bBytes, double centerFrequency,
@@ -136,6 +138,7 @@ class SampleQueue {
     enum { Free, Open, InFlight } state;
   };
   std::vector<StagingSlot> m_staging;
+  std::vector<std::unique_ptr<MessageType>> m_stagingMessages;  // [slot][place]: the message objects of the staged buffers
   uint32_t m_stagingCapacity;
   int m_fillSlot;
   uint64_t m_nextSequenceId;
@@ -156,5 +159,6 @@ class SampleQueue {
   std::deque<CaptureJob> m_captures;  // front = the one being written
   bool m_writeShutdown;  // set by the destructor: the consumers are gone, drain what is there and stop
   std::atomic<uint32_t> m_writeErrors;
+  std::atomic<uint64_t> m_producerWaitNs;
   Converter m_converter;
 };

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,7 +45,7 @@ ProcessSamples::ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_
       m_preTrigger(preTrigger), m_postTrigger(postTrigger), m_endSequenceId(0), m_writing(false), m_mode(mode),
       m_fileNameBase(fileNameBase), m_threshold(threshold), m_useBandWidth(useBandWidth), m_windowType(windowType),
       m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_pipeDepth(3), m_firstDevice(0), m_hitCount(0),
-      m_bufferCount(0), m_failed(false) {
+      m_bufferCount(0), m_tWait(0), m_tSubmit(0), m_tCollect(0), m_tReport(0), m_failed(false) {
   (void)dcIgnoreWidth;  // the reference ignores it too and hard-codes 4 bins (process.cpp:86-88)
   assert(mode > Illegal && mode <= FrequencyDomain);  // process.cpp:99
   assert(threadCount <= MAX_THREADS);                 // process.cpp:100
@@ -157,7 +158,9 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   uint64_t lastSequenceId = 0;
   double lastFrequency = 0;
 
+  auto nowNs = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto drain = [&](int s) {
+    const uint64_t tDrain0 = nowNs();
     uint32_t nHits = 0, have = 0;
     const scn_hit *hits = nullptr;  // the batch's ordered records, read IN PLACE from the plan's pinned list (scn_hits_view)
     int st = SCN_OK;
@@ -170,6 +173,8 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
     // More detections than the plan's pinned list holds (a wideband burst: every triggered buffer alone has > 1047): the
     // list on the GPU is complete and ordered, so the rest is fetched window by window below -- the reference prints every line.
     bool failed = !Ok(st, timeDomain ? "scn_collect_time_domain" : "scn_collect / scn_hits_view");
+    const uint64_t tDrain1 = nowNs();
+    m_tCollect += tDrain1 - tDrain0;
     uint32_t first = 0;  // index, in the batch's ordered hit list, of hits[0]
     size_t k = 0;
     for (size_t b = 0; b < inflight[s].size(); b++) {
@@ -218,6 +223,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
     inflight[s].clear();
     pending[s] = false;
     if (staged) q.ReleaseStaging(s);  // the slot goes back to the producer
+    m_tReport += nowNs() - tDrain1;
   };
 
   // A ring of kPipe slots: `head` is filled next, the oldest submit in flight is `inFlight` behind it.  Results are
@@ -231,11 +237,12 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
       inFlight--;
     }
     uint32_t n = 0;
+    const uint64_t tTake0 = nowNs();
     if (more && staged) {
       // every queued message of the queue's oldest slot -- which is `head`: the queue fills its slots in ring order and a
       // slot is sealed by being taken.  Block only while nothing is in flight.
       int slot = -1;
-      n = q.TakeStagedBatch(inflight[head], &slot, inFlight == 0);
+      n = q.TakeStagedBatch(inflight[head], &slot, inFlight == 0, 40);
       if (!n && !inFlight) more = false;
       if (n && slot != head) {
         Fail("ProcessSamples: the queue handed out staging slot " + std::to_string(slot) + ", the worker expected " + std::to_string(head));
@@ -265,8 +272,12 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
         m = q.TryGetNextSamples();
       }
     }
+    const uint64_t tTake1 = nowNs();
+    m_tWait += tTake1 - tTake0;
     if (n) {
-      if (Ok(scn_submit(plan, head, n, fc.data(), seq.data()), "scn_submit")) {
+      const int stSubmit = scn_submit(plan, head, n, fc.data(), seq.data());
+      m_tSubmit += nowNs() - tTake1;
+      if (Ok(stSubmit, "scn_submit")) {
         pending[head] = true;
         inFlight++;
         head = (head + 1) % kPipe;

@@ -50,6 +50,14 @@ class ProcessSamples {
   void SetPipelineDepth(uint32_t depth) { m_pipeDepth = depth; }
   uint64_t GetHitCount() const { return m_hitCount; }
   uint64_t GetBufferCount() const { return m_bufferCount; }
+  // where the consumer threads' time went, summed over threads (seconds): waiting for the producer, in scn_submit, in
+  // scn_collect / scn_hits_view (waiting for the GPU), reporting (printf, acks, recycling)
+  struct WorkerTimes {
+    double waitProducer, submit, collect, report;
+  };
+  WorkerTimes GetWorkerTimes() const {
+    return WorkerTimes{m_tWait.load() * 1e-9, m_tSubmit.load() * 1e-9, m_tCollect.load() * 1e-9, m_tReport.load() * 1e-9};
+  }
 
   bool m_writeData;
 
@@ -78,6 +86,7 @@ class ProcessSamples {
   uint32_t m_maxBatch, m_pipeDepth;
   int m_firstDevice;
   std::atomic<uint64_t> m_hitCount, m_bufferCount;
+  std::atomic<uint64_t> m_tWait, m_tSubmit, m_tCollect, m_tReport;  // nanoseconds, see GetWorkerTimes
   std::atomic<bool> m_failed;
   std::mutex m_errorMutex;
   std::string m_error;

@@ -102,5 +102,8 @@ int main(int argc, char **argv) {
   fprintf(stderr, "buffers %lu hits %lu\n", (unsigned long)process.GetBufferCount(), (unsigned long)process.GetHitCount());
   // (the clock starts before the discarded warm-up sweep and includes plan creation: a lower bound on the pipeline's rate)
   fprintf(stderr, "seconds %.3f Msamples/s %.1f\n", seconds, (double)process.GetBufferCount() * n / seconds / 1e6);
+  const ProcessSamples::WorkerTimes wt = process.GetWorkerTimes();
+  fprintf(stderr, "producer blocked %.3f s; consumer: waiting for samples %.3f s, scn_submit %.3f s, scn_collect %.3f s, reporting %.3f s\n",
+          sampleQueue.GetProducerWaitSeconds(), wt.waitProducer, wt.submit, wt.collect, wt.report);
   return ok ? 0 : 1;
 }

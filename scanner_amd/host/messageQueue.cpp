@@ -234,7 +234,7 @@ uint32_t SampleQueue::TakeStagedBatch(std::vector<MessageType *> &out, int *slot
   // empty: ~1 us per 32 KiB buffer, as much as the copy) and the GPU a launch per buffer.  A front-end that delivers a
   // buffer every 80 us is not held up: the wait ends after lingerMicros at the latest.
   if (block && lingerMicros && !m_done && !m_buffer.empty() && m_buffer.size() < m_stagingCapacity)
-    m_notEmpty.wait_for(lock, std::chrono::microseconds(lingerMicros));
+    m_notEmpty.wait_until(lock, std::chrono::system_clock::now() + std::chrono::microseconds(lingerMicros));  // (system clock -> pthread_cond_timedwait: gcc 11's TSan does not know the steady-clock wait)
   if (m_buffer.empty()) return 0;
   const int s = m_buffer.back()->m_slot;
   uint32_t n = 0;

@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: every rank (gloo) shards the table, fabricates its shard's expected hit list, the list is "
                          "gathered and checked on rank 0 -- exercises the launcher, rendezvous, sharding, gather and the JSON line")
+    ap.add_argument("--dry-run-quiet-rank", type=int, default=-1,
+                    help="dry run: this rank's shard reports no detection (a quiet part of the band): its empty list still takes part in the gather")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0: pick a free one)")
     ap.add_argument("--welch", action="store_true", help="BASELINE config C5: streaming 65536-pt 50%%-overlap Welch PSD")
     ap.add_argument("--welch-psd", type=int, default=32, help="PSDs per submit (K=16 segments each)")
@@ -309,7 +311,9 @@ def dry_run_main(args):
     if "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-    n, n_centres = 4096, args.centres
+    c4 = args.config == "c4"
+    # c4: the table of --centres entries sharded over the ranks (strong scaling); c2: --batch centres PER rank (weak scaling)
+    n, n_centres = 4096, (args.centres if c4 else world * args.batch)
     _, fc_all = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0)
     first, fc = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
     lo, hi = sweep.shard_range(n_centres, rank, world)
@@ -319,6 +323,11 @@ def dry_run_main(args):
     centres, i0 = synth.c4_emitters(n_centres, n)
     want = synth.c4_expected_hits(synth.blackman_harris(n), fc_all, centres, i0, n, FS, args.threshold)
     mine = want[(want["seq_id"] >= lo) & (want["seq_id"] < hi)]
+    if 0 <= args.dry_run_quiet_rank < world:  # that shard saw nothing: its records leave the expectation, its (empty) list stays in the gather
+        qlo, qhi = sweep.shard_range(n_centres, args.dry_run_quiet_rank, world)
+        want = want[(want["seq_id"] < qlo) | (want["seq_id"] >= qhi)]
+        if rank == args.dry_run_quiet_rank:
+            mine = mine[:0]
     t0 = time.perf_counter()
     with sweep.HitGather(torch.device("cpu")) as g:
         got, per_rank = g.gather(mine)
@@ -329,10 +338,11 @@ def dry_run_main(args):
         ok, _ = compare_hit_lists(got, want, power_tol=0.0)
         emit({"metric": "Msamples/s (complex samples through convert->window->FFT->dB->threshold)", "value": 0.0,
               "unit": "Msamples/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": round(elapsed * 1e3, 3),
-              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "higher_is_better": True, "scaling": "strong" if c4 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "dry_run": True,
-              "config": {"workload": f"DRY RUN on CPU (gloo), no kernels: C4 table of {n_centres} centres sharded over {world} "
-                                     f"rank(s), planted-emitter hit lists gathered to rank 0", "n": n, "centres": n_centres},
+              "config": {"workload": f"DRY RUN on CPU (gloo), no kernels: {'C4' if c4 else 'C2-shaped'} table of {n_centres} centres sharded over {world} "
+                                     f"rank(s), planted-emitter hit lists gathered to rank 0", "n": n, "centres": n_centres,
+                         "batch_per_gpu": n_centres // world},
               "c4_check": {"expected_hits": int(len(want)), "gathered_hits": int(len(got)), "match": ok,
                            "per_rank": [int(c) for c in per_rank]}})
         if not ok:

@@ -234,9 +234,13 @@ int scn_frequency_table(uint32_t sample_rate, double start, double stop,
  *                        min(*n_total, all_cap) records (SCN_E_TRUNCATED if fewer than all -- nothing is lost, the rest
  *                        is read with scn_gather_fetch), per_rank[world_size] the counts; both may be NULL elsewhere, and
  *                        `all` may be NULL on the root too (learn *n_total first, then fetch into an exact-size array:
- *                        the records are exchanged ONCE either way).  *n_total is set on every rank.  A rank that cannot
- *                        take part (allocation failure, bad arguments) still runs the exchange and says so in it: every
- *                        rank then returns an error and nothing is transferred -- no rank is left waiting.
+ *                        the records are exchanged ONCE either way).  *n_total is set on every rank.  Every rank runs the
+ *                        same sequence of collective steps whatever happens to it locally (scn_gather_protocol.h): a rank
+ *                        that cannot take part -- a failed staging copy or allocation, a null list, a root out of range, a
+ *                        failed device selection, a plan slot that was never collected, the root's failure to make room
+ *                        for the list -- ANNOUNCES that in the exchange instead of returning before it: every rank then
+ *                        returns an error, nothing is transferred, no rank is left waiting.  Not covered: a null
+ *                        communicator (nothing to take part with) and a communicator RCCL itself reports broken.
  *   scn_gather_hits_device  the same with this rank's part taken from a collected slot of its plan -- the ordered list
  *                        the compaction kernel left in device memory (scn_hits.hip) -- instead of a host array: no
  *                        device->host->device round trip in front of the send.  The slot must have been collected

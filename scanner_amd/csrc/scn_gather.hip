@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/scanner_hip.h"
+#include "scn_gather_protocol.h"
 
 int scn_set_last_error(int status, const char *fmt, ...);  // scn_api.hip
 // scn_api.hip: the collected slot's ordered list in device memory (built if it was not yet), without a host copy
@@ -146,6 +147,7 @@ int scn_comm_create(const void *id, int rank, int world_size, int device_id, scn
   do {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(uint32_t) * (2u * (size_t)world_size + 2u));
+    if (e == hipSuccess) e = hipMemset(c->d_counts, 0xff, sizeof(uint32_t) * (2u * (size_t)world_size + 2u));  // the announce slot's poison (SCN_GATHER_POISON)
     if (e != hipSuccess) {
       st = scn_set_last_error(SCN_E_HIP, "scn_comm_create: %s", hipGetErrorString(e));
       break;
@@ -177,94 +179,110 @@ int scn_comm_destroy(scn_comm *c) {
   return SCN_OK;
 }
 
-// The collective itself, shared by the host- and the device-pointer form.  `d_local`: this rank's records in DEVICE memory
-// (already staged, or the plan's own ordered list).  Protocol, the same instruction sequence on every rank whatever its
-// arguments -- no rank can leave early and strand its peers:
-//   (1) all-gather {count, status}: a rank that could not prepare its part (allocation failure, bad list) announces it here
-//   (2) if nobody failed, the root makes room for the whole list and says so in a second one-word all-gather (its
-//       allocation can only be sized now); otherwise everybody returns the failure
-//   (3) ONE group: the root posts a receive per peer straight into its place of the rank-major list, peers send.  Every
-//       call between ncclGroupStart and ncclGroupEnd is attempted-or-skipped, never returned out of: the group is always
-//       closed, the first error reported afterwards.
-// The gathered list stays in the communicator's device buffer on the root (scn_gather_fetch reads it, locally).
+}  // extern "C"
+
+// The collective itself, shared by the host- and the device-pointer form: scn_gather_protocol (scn_gather_protocol.h) over
+// this transport.  `d_local`: this rank's records in DEVICE memory (already staged, or the plan's own ordered list).
+// d_counts layout: [2 * world] gathered words, then this rank's announce slot (2 words), which holds SCN_GATHER_POISON
+// whenever no announce is in progress -- so a rank whose own staging copy fails still announces "not OK".
+namespace {
+struct RcclTransport {
+  scn_comm *c;
+  RcclApi &api;
+  const void *d_local;
+  ncclResult_t nccl_err = ncclSuccess;
+  hipError_t hip_err = hipSuccess;
+
+  uint32_t rank() const { return (uint32_t)c->rank; }
+  uint32_t world() const { return (uint32_t)c->world; }
+
+  ScnAnnounce announce(const uint32_t *words, uint32_t n_words, uint32_t *all) {
+    uint32_t *slot = c->d_counts + 2u * world();
+    hipError_t e = hipMemcpyAsync(slot, words, sizeof(uint32_t) * n_words, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess && hip_err == hipSuccess) hip_err = e;  // (the slot keeps its poison: the peers read "not OK")
+    const ncclResult_t r = api.AllGather(slot, c->d_counts, n_words, ncclUint32, c->comm, c->stream);
+    if (r != ncclSuccess) {
+      nccl_err = r;
+      return SCN_ANNOUNCE_BROKEN;
+    }
+    e = hipMemcpyAsync(all, c->d_counts, sizeof(uint32_t) * n_words * world(), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipMemsetAsync(slot, 0xff, sizeof(uint32_t) * 2u, c->stream);  // poison again for the next announce
+    if (e != hipSuccess) {
+      if (hip_err == hipSuccess) hip_err = e;
+      return SCN_ANNOUNCE_VIEW_LOST;
+    }
+    return SCN_ANNOUNCE_OK;
+  }
+
+  int make_room(uint64_t records) { return grow(&c->d_recv, &c->recv_cap, (size_t)(records ? records : 1) * sizeof(scn_hit)); }
+
+  // ONE group: the root posts a receive per peer straight into its place of the rank-major list, peers send.  Every call
+  // between ncclGroupStart and ncclGroupEnd is attempted-or-skipped, never returned out of: the group is always closed, the
+  // first error reported afterwards.
+  int exchange(uint32_t root, const std::vector<uint32_t> &counts, const std::vector<uint64_t> &offsets, uint32_t n_local) {
+    const size_t rec = sizeof(scn_hit);
+    const bool is_root = rank() == root;
+    ncclResult_t first_err = ncclSuccess;
+    hipError_t copy_err = hipSuccess;
+    if (is_root && n_local)
+      copy_err = hipMemcpyAsync(static_cast<char *>(c->d_recv) + offsets[root] * rec, d_local, rec * n_local, hipMemcpyDeviceToDevice, c->stream);
+    const ncclResult_t r0 = api.GroupStart();
+    if (r0 == ncclSuccess) {
+      if (is_root) {
+        for (uint32_t r = 0; r < world(); r++)
+          if (r != root && counts[r]) {
+            const ncclResult_t e = api.Recv(static_cast<char *>(c->d_recv) + offsets[r] * rec, rec * counts[r], ncclUint8, (int)r, c->comm, c->stream);
+            if (e != ncclSuccess && first_err == ncclSuccess) first_err = e;  // keep posting: the peers' sends are coming
+          }
+      } else if (n_local) {
+        first_err = api.Send(d_local, rec * n_local, ncclUint8, (int)root, c->comm, c->stream);
+      }
+      const ncclResult_t e = api.GroupEnd();  // always closed
+      if (e != ncclSuccess && first_err == ncclSuccess) first_err = e;
+    } else {
+      first_err = r0;
+    }
+    const hipError_t sync_err = hipStreamSynchronize(c->stream);
+    if (first_err != ncclSuccess) {
+      nccl_err = first_err;
+      return SCN_E_COMM;
+    }
+    if (copy_err != hipSuccess || sync_err != hipSuccess) {
+      hip_err = copy_err != hipSuccess ? copy_err : sync_err;
+      return SCN_E_HIP;
+    }
+    return SCN_OK;
+  }
+};
+}  // namespace
+
 static int gather_core(scn_comm *c, const void *d_local, uint32_t n_local, int local_status, uint32_t root, uint64_t *n_total, uint32_t *per_rank) {
   RcclApi &api = rccl();
-  const uint32_t world = (uint32_t)c->world;
-  const bool is_root = (uint32_t)c->rank == root;
   c->gathered = 0;
   c->gather_root = false;
-
-  // (1) counts + status; slot layout of d_counts: [2 * world] gathered pairs, then this rank's own pair
-  uint32_t mine[2] = {n_local, (uint32_t)local_status};
-  SCN_G_HIP(hipMemcpyAsync(c->d_counts + 2u * world, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
-  SCN_G_NCCL(api.AllGather(c->d_counts + 2u * world, c->d_counts, 2, ncclUint32, c->comm, c->stream));
-  std::vector<uint32_t> pairs(2u * world);
-  SCN_G_HIP(hipMemcpyAsync(pairs.data(), c->d_counts, sizeof(uint32_t) * 2u * world, hipMemcpyDeviceToHost, c->stream));
-  SCN_G_HIP(hipStreamSynchronize(c->stream));
-  std::vector<uint32_t> counts(world);
-  int first_bad = -1;
-  for (uint32_t r = 0; r < world; r++) {
-    counts[r] = pairs[2u * r];
-    if (pairs[2u * r + 1u] != (uint32_t)SCN_OK && first_bad < 0) first_bad = (int)r;
-  }
-  std::vector<uint64_t> offsets(world + 1u);
-  scn_gather_layout(counts.data(), world, offsets.data());
-  const uint64_t total = offsets[world];
-  if (n_total) *n_total = total;
-  if (per_rank) memcpy(per_rank, counts.data(), sizeof(uint32_t) * world);
-  if (first_bad >= 0) {
-    if (first_bad == c->rank) return local_status;  // (the caller has set the message)
-    return scn_set_last_error(SCN_E_COMM, "rank %d could not prepare its part of the gather (status %u): nothing was exchanged", first_bad,
-                              pairs[2u * (uint32_t)first_bad + 1u]);
-  }
-  if (counts[c->rank] != n_local) return scn_set_last_error(SCN_E_COMM, "count exchange returned %u for this rank, sent %u", counts[c->rank], n_local);
-
-  // (2) the root's room for the list
-  const size_t rec = sizeof(scn_hit);
-  uint32_t ready[1] = {(uint32_t)SCN_OK};
-  if (is_root) ready[0] = (uint32_t)grow(&c->d_recv, &c->recv_cap, (size_t)(total ? total : 1) * rec);
-  if (world > 1) {
-    SCN_G_HIP(hipMemcpyAsync(c->d_counts + 2u * world, ready, sizeof(ready), hipMemcpyHostToDevice, c->stream));
-    SCN_G_NCCL(api.AllGather(c->d_counts + 2u * world, c->d_counts, 1, ncclUint32, c->comm, c->stream));
-    SCN_G_HIP(hipMemcpyAsync(ready, c->d_counts + root, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    SCN_G_HIP(hipStreamSynchronize(c->stream));
-  }
-  if (ready[0] != (uint32_t)SCN_OK) {
-    if (is_root) return (int)ready[0];
-    return scn_set_last_error(SCN_E_COMM, "the root (rank %u) could not allocate room for %llu records: nothing was exchanged", root, (unsigned long long)total);
-  }
-
-  // (3) the transfers
-  ncclResult_t first_err = ncclSuccess;
-  hipError_t hip_err = hipSuccess;
-  if (is_root && n_local)
-    hip_err = hipMemcpyAsync(static_cast<char *>(c->d_recv) + offsets[root] * rec, d_local, rec * n_local, hipMemcpyDeviceToDevice, c->stream);
-  ncclResult_t r0 = api.GroupStart();
-  if (r0 == ncclSuccess) {
-    if (is_root) {
-      for (uint32_t r = 0; r < world; r++)
-        if (r != root && counts[r]) {
-          const ncclResult_t e = api.Recv(static_cast<char *>(c->d_recv) + offsets[r] * rec, rec * counts[r], ncclUint8, (int)r, c->comm, c->stream);
-          if (e != ncclSuccess && first_err == ncclSuccess) first_err = e;  // keep posting: the peers' sends are coming
-        }
-    } else if (n_local) {
-      first_err = api.Send(d_local, rec * n_local, ncclUint8, (int)root, c->comm, c->stream);
+  RcclTransport t{c, api, d_local};
+  const ScnGatherOutcome o = scn_gather_protocol(t, n_local, local_status, root);
+  if (n_total) *n_total = o.total;
+  if (per_rank && o.counts.size() == (size_t)c->world) memcpy(per_rank, o.counts.data(), sizeof(uint32_t) * (size_t)c->world);
+  if (o.status == SCN_OK) {
+    if ((uint32_t)c->rank == root) {
+      c->gathered = o.total;
+      c->gather_root = true;
     }
-    const ncclResult_t e = api.GroupEnd();  // always closed
-    if (e != ncclSuccess && first_err == ncclSuccess) first_err = e;
-  } else {
-    first_err = r0;
+    return SCN_OK;
   }
-  const hipError_t sync_err = hipStreamSynchronize(c->stream);
-  if (first_err != ncclSuccess) return scn_set_last_error(SCN_E_COMM, "gather transfers failed: %s", api.GetErrorString(first_err));
-  if (hip_err != hipSuccess || sync_err != hipSuccess)
-    return scn_set_last_error(SCN_E_HIP, "gather: %s", hipGetErrorString(hip_err != hipSuccess ? hip_err : sync_err));
-  if (is_root) {
-    c->gathered = total;
-    c->gather_root = true;
-  }
-  return SCN_OK;
+  if (o.bad_rank == c->rank && local_status != SCN_OK) return local_status;  // (the caller has set the message)
+  if (t.nccl_err != ncclSuccess) return scn_set_last_error(SCN_E_COMM, "gather step %d failed: %s", o.step, api.GetErrorString(t.nccl_err));
+  if (o.bad_rank >= 0 && o.bad_rank != c->rank)
+    return scn_set_last_error(SCN_E_COMM, "rank %d %s (status %u): nothing was exchanged", o.bad_rank,
+                              o.step == 1 ? "could not prepare its part of the gather" : "was not ready for the transfers (the root: no room for the list)", o.bad_status);
+  if (t.hip_err != hipSuccess)
+    return scn_set_last_error(o.status == SCN_E_NOMEM ? SCN_E_NOMEM : SCN_E_HIP, "gather step %d: %s", o.step, hipGetErrorString(t.hip_err));
+  return scn_set_last_error(o.status, "gather step %d failed on this rank (status %d)", o.step, o.status);
 }
+
+extern "C" {
 
 int scn_gather_fetch(scn_comm *c, uint64_t first, scn_hit *out, uint64_t cap, uint64_t *n_written) {
   if (!c || !n_written || (cap && !out)) return scn_set_last_error(SCN_E_INVALID, "bad arguments");
@@ -293,11 +311,15 @@ static int gather_copy_out(scn_comm *c, scn_hit *all, uint64_t all_cap, uint64_t
 
 int scn_gather_hits(scn_comm *c, const scn_hit *local, uint32_t n_local, uint32_t root, scn_hit *all, uint64_t all_cap,
                     uint64_t *n_total, uint32_t *per_rank) {
-  if (!c || root >= (uint32_t)c->world) return scn_set_last_error(SCN_E_INVALID, "bad arguments");
-  SCN_G_HIP(hipSetDevice(c->device));
-  // this rank's part into device memory; whatever goes wrong here is ANNOUNCED in the exchange, not returned before it
+  if (!c) return scn_set_last_error(SCN_E_INVALID, "null communicator");  // (nothing to take part with)
+  // whatever goes wrong on this rank from here on is ANNOUNCED in the exchange, not returned before it
   int status = SCN_OK;
-  if (n_local && !local) status = scn_set_last_error(SCN_E_INVALID, "n_local > 0 with a null list");
+  if (root >= (uint32_t)c->world) {
+    status = scn_set_last_error(SCN_E_INVALID, "root %u out of range (world size %d)", root, c->world);
+    root = 0;
+  }
+  if (status == SCN_OK && hipSetDevice(c->device) != hipSuccess) status = scn_set_last_error(SCN_E_HIP, "hipSetDevice(%d) failed", c->device);
+  if (status == SCN_OK && n_local && !local) status = scn_set_last_error(SCN_E_INVALID, "n_local > 0 with a null list");
   if (status == SCN_OK && n_local) {
     status = grow(&c->d_send, &c->send_cap, sizeof(scn_hit) * (size_t)n_local);
     if (status == SCN_OK && hipMemcpyAsync(c->d_send, local, sizeof(scn_hit) * (size_t)n_local, hipMemcpyHostToDevice, c->stream) != hipSuccess)
@@ -314,14 +336,18 @@ int scn_gather_hits(scn_comm *c, const scn_hit *local, uint32_t n_local, uint32_
 
 int scn_gather_hits_device(scn_comm *c, scn_plan *plan, int slot, uint32_t root, scn_hit *all, uint64_t all_cap, uint64_t *n_total,
                            uint32_t *per_rank) {
-  if (!c || root >= (uint32_t)c->world) return scn_set_last_error(SCN_E_INVALID, "bad arguments");
+  if (!c) return scn_set_last_error(SCN_E_INVALID, "null communicator");
   const scn_hit *d_list = nullptr;
   uint32_t n_local = 0;
   int dev = c->device;
   int status = plan ? scn_plan_device_hits(plan, slot, &d_list, &n_local, &dev) : scn_set_last_error(SCN_E_INVALID, "null plan");
   if (status == SCN_OK && dev != c->device)
     status = scn_set_last_error(SCN_E_INVALID, "the plan lives on device %d, the communicator on device %d", dev, c->device);
-  SCN_G_HIP(hipSetDevice(c->device));
+  if (root >= (uint32_t)c->world) {
+    status = scn_set_last_error(SCN_E_INVALID, "root %u out of range (world size %d)", root, c->world);
+    root = 0;
+  }
+  if (hipSetDevice(c->device) != hipSuccess && status == SCN_OK) status = scn_set_last_error(SCN_E_HIP, "hipSetDevice(%d) failed", c->device);
   uint64_t total = 0;
   if (int st = gather_core(c, d_list, status == SCN_OK ? n_local : 0u, status, root, &total, per_rank)) {
     if (n_total) *n_total = total;

@@ -60,12 +60,14 @@ class HitGather:
     def __exit__(self, *a):
         self.close()
 
-    def gather(self, hits, dst=0):
-        """Every rank passes its ordered scn_hit array; returns (all hits on dst / empty elsewhere, per-rank counts)."""
+    def gather(self, hits, dst=0, local_status=capi.OK):
+        """Every rank passes its ordered scn_hit array; returns (all hits on dst / empty elsewhere, per-rank counts).
+        local_status (the torch.distributed form only): a rank that could not prepare its part says so -- it still takes
+        part in the exchange, and every rank then raises ScannerError (scn_gather_protocol.h, step 1)."""
         hits = np.ascontiguousarray(hits, dtype=capi.HIT_DTYPE)
         if self._comm:
             return self._gather_rccl(hits, dst)
-        return self._gather_torch(hits, dst)
+        return self._gather_torch(hits, dst, local_status)
 
     def _gather_rccl(self, hits, dst, plan=None, slot=0):
         """ONE collective (counts, then the records straight into the root's device list); the root then reads the list --
@@ -95,17 +97,27 @@ class HitGather:
             raise RuntimeError("gather_device needs the RCCL communicator (a cuda device)")
         return self._gather_rccl(None, dst, plan=plan, slot=slot)
 
-    def _gather_torch(self, hits, dst):
+    def _gather_torch(self, hits, dst, local_status=capi.OK):
+        """The steps of scn_gather_protocol.h over torch.distributed: all-gather {count, status}; if anybody announced a
+        failure every rank raises and nothing is transferred; else the records go to dst."""
         import torch
         import torch.distributed as dist
 
         if self.world == 1:
+            if local_status != capi.OK:
+                raise capi.ScannerError(local_status, "gather", "this rank could not prepare its part")
             return hits, np.array([len(hits)], np.uint32)
         dev = self.device or "cpu"
-        cnt = torch.tensor([len(hits)], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([len(hits) if local_status == capi.OK else 0, int(local_status)], dtype=torch.int64, device=dev)
         counts = [torch.zeros_like(cnt) for _ in range(self.world)]
         dist.all_gather(counts, cnt, group=self.group)
-        per_rank = np.array([int(c.item()) for c in counts], np.uint32)
+        bad = [r for r, c in enumerate(counts) if int(c[1].item()) != capi.OK]
+        if bad:
+            if self.rank == bad[0]:
+                raise capi.ScannerError(local_status, "gather", "this rank could not prepare its part")
+            raise capi.ScannerError(capi.E_COMM, "gather", f"rank {bad[0]} could not prepare its part of the gather "
+                                                           f"(status {int(counts[bad[0]][1].item())}): nothing was exchanged")
+        per_rank = np.array([int(c[0].item()) for c in counts], np.uint32)
         off = capi.gather_layout(per_rank)
         width = max(int(per_rank.max()), 1) * capi.HIT_DTYPE.itemsize
         buf = torch.zeros(width, dtype=torch.uint8, device=dev)

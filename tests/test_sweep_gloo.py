@@ -91,3 +91,58 @@ def test_shard_ranges_partition():
             assert r[0][0] == 0 and r[-1][1] == count
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+@pytest.mark.parametrize("san", ["", "thread"])
+def test_gather_protocol_every_rank_returns(tmp_path, san):
+    """The gather's control flow -- scanner_amd/csrc/scn_gather_protocol.h, the very code scn_gather.hip runs over RCCL -- with
+    threads for ranks (worlds of 3 and 8) and a failure injected on each rank in turn: its part cannot be prepared, the staging
+    of its announce words fails, it cannot read an announce back, the root cannot make room.  Every rank must return, with an
+    error, within the transport's deadline, and nothing may be transferred (tests/cpp/test_gather_protocol.cpp)."""
+    import subprocess
+
+    exe = tmp_path / "test_gather_protocol"
+    cmd = ["g++", "-std=gnu++11", "-O1", "-g", "-pthread", "-I", os.path.join(ROOT, "scanner_amd", "csrc")] + (
+        [f"-fsanitize={san}"] if san else []) + [os.path.join(ROOT, "tests", "cpp", "test_gather_protocol.cpp"), "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and san and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    if out.returncode != 0 and "unexpected memory mapping" in out.stderr:
+        pytest.skip("TSan cannot run under this kernel's address-space layout")
+    assert out.returncode == 0 and "gather protocol tests ok" in out.stdout, out.stderr[-2000:]
+
+
+def _failing_worker(rank, world, port, bad_rank, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scanner_amd import capi, sweep
+
+    hits = np.zeros(5 + rank, capi.HIT_DTYPE)
+    hits["seq_id"] = 100 * rank + np.arange(len(hits))
+    import time
+
+    t0 = time.time()
+    try:
+        with sweep.HitGather(torch.device("cpu")) as g:
+            g.gather(hits, local_status=capi.E_NOMEM if rank == bad_rank else capi.OK)
+        result = "ok"
+    except capi.ScannerError as e:
+        result = f"error {e.status}"
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(f"{result} {time.time() - t0:.3f}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_with_a_failing_rank_over_gloo(tmp_path, built_lib):
+    """The CPU twin of the same protocol (sweep.HitGather over torch.distributed): rank 1 of 3 cannot stage its part; every
+    rank -- the root included -- returns an error promptly instead of waiting for records that never come."""
+    world = 3
+    mp.spawn(_failing_worker, args=(world, _free_port(), 1, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        word, status, seconds = open(tmp_path / f"rank{r}.txt").read().split()
+        assert word == "error" and float(seconds) < 20.0, (r, word, status, seconds)
+        assert int(status) == (3 if r == 1 else 7)   # E_NOMEM on the failing rank, E_COMM on its peers

@@ -514,8 +514,17 @@ def main():
     # the noise floor of a bin grows with N, so beyond the fused sizes a tenth of the bins cross 10 dB
     # (the 10 dB default sits UNDER the noise mean of a 65536-point buffer: 30 % of the bins are hits, 7.7 M records per launch)
     hit_cap = nb * max(64, n // 64) if n <= 16384 else min(nb * (n // 2), 8 << 20)
-    plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank)
+    # C4 with a launch per sweep: every slot on a stream of its own (SCN_PLAN_OVERLAP_SLOTS) and three slots in the ring.  A
+    # shard's launch (2048 buffers at N = 8: 23.8 us of kernel) ends with a third of its workgroups one buffer short of the
+    # others, and on one stream the next launch waits for the last of them plus ~5 us of dispatch: 28.6 us per step from a C++
+    # caller; overlapped, the next launch's workgroups take the CUs as they come free: 25.9 us (scanner_amd/host/abi_bench,
+    # profiles/r04_experiments.md section 3).  The C2-sized launches keep the single-stream plan (see the `overlap` leg).
+    c4_overlap = c4 and S == 1 and nb < 8192
+    main_flags = capi.OUT_SPECTRUM | capi.OUT_HITS | (capi.PLAN_OVERLAP_SLOTS if c4_overlap else 0)
+    main_depth = 3 if c4_overlap else 2
+    plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank, flags=main_flags)
     ext = torch.cuda.ExternalStream(plan.stream_handle, device=dev)
+    slot_streams = [torch.cuda.ExternalStream(plan.slot_stream_handle(s), device=dev) for s in range(main_depth)] if c4_overlap else [ext]
 
     def make_loop(pl, want_records, zero_copy=False, spectrum=True, depth=2):
         """step(k): one pass over this rank's batch = len(chunks) launches, double-buffered over two of the plan's slots (`depth`
@@ -524,6 +533,15 @@ def main():
         pending = [False] * depth
         state = {"launch": 0, "hits": 0, "acc": 0, "group": 0}
         rec_buf = np.zeros(hit_cap, capi.HIT_DTYPE) if want_records else None  # the caller's record buffer, reused
+        # counts-only loops with a launch per chunk go through the prepared calls (two ctypes calls per launch, every
+        # argument a C value made here once): Python's own cost per step must stay below a 24 us launch
+        import ctypes as C
+        fast = S == 1 and not want_records
+        if fast:
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            prep = [[(C.c_void_p(raws[r][lo:hi].data_ptr()), hi - lo, vp(fc[lo:hi]), vp(seq[lo:hi]),
+                      C.c_void_p(outs[r][lo:hi].data_ptr()) if spectrum else None) for lo, hi in chunks] for r in range(R)]
+            state["keep"] = [fc, seq]
 
         def collect(s):
             tc0 = time.perf_counter()
@@ -561,6 +579,15 @@ def main():
                 if state["acc"] == S:
                     flush()
                 return
+            if fast:
+                for a in prep[k % R]:
+                    s = state["launch"] % depth
+                    state["launch"] += 1
+                    if pending[s]:
+                        pl.collect_counts(s)
+                    pl.submit_prepared(s, *a)
+                    pending[s] = True
+                return
             for lo, hi in chunks:
                 s = state["launch"] % depth
                 state["launch"] += 1
@@ -575,11 +602,15 @@ def main():
             for j in range(depth):  # oldest slot first
                 s = (state["launch"] + j) % depth
                 if pending[s]:
-                    collect(s)
+                    if fast:
+                        pl.collect_counts(s)
+                        pending[s] = False
+                    else:
+                        collect(s)
 
         return step, drain, state
 
-    step, drain, main_state = make_loop(plan, False)
+    step, drain, main_state = make_loop(plan, False, depth=main_depth)
 
     # The driver times as few as 20 steps (1.5 ms), so everything that is not a step stays out of the region AND out of the gap in
     # front of it: the events exist (a torch event creates its HIP event at the first record), no stream-context switches, no
@@ -588,9 +619,11 @@ def main():
     # 90-110 us instead of 74).
     import gc
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev_end = [torch.cuda.Event(enable_timing=True) for _ in slot_streams]  # one per stream that launches (several with overlapped slots)
     ev0.record(ext)
-    ev1.record(ext)
+    for e, st_ in zip(ev_end, slot_streams):
+        e.record(st_)
     gc.collect()
     gc.disable()
     # settle: the same steps, untimed and reported, until the GPU is out of its idle power state
@@ -624,7 +657,8 @@ def main():
     for k in range(args.steps):
         step(k)
     main_state["flush"]()
-    ev1.record(ext)
+    for e, st_ in zip(ev_end, slot_streams):
+        e.record(st_)
     drain()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0  # this rank's K steps, from the common start; the job's time is the MAX over ranks (below)
@@ -632,7 +666,9 @@ def main():
         dist.barrier()                  # the closing bracket: nobody goes on before everybody is done
     gc.enable()
     launches = main_state["launch"] - launch0
-    kernel_ms = ev0.elapsed_time(ev1) / launches  # average launch-to-launch duration on the plan's stream
+    # average launch-to-launch duration on the stream(s) the kernels are launched on: from the first launch's start to the
+    # last stream's last completion
+    kernel_ms = max(ev0.elapsed_time(e) for e in ev_end) / launches
 
     if world > 1:
         tt = torch.tensor([elapsed, kernel_ms], device=dev, dtype=torch.float64)
@@ -838,13 +874,15 @@ def main():
             "config": {
                 "workload": (f"{config_tag}: full frequency table of {n_centres} centres x {n}-pt FFT+power+threshold, "
                              f"{shard} cfloat buffers per GPU per sweep in launches of {nb}" + (f" (= {S} consecutive sweeps)" if S > 1 else "") +
+                             (", each slot on its own stream (SCN_PLAN_OVERLAP_SLOTS), three in flight" if c4_overlap else "") +
                              f", emitters planted on {len(centres)} centres, "
                              if c4 else
                              f"{config_tag}: {n}-pt FFT+power+threshold, batch {nb} {args.kind} buffers per GPU resident in HBM, ") +
                             f"Blackman-Harris, fs={FS} Hz, threshold {args.threshold} dB; frequency table range-sharded over "
                             f"{world} GPU(s); {settle_steps} untimed settle steps (>= {args.settle} s, until the launch time is steady) before the {args.warmup} warm-up steps",
                 "n": n, "batch_per_gpu": shard, "buffers_per_launch": nb, "sample_kind": args.kind,
-                "parallelism": f"table-shard x{world}", "rotating_batches": R, "footprint_MiB": round(R * step_bytes / 2**20),
+                "parallelism": f"table-shard x{world}", "plan_flags": "SCN_OUT_SPECTRUM|SCN_OUT_HITS" + ("|SCN_PLAN_OVERLAP_SLOTS" if c4_overlap else ""),
+                "rotating_batches": R, "footprint_MiB": round(R * step_bytes / 2**20),
             },
             "swept_GHz_per_s": round(buffers_per_s * USE_BW * FS / 1e9, 1),
             "buffers_per_s": round(buffers_per_s, 1),

@@ -42,6 +42,7 @@ class Plan:
         capi.check(self._L.scn_plan_create(C.byref(d), C.byref(self._h)), "scn_plan_create")
         self._nb = [0] * capi.NUM_SLOTS
         self._keep = [None] * capi.NUM_SLOTS
+        self._submit_device, self._collect, self._n_hits = self._L.scn_submit_device, self._L.scn_collect, C.c_uint32()
 
     # -- lifetime -----------------------------------------------------------
     @property
@@ -118,6 +119,24 @@ class Plan:
                    "scn_submit_device")
         self._nb[slot] = n_buffers
         self._keep[slot] = (d_raw, d_power_db)  # keep the tensors alive until collected
+
+    # -- the same two calls without the conveniences: for loops whose step is tens of microseconds ---------------
+    def submit_prepared(self, slot, raw_ptr, n_buffers, fc_ptr, seq_ptr, out_ptr):
+        """scn_submit_device with everything already a C value (device addresses as ints / c_void_p, the header arrays as
+        pointers the caller keeps alive): one ctypes call, no array conversion, nothing retained.  A 2048-buffer launch takes
+        24 us on the GPU; submit_device + collect cost more than that in Python alone."""
+        st = self._submit_device(self._h, slot, raw_ptr, n_buffers, fc_ptr, seq_ptr, out_ptr)
+        if st:
+            capi.check(st, "scn_submit_device")
+        self._nb[slot] = n_buffers
+
+    def collect_counts(self, slot, trigger_ptr=None):
+        """scn_collect for the per-buffer counts / trigger flags only; returns the batch's total number of hits."""
+        st = self._collect(self._h, slot, None, None, 0, C.byref(self._n_hits), trigger_ptr)
+        if st:
+            capi.check(st, "scn_collect")
+        self.last_n_hits = self._n_hits.value
+        return self.last_n_hits
 
     def wait(self, slot):
         capi.check(self._L.scn_wait(self._h, slot), "scn_wait")

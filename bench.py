@@ -53,7 +53,10 @@ def parse():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--kind", default="cfloat", choices=["cfloat", "int16", "int8"])
-    ap.add_argument("--threshold", type=float, default=10.0)
+    ap.add_argument("--threshold", type=float, default=None,
+                    help="dB; default: 10 dB at 4096 points and the same margin over the noise mean at every other size "
+                         "(10 + 5 log10(n / 4096): a bin's noise power grows with n, and a fixed 10 dB sits UNDER the noise mean of a "
+                         "65536-point buffer -- 30 %% of the bins became hits and the large sizes' numbers measured hit recording)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0,
                     help="approximate wall budget of the CPU baseline (three legs: 1, 2 and 8 threads, ~20 CPU-seconds)")
@@ -83,7 +86,10 @@ def parse():
     ap.add_argument("--welch", action="store_true", help="BASELINE config C5: streaming 65536-pt 50%%-overlap Welch PSD")
     ap.add_argument("--welch-psd", type=int, default=32, help="PSDs per submit (K=16 segments each)")
     ap.add_argument("--welch-pinned", action="store_true", help="feed from pinned host memory through the captured hipGraph")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.threshold is None:
+        args.threshold = round(10.0 + 5.0 * np.log10((4096 if args.config == "c4" else args.n) / 4096.0), 2)
+    return args
 
 
 def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s):
@@ -907,6 +913,8 @@ def main():
                                         if prof.get("kernel_avg_us") else None),
                 "traffic_source": prof.get("source"), "traffic_build": prof.get("build"), "traffic_stale": prof.get("stale"),
             },
+            "threshold_db": args.threshold,
+            "hit_density": round(len(all_hits) / max(1, samples_per_step * 0.7485), 6),  # hits per EVALUATED bin (the mask of process.cpp:46-52 keeps 3066 of 4096)
             "final_sweep_hits": int(len(all_hits)),
             "final_sweep_collect_gather_ms": round(gather_ms, 3),
             "gather": gather_info,

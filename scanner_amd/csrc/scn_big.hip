@@ -215,7 +215,12 @@ template <bool HITS, bool SPEC>
 __global__ __launch_bounds__(256, 3) void scn_big_rows_kernel(ScnBigArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-  float *lds_out = reinterpret_cast<float *>(smem_raw);  // the dB tile [k2][17] on its way out (re-uses the exchange area)
+  // the dB tile on its way out (re-uses the exchange area): [k2 (256)][16] floats with the k1 index XOR-swizzled by bits 1..3 of
+  // k2, slot(k2, k1) = 16 k2 + (k1 ^ (k2 & 14)).  Written by 32-lane groups of (two k1) x (16 k2 = lo + 16 q) and read by
+  // groups of (two consecutive k2) x (16 k1): both hit 32 distinct banks.  (Round 3 used a [k2][17] pitch: lane (k1, lo = 0)
+  // and lane (k1 + 1, lo = 15) then share a bank on the way in, rows k2 and k2 + 1 overlap by one bank on the way out --
+  // 2-way both times, SQ_LDS_BANK_CONFLICT = 17 % of the kernel's LDS cycles.)
+  float *lds_out = reinterpret_cast<float *>(smem_raw);
   const uint32_t t = threadIdx.x, lane = t & 63u;
   const uint32_t i = blockIdx.x & 15u, b = blockIdx.x >> 4;
   const uint32_t hi = t >> 4, lo = t & 15u;  // pass 1: (rho, b)   pass 2: (rho, p)
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows_kernel(ScnBigArgs args) {
     const float p = (float)__builtin_fma(xq.y, xq.y, xq.x * xq.x);
     pw[q] = p;
     gmax[q >> 2] = fmaxf(gmax[q >> 2], p);
-    if constexpr (SPEC) lds_out[(lo + 16u * q) * 17u + hi] = db_of_power(p);
+    if constexpr (SPEC) lds_out[(lo + 16u * q) * 16u + (hi ^ (lo & 14u))] = db_of_power(p);
   }
   if constexpr (SPEC) {
     __syncthreads();
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows_kernel(ScnBigArgs args) {
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       const uint32_t k2 = (t >> 4) + 16u * u, kk1 = t & 15u;
-      const float d = lds_out[k2 * 17u + kk1];
+      const float d = lds_out[k2 * 16u + (kk1 ^ ((t >> 4) & 14u))];
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, (16u * i + kk1 + 256u * k2) * 4u, 0, 2);
     }
   }
@@ -297,10 +302,16 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows_kernel(ScnBigArgs args) {
 // pass 2: thread (rho, pl): 8-pt DFTs over b for p = pl and pl + 8.  In double like the 65536-point rows (float exchange).
 template <bool HITS, bool SPEC>
 __global__ __launch_bounds__(256, 3) void scn_big_rows32k_kernel(ScnBigArgs args) {
-  constexpr uint32_t N = 32768u, RP = 162u;  // exchange: [rho][p][b] at rho*RP + 9 p + b (conflict-free reads, 2-way on the writes)
+  // exchange: [rho][p][b] at rho*RP + 9 p + b, RP = 152 = 8 mod 16: a ds_write_b64 is served in groups of 16 lanes = (two
+  // rho) x (8 b), whose slots rho RP + b then cover 16 distinct bank pairs; the pass-2 reads' 32 lanes = (four rho) x (8 p) sit
+  // at slots 24 rho + 9 p mod 32, all distinct.  (Round 3: RP = 162: 2-way on the writes and on the reads.)
+  constexpr uint32_t N = 32768u, RP = 152u;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-  float *lds_out = reinterpret_cast<float *>(smem_raw);  // the dB tile [k2 (128)][33] on its way out
+  // the dB tile on its way out: [k2 (128)][32] floats, slot(k2, k1) = 32 k2 + (k1 ^ ((k2 & 7) << 2)): written by 32-lane
+  // groups of (four k1) x (8 k2 = pl + ...) -- k1's upper bits XOR the 8 values of pl: 32 distinct banks --, read a whole k2
+  // row per group.  (Round 3: pitch 33 -> bank = pl + rho, up to 4-way: 41 % of the kernel's LDS cycles were conflict cycles.)
+  float *lds_out = reinterpret_cast<float *>(smem_raw);
   const uint32_t t = threadIdx.x, lane = t & 63u;
   const uint32_t i = blockIdx.x & 7u, b = blockIdx.x >> 3;
   const uint32_t rho = t >> 3, bq = t & 7u;
@@ -311,7 +322,9 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows32k_kernel(ScnBigArgs args
   const uint32_t ld_voff = ((k1 >> 4) * 8u * 256u + (k1 & 15u) * 16u + bq) * 8u;  // + (a / 2) * 2048 + (a & 1) * 64
   v2f raw[16];
 #pragma unroll
-  for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rw, ld_voff, (a >> 1) * 2048u + (a & 1) * 64u, 2));
+  // (default cache policy, not non-temporal: the loads for a = 2 j and 2 j + 1 read the two 64-byte halves of the same 128-byte
+  // lines, and with the nt hint the second one fetched a third of them from HBM again: FETCH_SIZE 3.6e8 B per launch for 2.7e8)
+  for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rw, ld_voff, (a >> 1) * 2048u + (a & 1) * 64u, 0));
   scn_v2d twa[16];  // W_128^(b p): entry 2 b p of the plan's W_256 table (double)
 #pragma unroll
   for (int p = 1; p < 16; p++) twa[p] = args.tw256[(2u * bq * p) & 255u];
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows32k_kernel(ScnBigArgs args
     const float p = (float)__builtin_fma(xq.y, xq.y, xq.x * xq.x);
     pw[o] = p;
     gmax[o >> 2] = fmaxf(gmax[o >> 2], p);
-    if constexpr (SPEC) lds_out[k2_of(o) * 33u + rho] = db_of_power(p);
+    if constexpr (SPEC) lds_out[k2_of(o) * 32u + (rho ^ (pl << 2))] = db_of_power(p);
   }
   if constexpr (SPEC) {
     __syncthreads();
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(256, 3) void scn_big_rows32k_kernel(ScnBigArgs args
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       const uint32_t k2 = (t >> 5) + 8u * u, kk1 = t & 31u;
-      const float d = lds_out[k2 * 33u + kk1];
+      const float d = lds_out[k2 * 32u + (kk1 ^ ((t >> 5) << 2))];
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, (32u * i + kk1 + 256u * k2) * 4u, 0, 2);
     }
   }
@@ -448,7 +461,7 @@ hipError_t scn_launch_big(uint32_t n, int kind, bool dc, bool hits, bool spec, c
     else hipLaunchKernelGGL((scn_big_rows_kernel<false, true>), grid, dim3(256), lds, s, a);
   } else {
     const dim3 grid(8u * a.n_buffers);
-    const size_t lds32 = 32 * 162 * sizeof(v2f);  // 41.5 KB: the exchange (the 128 x 33 float output tile fits inside)
+    const size_t lds32 = 32 * 152 * sizeof(v2f);  // 38 KiB: the exchange (the 128 x 32 float output tile fits inside)
     if (hits && spec) hipLaunchKernelGGL((scn_big_rows32k_kernel<true, true>), grid, dim3(256), lds32, s, a);
     else if (hits) hipLaunchKernelGGL((scn_big_rows32k_kernel<true, false>), grid, dim3(256), lds32, s, a);
     else hipLaunchKernelGGL((scn_big_rows32k_kernel<false, true>), grid, dim3(256), lds32, s, a);

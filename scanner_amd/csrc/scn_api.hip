@@ -222,6 +222,15 @@ int check_slot(scn_plan *p, int slot) {
   return SCN_OK;
 }
 
+// SCN_PLAN_OVERLAP_SLOTS: the streams of slots 2 and 3 exist from their first use on
+int ensure_slot_stream(scn_plan *p, Slot &s) {
+  if (s.own_stream && !s.stream) {
+    SCN_HIP(hipSetDevice(p->d.device_id));
+    SCN_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  }
+  return SCN_OK;
+}
+
 // `gen`: the generation of hit regions / counts the coming submit writes (allocated when first used: a plan that only ever
 // drives one slot, or submits once per slot, holds one or two of the four region sets -- 201 MB each for the C2 plan)
 int ensure_slot_outputs(scn_plan *p, Slot &s, uint32_t gen) {
@@ -356,8 +365,9 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
   s.list_built = false;
   if (hits && nb) {
-    // this submit's generation; the only thing that can still be using it is the compaction of the submit FOUR launches
-    // back on this plan (two on this slot) -- wait for it on the host, where it never blocks in practice
+    // this submit's generation; the only thing that can still be using it is the list (compaction + copy) of the submit TWO
+    // submits back ON THIS SLOT -- 2 x (slots in use) launches back on the plan -- wait for it on the host, where it never
+    // blocks in practice
     s.gen ^= 1u;
     if (s.list_used[s.gen] && hipEventQuery(s.list_done[s.gen]) != hipSuccess) SCN_HIP(hipEventSynchronize(s.list_done[s.gen]));
     // the header fields: read by the compaction kernel in place, over PCIe (two 8-byte reads per buffer that has hits;
@@ -629,8 +639,11 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
       Slot &sl = p->slot[k];
       sl.stream = p->stream;
       if ((d.flags & SCN_PLAN_OVERLAP_SLOTS) && k > 0) {  // slot 0 keeps the plan's stream (scn_plan_stream)
-        SCN_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        // slot 1's stream now, those of slots 2 and 3 when they are first used (ensure_slot_stream): HIP maps streams onto
+        // 4 hardware queues, and a two-slot caller should not have five streams competing for them
         sl.own_stream = true;
+        sl.stream = nullptr;
+        if (k == 1) SCN_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
       }
     }
     // the transform length: the buffer length, except for sizes that are not powers of two (Bluestein, scn_generic.hip)
@@ -781,6 +794,7 @@ int scn_submit(scn_plan *p, int slot, uint32_t nb, const double *fc, const uint6
   if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
   if (!s.h_raw) return fail(SCN_E_STATE, "slot %d: scn_host_buffer was never called", slot);
   SCN_HIP(hipSetDevice(p->d.device_id));
+  if ((st = ensure_slot_stream(p, s))) return st;
   if (!s.d_raw) SCN_HIP(hipMalloc(&s.d_raw, p->buf_bytes * p->d.max_batch));
   if (nb) {
     // stage on the h2d stream so this copy overlaps the other slot's kernel; the compute stream
@@ -802,6 +816,7 @@ int scn_submit_device(scn_plan *p, int slot, const void *d_raw, uint32_t nb, con
   if (nb && (!fc || !d_raw)) return fail(SCN_E_INVALID, "null argument");
   if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
   SCN_HIP(hipSetDevice(p->d.device_id));
+  if ((st = ensure_slot_stream(p, s))) return st;
   return submit_common(p, s, d_raw, nb, fc, seq, d_power_db);
 }
 
@@ -980,6 +995,7 @@ extern "C" {
 int scn_slot_stream(scn_plan *p, int slot, void **hip_stream) {
   if (int st = check_slot(p, slot)) return st;
   if (!hip_stream) return fail(SCN_E_INVALID, "null argument");
+  if (int st = ensure_slot_stream(p, p->slot[slot])) return st;
   *hip_stream = (void *)p->slot[slot].stream;
   return SCN_OK;
 }

@@ -104,7 +104,12 @@ struct RawLoader<SCN_K_BYTE_COMPLEX> {
   typedef int raw_t;
   template <int AUX>
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
-    return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, AUX);
+    // (only bytes 0 and 1 of the register are ever read -- by the SDWA converts of conv() --, so the 16-bit load is taken as it
+    // comes: widening it in C++ costs a v_and_b32 per sample that buffer_load_ushort has already done)
+    int v;
+    const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, AUX);
+    asm("" : "=v"(v) : "0"(h));
+    return v;
   }
   template <int AUX>
   static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {

@@ -304,6 +304,16 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
 
 bool ProcessSamples::StartProcessing(SampleQueue &sampleQueue) {  // process.cpp:316-331
   m_sampleQueue = &sampleQueue;
+  // (a start that fails still empties the queue, or the producer blocks on a full one forever)
+  auto refuse = [&] {
+    while (SampleQueue::MessageType *m = sampleQueue.GetNextSamples()) sampleQueue.MessageProcessed(m);
+    return false;
+  };
+  if (scn_abi_version() != SCN_ABI_VERSION) {  // a libscanner_hip.so built from another header: slot count and entry points differ
+    Fail("ProcessSamples: libscanner_hip.so has ABI version " + std::to_string(scn_abi_version()) + ", this code was built against " +
+         std::to_string((unsigned)SCN_ABI_VERSION));
+    return refuse();
+  }
   // Triggered capture writes converted samples (fftwf_complex records); the queue holds raw ones, so give it K1
   // on the GPU through a small dedicated plan.  The converter is installed once, before any thread can call it,
   // and OWNS what it uses (plan and lock are shared_ptr captures): the queue's write thread may still be
@@ -322,7 +332,7 @@ bool ProcessSamples::StartProcessing(SampleQueue &sampleQueue) {  // process.cpp
     d.max_batch = 1;
     d.device_id = m_firstDevice;
     scn_plan *raw = nullptr;
-    if (!Ok(scn_plan_create(&d, &raw), "scn_plan_create")) return false;
+    if (!Ok(scn_plan_create(&d, &raw), "scn_plan_create")) return refuse();
     std::shared_ptr<scn_plan> plan(raw, [](scn_plan *p) { scn_plan_destroy(p); });
     std::shared_ptr<std::mutex> lock = std::make_shared<std::mutex>();
     const uint32_t n = m_sampleCount;

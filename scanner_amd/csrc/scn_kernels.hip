@@ -479,8 +479,8 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 // P2 = 256 + 16 / M, conflict-free within the 16-lane groups a ds_*_b64 is served in):
 //   pass 1  thread t = M b + c of a slot: 16-pt DFT over a of x[T a + t] w[T a + t] -> * W_N^(t p) -> LDS row p
 //   pass 2  thread (p, c): 16-pt DFT over b -> * W_(16 M)^(c q) -> LDS
-//   pass 3  M = 2: eight radix-2 butterflies per thread (kl = t + 32 u -> bins kl, kl + 256);  M = 1: nothing left to transform,
-//           the exchange only transposes (thread t stores bins t + 16 u)
+//   pass 3  M = 2: eight radix-2 butterflies per thread (kl = t + 32 u -> bins kl, kl + 256);  M = 1: there is none -- 256 = 16 x 16,
+//           pass 2's outputs are the spectrum (thread t stores its own bins t + 16 q: 64-byte runs per buffer)
 // One buffer descriptor spans the workgroup's SLOTS consecutive buffers (a wave holds two or four of them, so a per-buffer
 // descriptor would not be wave-uniform); slots past the end of the batch read zeros and store nothing (range check).
 // Hits: a wave is no longer one buffer, so slots in a buffer's region come from one LDS atomic per HIT (rare) on the slot's
@@ -600,19 +600,24 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
     for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * M]);
     load_group(rn, 6, 11);
     fft16(v);
+    if constexpr (M == 1) {
+      // 256 = 16 x 16: pass 2's outputs ARE the spectrum (thread t holds bins t + 16 q in v[OUT16(q)]): no twiddles (all
+      // ones), no second exchange (until round 4 it was written and read back by the same thread: 32 LDS accesses, 15 complex
+      // multiplies by one and two barriers per buffer for nothing)
+      load_group(rn, 11, 16);
+    } else {
 #pragma unroll
-    for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * M]));
-    __syncthreads();  // every exchange-1 read done before the area is re-used
-    load_group(rn, 11, 16);
+      for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * M]));
+      __syncthreads();  // every exchange-1 read done before the area is re-used
+      load_group(rn, 11, 16);
 #pragma unroll
-    for (int q = 0; q < 16; q++) w2[q * 16] = to_v2f(v[OUT16(q)]);
-    __syncthreads();
-    // ---- pass 3 ----
+      for (int q = 0; q < 16; q++) w2[q * 16] = to_v2f(v[OUT16(q)]);
+      __syncthreads();
+      // ---- pass 3: eight radix-2 butterflies per thread (kl = t + 32 u -> bins kl, kl + 256) ----
 #pragma unroll
-    for (int u = 0; u < 16 / M; u++)
+      for (int u = 0; u < 16 / M; u++)
 #pragma unroll
-      for (int c = 0; c < M; c++) v[u * M + c] = from_v2f(r3[c * P2 + T * u]);
-    if constexpr (M == 2) {
+        for (int c = 0; c < M; c++) v[u * M + c] = from_v2f(r3[c * P2 + T * u]);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const cf a = v[2 * u], b = v[2 * u + 1];
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
     const uint32_t st_voff = (slot * N + t) * 4u;
 #pragma unroll
     for (int o = 0; o < 16; o++) {
-      const float q = power_of(v[o]);
+      const float q = power_of(v[M == 1 ? OUT16(o) : o]);
       pw[o] = q;
       gmax[o >> 2] = fmaxf(gmax[o >> 2], q);
       if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 4u * joff_of(o), AUX_ST);

@@ -25,7 +25,8 @@ for n in sizes:
         for dc in ((False,) if kind == capi.KIND_FLOAT_COMPLEX else (False, True)):
             row = []
             for flags, mode in ((1, capi.MODE_FREQUENCY_DOMAIN), (3, capi.MODE_FREQUENCY_DOMAIN), (2, capi.MODE_FREQUENCY_DOMAIN), (3, capi.MODE_TIME_DOMAIN)):
-                p = Plan(n, 8000000, 10.0 + 5.0 * np.log10(n / 4096.0), kind=kind,   # (bench.py's default: the same margin over the noise mean at every size) enob=8 if kind == capi.KIND_BYTE_COMPLEX else 12, correct_dc=dc, max_batch=nb,
+                # threshold: bench.py's default (the same margin over the noise mean at every size)
+                p = Plan(n, 8000000, 10.0 + 5.0 * np.log10(n / 4096.0), kind=kind, enob=8 if kind == capi.KIND_BYTE_COMPLEX else 12, correct_dc=dc, max_batch=nb,
                          max_hits=nb * 64, flags=flags, mode=mode)
                 ext = torch.cuda.ExternalStream(p.stream_handle, device=dev)
                 td = mode == capi.MODE_TIME_DOMAIN

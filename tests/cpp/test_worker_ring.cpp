@@ -212,7 +212,7 @@ int main() {
   // 1. a fast producer, a "GPU" that takes its time: the ring fills up (three submits in flight) and is drained oldest first
   g_hitsPerBuffer = 2;
   g_failSubmitAt = -1;
-  g_collectSleepUs = 300;
+  g_collectSleepUs = 2000;  // (long against the producer's microseconds per buffer also on a loaded test host)
   std::vector<uint64_t> got = run(256, 4, 64, 6, ok);
   CHECK(ok);
   for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
@@ -237,7 +237,7 @@ int main() {
   // 4. the GPU path dies in the middle: every submit in flight is still reported (oldest first), every message goes back to
   //    the queue (the producer is not left blocked), StartProcessing says it failed
   g_hitsPerBuffer = 2;
-  g_collectSleepUs = 300;
+  g_collectSleepUs = 2000;  // (long against the producer's microseconds per buffer also on a loaded test host)
   g_failSubmitAt = fastSubmits / 2;
   got = run(256, 4, 64, 6, ok);
   CHECK(!ok);

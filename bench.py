@@ -387,6 +387,8 @@ def kernel_name(n, kind, hits=True, spectrum=True):
     """the kernel's name as rocprofv3 prints it: template arguments <.., KIND, DC, HITS, SPEC> (scn_kernels.hip)"""
     k = {"cfloat": "SCN_K_FLOAT_COMPLEX", "int16": "SCN_K_SHORT_COMPLEX", "int8": "SCN_K_BYTE_COMPLEX"}[kind]
     h, sp = ("true" if hits else "false"), ("true" if spectrum else "false")
+    if n in (16, 32, 64, 128):  # 1, 2, 4 or 8 threads per buffer
+        return f"scn_fft_tiny_kernel<{n // 16}, {k}, false, {h}, {sp}>"
     if n in (256, 512):  # several buffers per workgroup
         return f"scn_fft_small_kernel<{n // 256}, {k}, false, {h}, {sp}>"
     if n == 8192:

@@ -87,10 +87,10 @@ typedef struct scn_hit {
 typedef struct scn_plan_desc {
   uint32_t struct_size;
   uint32_t n;              /* sampleCount = FFT size (scan.cpp:85; the reference plans any count, fft.cpp:4-11): any size from
-                              16 to 65536.  256 ... 16384 (powers of two) run in fused single-pass LDS kernels, 32768 and
-                              65536 in a four-step pair of kernels (integer DC removal included); the other sizes through
-                              a staged, slower path (Bluestein for the sizes that are not powers of two) with the same
-                              outputs.  scn_size_path tells which. */
+                              16 to 65536.  The powers of two from 16 to 16384 run in fused single-pass LDS kernels, 32768
+                              and 65536 in a four-step pair of kernels (integer DC removal included); the sizes that are
+                              not powers of two through a staged, slower path (Bluestein, in double) with the same outputs.
+                              scn_size_path tells which. */
   uint32_t sample_rate;    /* Hz (scan.cpp:92) */
   uint32_t sample_kind;    /* SCN_KIND_* */
   uint32_t enob;           /* effective bits (scan.cpp:138,183) */
@@ -127,9 +127,10 @@ int scn_device_count(int *count);
  * wants to know, and what the parity tests walk so that no fused specialisation goes untested. */
 enum {
   SCN_PATH_UNSUPPORTED = 0,
-  SCN_PATH_FUSED = 1,     /* one launch, the FFT staged in LDS (256 ... 16384) */
+  SCN_PATH_FUSED = 1,     /* one launch, the FFT staged in LDS (the powers of two 16 ... 16384) */
   SCN_PATH_FOUR_STEP = 2, /* two launches around a work buffer (32768, 65536) */
-  SCN_PATH_STAGED = 3,    /* one launch per radix stage through HBM, in double (the other powers of two from 16 up) */
+  SCN_PATH_STAGED = 3,    /* one launch per radix stage through HBM, in double.  No size reports it any more (until round 4:
+                             16 ... 128); the stages live on as the transform inside SCN_PATH_BLUESTEIN */
   SCN_PATH_BLUESTEIN = 4  /* the staged path around a chirp-z convolution (sizes that are not powers of two) */
 };
 int scn_size_path(uint32_t n, uint32_t *path);

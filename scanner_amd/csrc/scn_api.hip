@@ -585,8 +585,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
   if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !scn_generic_size_supported(d.n) &&
       !scn_bluestein_size_supported(d.n))
-    return fail(SCN_E_INVALID, "unsupported FFT size %u (16 to 65536; fused kernels for "
-                "1024 ... 16384)", d.n);
+    return fail(SCN_E_INVALID, "unsupported FFT size %u (16 to 65536)", d.n);
   if (d.n == 0 || d.n > (1u << 24)) return fail(SCN_E_INVALID, "bad sample count %u", d.n);
   if (d.sample_rate == 0) return fail(SCN_E_INVALID, "sample_rate must be > 0");
 

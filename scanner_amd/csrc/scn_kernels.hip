@@ -520,13 +520,15 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
     const uint32_t nb = ok ? (args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS) : 0u;
     return make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(ok ? first : 0u) * buf_bytes, nb * buf_bytes);
   };
-  // planar int16 reads I and Q of a buffer n samples apart: the loader takes the buffer's own sample count, the slot offset
-  // goes into the index (in samples of the loader's element size)
+  // planar int16 reads I and Q of a buffer n samples apart: the loader takes the buffer's own sample count.  The slot's offset
+  // goes into the PER-LANE index, the part that depends on `a` only into the wave-uniform one: a wave holds several slots, and
+  // until round 4 the slot offset sat in the uniform operand -- hipcc then wraps every load in a waterfall loop (one trip per
+  // distinct slot in the wave: four at 256 points, 80 s_nop and 32 v_readfirstlane per iteration)
   typename L::raw_t raw[16];
   auto load_group = [&](const __amdgpu_buffer_rsrc_t &r, int a_lo, int a_hi) {
 #pragma unroll
     for (int a = 0; a < 16; a++)
-      if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(r, N, t, slot * (KIND == SCN_K_SHORT ? 2u * N : N) + T * a);
+      if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(r, N, t + slot * (KIND == SCN_K_SHORT ? 2u * N : N), T * a);
   };
   uint32_t first = blockIdx.x * SLOTS;
   load_group(in_rsrc(first), 0, 16);
@@ -685,6 +687,216 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
         if (args.host_hits) args.host_hits[buf] = (uint32_t)lds_hits[slot];
       }
       lds_hits[slot] = 0;  // (the next recording is three barriers away)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 16, 32, 64 and 128 points (round 4): N = 16 R with R = 1, 2, 4, 8 THREADS per buffer.
+//
+// fft.cpp:4-11 plans whatever --count it is given; these sizes ran the staged double-precision path (39 Gsamples/s at 128
+// points).  n = R a + c, k = p + 16 r:
+//   X[p + 16 r] = sum_c W_R^(c r) * ( W_N^(c p) * sum_a W_16^(a p) x[R a + c] w[R a + c] )
+//   pass 1  thread c of a buffer: the 16-point DFT over a of its 16 samples, * W_N^(c p) -> LDS [p][c]
+//   pass 2  thread c': the R-point DFTs over c for ITS 16 / R values of p = c' + R m; output o = R m + r is bin c' + R m + 16 r
+//   R = 1: one thread holds the whole buffer, there is no exchange at all.
+// A 256-thread workgroup carries SLOTS = 256 / R consecutive buffers per iteration (4096 samples, as everywhere), under one
+// descriptor like scn_fft_small_kernel, hits with the slot's own LDS counter like there.  The exchange is [p][R + 1] per
+// buffer with R + 16 slots of padding between buffers: both sides conflict-free (16-lane write groups, 32-lane read groups;
+// found by enumeration).  Global loads and stores move runs of R samples / R bins per buffer -- 64 bytes at 128 points, one
+// element at 16: the small end of this family is bound by the number of memory requests, not by bytes.
+// ------------------------------------------------------------------------------------
+namespace {
+template <int R>
+struct GeoTiny {
+  static constexpr uint32_t N = 16u * R, T = R, SLOTS = 256u / R;
+  static constexpr uint32_t P1 = R + 1u;
+  static constexpr uint32_t EXCH = R == 1 ? 0u : 16u * P1 + R;  // slots per buffer
+  static constexpr uint32_t LDS_BYTES = SLOTS * EXCH * 8u + SLOTS * 4u + 16u;
+  static constexpr uint32_t WG_PER_CU = 3;
+};
+}  // namespace
+
+template <int R, int KIND, bool DC, bool HITS, bool SPEC>
+__global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
+  static_assert(R == 1 || R == 2 || R == 4 || R == 8, "16, 32, 64 or 128 points");
+  static_assert(HITS || SPEC, "a kernel that reports nothing");
+  typedef GeoTiny<R> G;
+  constexpr int AUX_LD = SCN_AUX_LD;
+  constexpr int AUX_ST = SCN_AUX_ST;
+  constexpr uint32_t N = G::N, SLOTS = G::SLOTS, P1 = G::P1;
+  typedef RawLoader<KIND> L;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint32_t tid = threadIdx.x, t = tid % R, slot = tid / R;
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw) + slot * G::EXCH;                  // this buffer's exchange area
+  int *lds_hits = reinterpret_cast<int *>(reinterpret_cast<v2f *>(smem_raw) + SLOTS * G::EXCH);  // [SLOTS]
+  const uint32_t buf_bytes = L::kBufBytes(N);
+
+  auto in_rsrc = [&](uint32_t first) {  // the iteration's SLOTS consecutive buffers (zero records past the end of the batch)
+    const bool ok = first < args.n_buffers;
+    const uint32_t nb = ok ? (args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS) : 0u;
+    return make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(ok ? first : 0u) * buf_bytes, nb * buf_bytes);
+  };
+  typename L::raw_t raw[16];
+  auto load_group = [&](const __amdgpu_buffer_rsrc_t &r, int a_lo, int a_hi) {  // (slot offset per lane, R a wave-uniform: see scn_fft_small_kernel)
+#pragma unroll
+    for (int a = 0; a < 16; a++)
+      if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(r, N, t + slot * (KIND == SCN_K_SHORT ? 2u * N : N), R * a);
+  };
+  uint32_t first = blockIdx.x * SLOTS;
+  load_group(in_rsrc(first), 0, 16);
+
+  cf tw1[16];
+  if constexpr (R > 1) {
+#pragma unroll
+    for (int p = 1; p < 16; p++) tw1[p] = from_v2f(args.tw1_table[(p - 1) * R + t]);  // W_N^(c p)
+  }
+  float win[16];
+#pragma unroll
+  for (int a = 0; a < 16; a++) win[a] = args.window[R * a + t] * args.scale;
+  if (HITS) {
+    if (tid < SLOTS) lds_hits[tid] = 0;
+    __syncthreads();
+  }
+
+  auto joff_of = [](int o) -> uint32_t { return R * ((uint32_t)o / R) + 16u * ((uint32_t)o % R); };  // output o is bin t + joff_of(o)
+  uint32_t keepmask = 0;
+  if (HITS) {
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+      const uint32_t j = t + joff_of(o);
+      const uint32_t i = j ^ (N / 2);  // (j + N/2) % N, process.cpp:47
+      const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
+      keepmask |= keep ? (1u << o) : 0u;
+    }
+  }
+
+  for (; first < args.n_buffers; first += gridDim.x * SLOTS) {
+    const uint32_t buf = first + slot;
+    const bool valid = buf < args.n_buffers;
+    int dc_re = 0, dc_im = 0;
+    if (DC) {  // integer mean with the reference's int32 /= uint32 quirk (utility.cpp:77-78), summed over the R lanes of this buffer
+      int sr = 0, si = 0;
+#pragma unroll
+      for (int a = 0; a < 16; a++) {
+        int re, im;
+        L::ints(raw[a], re, im);
+        sr += re;
+        si += im;
+      }
+#pragma unroll
+      for (uint32_t off = R / 2; off > 0; off >>= 1) {
+        sr += __shfl_xor(sr, (int)off, 64);
+        si += __shfl_xor(si, (int)off, 64);
+      }
+      dc_re = (int)((uint32_t)sr / N);
+      dc_im = (int)((uint32_t)si / N);
+    }
+    cf v[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, 1.0f) * win[a];
+    const __amdgpu_buffer_rsrc_t rn = in_rsrc(first + gridDim.x * SLOTS);
+    load_group(rn, 0, 8);
+
+    // ---- pass 1 ----
+    fft16(v);
+    cf x[16];  // output o = R m + r
+    if constexpr (R == 1) {
+#pragma unroll
+      for (int o = 0; o < 16; o++) x[o] = v[OUT16(o)];
+      load_group(rn, 8, 16);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        cf y = v[OUT16(p)];
+        if (p) y = cmul(y, tw1[p]);
+        lds[p * P1 + t] = to_v2f(y);
+      }
+      __syncthreads();
+      // ---- pass 2: R-point DFTs over c, for p = t + R m ----
+#pragma unroll
+      for (int m = 0; m < 16 / R; m++)
+#pragma unroll
+        for (int c = 0; c < R; c++) x[m * R + c] = from_v2f(lds[(t + R * m) * P1 + c]);
+      load_group(rn, 8, 16);
+#pragma unroll
+      for (int m = 0; m < 16 / R; m++) {
+        if constexpr (R == 2) {
+          const cf a = x[2 * m], b = x[2 * m + 1];
+          x[2 * m] = a + b;
+          x[2 * m + 1] = a - b;
+        } else if constexpr (R == 4) {
+          radix4(x[4 * m], x[4 * m + 1], x[4 * m + 2], x[4 * m + 3]);
+        } else {
+          cf z[8];
+#pragma unroll
+          for (int c = 0; c < 8; c++) z[c] = x[8 * m + c];
+          fft8(z);
+#pragma unroll
+          for (int r = 0; r < 8; r++) x[8 * m + r] = z[OUT8(r)];
+        }
+      }
+    }
+    // ---- K4 (see scn_fft_kernel) ----
+    v16f pw;
+    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t nvalid = args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS;
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, (SPEC && args.power_db) ? nvalid * 4u * N : 0u);
+    const uint32_t st_voff = (slot * N + t) * 4u;
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+      const float q = power_of(x[o]);
+      pw[o] = q;
+      gmax[o >> 2] = fmaxf(gmax[o >> 2], q);
+      if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 4u * joff_of(o), AUX_ST);
+    }
+    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
+    if constexpr (SPEC) {
+      if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+            for (int o = 4 * g; o < 4 * g + 4; o++) {
+              const float q = pw[o];
+              if (__ballot(q >= SCN_P_EXACT_FROM)) {
+                const float d = db_exact(q);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 4u * joff_of(o), AUX_ST);
+              }
+            }
+          }
+        }
+      }
+    }
+    // ---- K5: every hit takes its slot of the buffer's region with its own LDS atomic (scn_fft_small_kernel) ----
+    if (HITS) {
+      if (__ballot(valid && pmax > args.p_lo)) {
+        uint32_t cand = 0;
+#pragma unroll
+        for (int o = 0; o < 16; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
+        cand &= valid ? keepmask : 0u;
+        ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+        while (__ballot(cand != 0u)) {
+          const bool act = cand != 0u;
+          const uint32_t o = act ? (uint32_t)__builtin_ctz(cand) : 0u;
+          cand &= cand - 1u;
+          const float q = scn_select_output<16>(pw, o);
+          float d = db_fast(q);
+          if (__ballot(act && q >= SCN_P_EXACT_FROM)) d = q >= SCN_P_EXACT_FROM ? db_exact(q) : d;
+          if (act && d > args.threshold) {  // strict >, process.cpp:54
+            const uint32_t pos = (uint32_t)atomicAdd(&lds_hits[slot], 1);
+            if (pos < args.hit_region) region[pos] = ScnDevHit{(t + joff_of((int)o)) ^ (N / 2), d};
+          }
+        }
+      }
+    }
+    if (R > 1) __syncthreads();  // exchange areas free again; the slots' hit counters final (R = 1: a slot is one thread's own)
+    if (HITS && t == 0) {
+      if (valid) {
+        args.per_buffer_hits[buf] = (uint32_t)lds_hits[slot];
+        if (args.host_hits) args.host_hits[buf] = (uint32_t)lds_hits[slot];
+      }
+      lds_hits[slot] = 0;  // (the next recording is a barrier away)
     }
   }
 }
@@ -1324,7 +1536,9 @@ __global__ __launch_bounds__(256) void scn_time_domain_wave_kernel(ScnTdArgs arg
   typedef int v4i_t __attribute__((__vector_size__(16)));
   constexpr bool PLANAR = KIND == SCN_K_SHORT;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
+  // (readfirstlane: the wave index is wave-uniform, which hipcc cannot see -- without it every load of the buffer's descriptor
+  //  sits in a one-trip waterfall loop)
+  const uint32_t gw = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = gridDim.x * 4u;
   const uint32_t N = args.n;
   const uint32_t bytes = L::kBufBytes(N);
   const uint32_t stream_bytes = PLANAR ? 2u * N : bytes;  // planar: the I block, then the Q block
@@ -1529,6 +1743,18 @@ struct SmallFamily {
     };
   };
 };
+template <int R>
+struct TinyFamily {
+  typedef GeoTiny<R> G;
+  static constexpr uint32_t THREADS = 256, SLOTS = G::SLOTS;
+  template <int KIND>
+  struct K {
+    template <bool DC, bool HITS, bool SPEC>
+    struct T {
+      static constexpr void (*fn)(ScnFftArgs) = scn_fft_tiny_kernel<R, KIND, DC, HITS, SPEC>;
+    };
+  };
+};
 struct Family8k {
   typedef Geo8k G;
   static constexpr uint32_t THREADS = G::T, SLOTS = 1;
@@ -1586,6 +1812,10 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, bool spec, c
   // (256 / 512 points: one descriptor spans a workgroup's SLOTS buffers only, but the per-lane offsets are 32-bit)
   if (n < 1024 && (uint64_t)args.n_buffers * n * 8u > 0xffffffffull) return hipErrorInvalidValue;
   switch (n) {
+    case 16: return launch_family<TinyFamily<1>>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 32: return launch_family<TinyFamily<2>>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 64: return launch_family<TinyFamily<4>>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 128: return launch_family<TinyFamily<8>>(kind, dc, hits, spec, args, num_cus, stream, stop);
     case 256: return launch_family<SmallFamily<1>>(kind, dc, hits, spec, args, num_cus, stream, stop);
     case 512: return launch_family<SmallFamily<2>>(kind, dc, hits, spec, args, num_cus, stream, stop);
     case 1024: return launch_family<NarrowFamily<4>>(kind, dc, hits, spec, args, num_cus, stream, stop);
@@ -1597,7 +1827,7 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, bool spec, c
   }
 }
 
-bool scn_fft_size_supported(uint32_t n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
+bool scn_fft_size_supported(uint32_t n) { return n >= 16 && n <= 16384 && (n & (n - 1u)) == 0u; }
 
 // layout of ScnFftArgs::tw1_table for size n: `rows` rows of `threads` entries, row p-1 = W_n^(t p): 15 rows of n/16 for the
 // 16 x 16 x M kernels, 31 rows of 512 for the 32 x 16 x 32 form of 16384 points

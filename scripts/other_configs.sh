@@ -26,7 +26,9 @@ run --n 65536 --batch 512 --steps 200 --warmup 20    # the four-step pair (scn_b
 run --n 65536 --batch 512 --kind int16 --steps 200 --warmup 20
 run --n 32768 --batch 1024 --steps 200 --warmup 20   # the four-step pair, 256 x 128
 run --n 32768 --batch 1024 --kind int16 --steps 200 --warmup 20
-run --n 128 --batch 65536 --steps 20 --warmup 3      # the staged path: a power of two without a fused kernel
+run --n 128 --batch 262144                          # eight threads per buffer (scn_fft_tiny_kernel)
+run --n 64 --batch 262144
+run --n 16 --batch 524288                           # one thread per buffer
 run --n 1000 --batch 4096 --steps 20 --warmup 3      # Bluestein
 run --welch --welch-psd 32 --steps 100 --warmup 10
 run --welch --welch-psd 8 --welch-pinned --steps 20 --warmup 3

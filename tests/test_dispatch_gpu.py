@@ -30,9 +30,9 @@ NAMES = {capi.KIND_FLOAT_COMPLEX: "cfloat", capi.KIND_SHORT_COMPLEX: "int16", ca
 
 
 def test_the_fused_sizes_are_the_documented_ones():
-    assert FUSED_SIZES == [256, 512, 1024, 2048, 4096, 8192, 16384]
+    assert FUSED_SIZES == [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
     assert capi.size_path(32768) == capi.size_path(65536) == capi.PATH_FOUR_STEP
-    assert capi.size_path(128) == capi.PATH_STAGED and capi.size_path(1000) == capi.PATH_BLUESTEIN
+    assert capi.size_path(1000) == capi.size_path(17) == capi.size_path(65535) == capi.PATH_BLUESTEIN
     assert capi.size_path(8) == capi.size_path(65537) == capi.PATH_UNSUPPORTED
 
 
@@ -69,10 +69,13 @@ def test_every_fused_specialisation_vs_oracle(built_lib, oracle_mod, n, kind, en
         # whose other bins are cancellation residue, where two correct float32 FFTs differ by whole dB -- so the few buffers
         # whose I or Q sum is not positive (a strong tone below one bin of frequency) are replaced by the first good one
         info = np.iinfo(raw.dtype)
-        raw = np.clip(raw.astype(np.int32) + (60 if raw.dtype == np.int16 else 11), info.min, info.max).astype(raw.dtype)
+        # (below 256 points a tone's sum over the buffer is no longer small against n times the offset: a larger offset, and
+        #  more replaced buffers allowed)
+        off = (60 if n >= 256 else 400) if raw.dtype == np.int16 else (11 if n >= 256 else 30)
+        raw = np.clip(raw.astype(np.int32) + off, info.min, info.max).astype(raw.dtype)
         sums = raw.astype(np.int64).sum(axis=2 if kind == capi.KIND_SHORT else 1)   # [B, 2]: I and Q sums of every buffer
         bad = (sums <= 0).any(axis=1)
-        assert bad.mean() < 0.05
+        assert bad.mean() < (0.05 if n >= 256 else 0.3)
         raw[bad] = raw[np.flatnonzero(~bad)[0]]
     fc = 70e6 + 6e6 * np.arange(nb)
     seq = np.arange(nb, dtype=np.uint64) + (1 << 33)
@@ -88,7 +91,7 @@ def test_every_fused_specialisation_vs_oracle(built_lib, oracle_mod, n, kind, en
     _, h_ref, _ = o.run(raw, fc, seq, want_power=False, threads=8)
     # process_fft's return value, hits > trigger_count (process.cpp:62), with the count at the batch's median so that about
     # half of the flags are set
-    trig_count = int(np.median(np.bincount((h_ref["seq_id"] - seq[0]).astype(np.int64), minlength=nb)))
+    trig_count = max(1, int(np.median(np.bincount((h_ref["seq_id"] - seq[0]).astype(np.int64), minlength=nb))))  # (0 means "the reference's 1047" to a plan)
     o.params.trigger_count = trig_count
     _, h_ref, t_ref = o.run(raw, fc, seq, want_power=False, threads=8)
     hs_ref = h_ref[h_ref["seq_id"] < seq[0] + np.uint64(small)]

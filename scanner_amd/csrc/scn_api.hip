@@ -395,7 +395,16 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.hits = s.d_hits[s.gen];
   a.hit_region = p->hit_region;
   a.per_buffer_hits = s.d_buf_hits[s.gen];
-  a.host_hits = (hits && p->direct_counts) ? s.h_buf_hits : nullptr;
+  // The per-buffer counts reach the host either by a DMA behind the kernel or by the kernel's own stores to pinned memory
+  // (4 bytes per buffer over PCIe: nothing beside the launch's HBM traffic).  The kernel stores them itself from 8192 points up
+  // (few buffers per launch) and -- round 4 -- whenever the ordered list follows eagerly: the list's DMA and the counts' DMA
+  // would share the D2H stream, and every DMA that has to wait for its predecessor starts ~20 us after it (the runtime
+  // resolves the dependency on the host), so two per submit made that stream the records loop's bottleneck (46 + 21 + 5 + 20 =
+  // 92 us per submit against 73 us of FFT: scripts/abi_trace.sh, profiles/r04_experiments.md section 10; same box, three in
+  // flight, records read in place: 373 .. 403 -> 429 Gsamples/s).
+  const bool eager = hits && nb && p->records_wanted;
+  const bool direct = p->direct_counts || (eager && !p->generic && !p->big && !s.own_stream);
+  a.host_hits = (hits && direct) ? s.h_buf_hits : nullptr;
   a.work_counter = s.d_work_counter;
   for (uint32_t x = 0; x < 8; x++) a.work_base[x] = s.work_base[x];
   // What follows the kernel: the counts (a DMA on the d2h stream: needs no CU -- or nothing, when the kernel stores them to
@@ -403,8 +412,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   // the list stream, beside the next launch).  With overlapped slots both follow the kernel on the slot's own stream --
   // its next kernel is two submits away, and fewer streams keep both compute streams on hardware queues of their own
   // (HIP maps streams onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one).
-  const bool eager = hits && nb && p->records_wanted;
-  hipStream_t cnt = (s.own_stream || p->direct_counts) ? s.stream : p->d2h_stream;
+  hipStream_t cnt = (s.own_stream || direct) ? s.stream : p->d2h_stream;
   hipStream_t lst = list_stream_of(p, s);
   const bool fork_list = eager && lst != s.stream;
   // ONE event marks the kernel's end for whoever waits for it: the host (`done`, when nothing else follows on the compute
@@ -474,7 +482,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     if (after && !in_packet) SCN_HIP(hipEventRecord(after, s.stream));
     if (cnt != s.stream) SCN_HIP(hipStreamWaitEvent(cnt, after, 0));
     if (fork_list) SCN_HIP(hipStreamWaitEvent(lst, after, 0));
-    if (!p->direct_counts)
+    if (!direct)
       SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits[s.gen], sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, cnt));
     if (!(after_is_done && after)) SCN_HIP(hipEventRecord(s.done, cnt));
     if (eager) {

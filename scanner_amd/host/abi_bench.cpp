@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/scanner_hip.h"
@@ -77,7 +78,7 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 int main(int argc, char **argv) {
   uint32_t n = 4096, batch = 8192, steps = 300, warmup = 50, depth = 3, rotate = 4, extra_flags = 0;
   float threshold = 10.0f;
-  std::string kind = "cfloat", mode = "copy", lib = "";
+  std::string kind = "cfloat", mode = "copy", lib = "", host_log = "";
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string a = argv[i], v = argv[i + 1];
     if (a == "--n") n = (uint32_t)atoi(v.c_str());
@@ -91,6 +92,7 @@ int main(int argc, char **argv) {
     else if (a == "--kind") kind = v;
     else if (a == "--mode") mode = v;
     else if (a == "--lib") lib = v;
+    else if (a == "--host-log") host_log = v;  // per-call host timestamps of the timed steps (steady_clock ns: the clock rocprofv3 stamps with)
     else {
       fprintf(stderr, "abi_bench: unknown argument %s\n", a.c_str());
       return 2;
@@ -219,7 +221,14 @@ int main(int argc, char **argv) {
   std::vector<uint8_t> trig(batch);
   std::vector<bool> pending(depth, false);
   uint64_t hits_seen = 0, checksum = 0;
-  double collect_s = 0;
+  double collect_s = 0, submit_s = 0;
+  std::vector<float> submit_us, collect_us;  // per call, for the percentiles
+  struct Call {
+    char what;
+    uint32_t slot;
+    double t0, t1;
+  };
+  std::vector<Call> calls;
   uint64_t collects = 0;
   int rc = 0;
   auto collect = [&](uint32_t s) {
@@ -227,6 +236,7 @@ int main(int argc, char **argv) {
     uint32_t nh = 0;
     int st = api.collect(plan, (int)s, nullptr, mode == "copy" ? rec.data() : nullptr, mode == "copy" ? (uint32_t)rec.size() : 0u, &nh, trig.data());
     if (st == SCN_OK && mode == "view") {
+      if (!host_log.empty()) calls.push_back({'c', s, t0, now()});  // (scn_collect alone; the 'C' record is collect + view)
       const scn_hit *v = nullptr;
       uint32_t nv = 0;
       st = api.hits_view(plan, (int)s, &v, &nv);
@@ -240,6 +250,8 @@ int main(int argc, char **argv) {
     }
     hits_seen += nh;
     collect_s += now() - t0;
+    collect_us.push_back((float)((now() - t0) * 1e6));
+    if (!host_log.empty()) calls.push_back({'C', s, t0, now()});
     collects++;
     pending[s] = false;
   };
@@ -248,10 +260,14 @@ int main(int argc, char **argv) {
     const uint32_t s = (uint32_t)(launch % depth), r = (uint32_t)(launch % rotate);
     launch++;
     if (pending[s]) collect(s);
+    const double t0 = now();
     if (api.submit_device(plan, (int)s, d_in[r], batch, fc.data(), seq.data(), static_cast<float *>(d_out[r])) != SCN_OK && !rc) {
       fprintf(stderr, "abi_bench: submit: %s\n", api.last_error());
       rc = 3;
     }
+    submit_s += now() - t0;
+    submit_us.push_back((float)((now() - t0) * 1e6));
+    if (!host_log.empty()) calls.push_back({'S', s, t0, now()});
     pending[s] = true;
   };
   auto drain = [&]() {
@@ -270,20 +286,37 @@ int main(int argc, char **argv) {
   drain();
   HIPCK(hipDeviceSynchronize());
   hits_seen = 0;
-  collect_s = 0;
+  collect_s = submit_s = 0;
   collects = 0;
+  submit_us.clear();
+  collect_us.clear();
+  calls.clear();
   const double t0 = now();
   for (uint32_t k = 0; k < steps; k++) step();
   drain();
   HIPCK(hipDeviceSynchronize());
   const double el = now() - t0;
   api.plan_destroy(plan);
+  auto pct = [](std::vector<float> &v, double q) -> double {
+    if (v.empty()) return 0.0;
+    std::sort(v.begin(), v.end());
+    return v[std::min(v.size() - 1, (size_t)(q * v.size()))];
+  };
+  fprintf(stderr, "abi_bench: host us per call  submit p50 %.1f p90 %.1f p99 %.1f max %.1f | collect p50 %.1f p90 %.1f p99 %.1f max %.1f\n",
+          pct(submit_us, 0.5), pct(submit_us, 0.9), pct(submit_us, 0.99), pct(submit_us, 1.0), pct(collect_us, 0.5), pct(collect_us, 0.9),
+          pct(collect_us, 0.99), pct(collect_us, 1.0));
+  if (!host_log.empty()) {
+    FILE *f = fopen(host_log.c_str(), "w");
+    for (const Call &c : calls)
+      if (f) fprintf(f, "%c %u %.0f %.0f\n", c.what, c.slot, c.t0 * 1e9, c.t1 * 1e9);
+    if (f) fclose(f);
+  }
   int hip_version = 0;
   (void)hipRuntimeGetVersion(&hip_version);
   printf("{\"value\": %.1f, \"unit\": \"Msamples/s\", \"ms_per_step\": %.5f, \"steps\": %u, \"n\": %u, \"batch\": %u, \"kind\": \"%s\", \"mode\": \"%s\", "
-         "\"submits_in_flight\": %u, \"hits_per_step\": %.1f, \"collect_call_avg_us\": %.1f, \"settle_steps\": %llu, \"hip_runtime_version\": %d, "
+         "\"submits_in_flight\": %u, \"hits_per_step\": %.1f, \"collect_call_avg_us\": %.1f, \"submit_call_avg_us\": %.1f, \"settle_steps\": %llu, \"hip_runtime_version\": %d, "
          "\"checksum\": %llu}\n",
          (double)batch * n * steps / el / 1e6, el / steps * 1e3, steps, n, batch, kind.c_str(), mode.c_str(), depth, (double)hits_seen / steps,
-         collects ? collect_s / collects * 1e6 : 0.0, (unsigned long long)settle, hip_version, (unsigned long long)checksum);
+         collects ? collect_s / collects * 1e6 : 0.0, submit_s / steps * 1e6, (unsigned long long)settle, hip_version, (unsigned long long)checksum);
   return rc;
 }

@@ -395,15 +395,16 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   a.hits = s.d_hits[s.gen];
   a.hit_region = p->hit_region;
   a.per_buffer_hits = s.d_buf_hits[s.gen];
-  // The per-buffer counts reach the host either by a DMA behind the kernel or by the kernel's own stores to pinned memory
-  // (4 bytes per buffer over PCIe: nothing beside the launch's HBM traffic).  The kernel stores them itself from 8192 points up
-  // (few buffers per launch) and -- round 4 -- whenever the ordered list follows eagerly: the list's DMA and the counts' DMA
-  // would share the D2H stream, and every DMA that has to wait for its predecessor starts ~20 us after it (the runtime
-  // resolves the dependency on the host), so two per submit made that stream the records loop's bottleneck (46 + 21 + 5 + 20 =
-  // 92 us per submit against 73 us of FFT: scripts/abi_trace.sh, profiles/r04_experiments.md section 10; same box, three in
-  // flight, records read in place: 373 .. 403 -> 429 Gsamples/s).
+  // The per-buffer counts reach the host either by a DMA behind the kernel or by the kernel's own stores to pinned memory.
+  // Both have a price (profiles/r04_experiments.md section 10).  A store over PCIe holds its wave's in-order memory returns up:
+  // ~0.4 ns per buffer on the launch (8192 buffers: 73.5 -> 76.7 us; 32768 1024-point buffers: 75 -> 96 us).  A DMA that waits
+  // for a kernel or for another DMA starts ~20 us after it (the runtime resolves the dependency on the host): nothing in a
+  // steady loop of long launches, but the whole difference for short ones (2048 buffers per launch, three in flight: 25.5
+  // -> 19.3 us per step), and fatal when the ordered list's DMA shares the D2H stream with it (two per submit: 92 us per submit
+  // on that stream against 73 us of FFT; records read in place, three in flight: 373 .. 403 -> 429 Gsamples/s).  So the kernel
+  // stores the counts itself when the launch has few buffers or the list follows eagerly, and a DMA carries them otherwise.
   const bool eager = hits && nb && p->records_wanted;
-  const bool direct = p->direct_counts || (eager && !p->generic && !p->big && !s.own_stream);
+  const bool direct = !p->generic && !p->big && (p->direct_counts || nb <= 4096u || eager);
   a.host_hits = (hits && direct) ? s.h_buf_hits : nullptr;
   a.work_counter = s.d_work_counter;
   for (uint32_t x = 0; x < 8; x++) a.work_base[x] = s.work_base[x];

@@ -17,6 +17,7 @@ run --n 4096 --batch 8192 --kind int16
 run --n 4096 --batch 8192 --kind int8
 run --n 4096 --batch 2048
 run --config c4
+run --n 8192 --batch 4096 --kind int8               # the reference's defaults: --count 8192 on a HackRF (int8)
 run --n 16384 --batch 2048
 run --n 16384 --batch 2048 --kind int16
 run --n 512 --batch 65536                           # several buffers per workgroup (scn_fft_small_kernel)

@@ -3,6 +3,7 @@
 # bench lines of the same build next to them.   usage: scripts/prof_all.sh <round tag>
 TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
+bash scripts/prof.sh ${TAG}_c1 --n 1024 --batch 32768 > /dev/null 2>&1
 bash scripts/prof.sh ${TAG}_c2 > /dev/null 2>&1
 bash scripts/prof.sh ${TAG}_c3 --n 8192 --kind int16 --batch 4096 > /dev/null 2>&1
 bash scripts/prof.sh ${TAG}_c4shape --batch 2048 > /dev/null 2>&1
@@ -14,7 +15,9 @@ if [ -n "$SCN_PROF_MORE" ]; then   # the other wire formats and sizes (not BASEL
   bash scripts/prof.sh ${TAG}_n16384cfloat --n 16384 --batch 2048 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n16384int16 --n 16384 --batch 2048 --kind int16 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n512cfloat --n 512 --batch 65536 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n256cfloat --n 256 --batch 131072 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n128cfloat --n 128 --batch 262144 > /dev/null 2>&1
   SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n65536cfloat --n 65536 --batch 512 > /dev/null 2>&1
   SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n32768cfloat --n 32768 --batch 1024 > /dev/null 2>&1
 fi
-for c in c2 c3 c4shape c5; do echo "=== $c"; cat gpurun_out/prof_${TAG}_$c/summary.txt; done
+for c in c1 c2 c3 c4shape c5; do echo "=== $c"; cat gpurun_out/prof_${TAG}_$c/summary.txt; done

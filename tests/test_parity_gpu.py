@@ -797,6 +797,33 @@ def test_ragged_batches(torch_cuda, oracle_mod, nb):
         assert e.value.status == capi.E_INVALID
 
 
+def test_counts_by_kernel_stores_and_by_dma_agree(torch_cuda, oracle_mod):
+    """The per-buffer counts reach the host by the kernel's own stores to pinned memory for launches of up to 4096 buffers
+    (and whenever the ordered list follows eagerly) and by a DMA above (scn_api.hip, submit_common): both sides of that
+    line, on one plan, counts-only collects first (no eager list), then with records (eager list: stores again)."""
+    n, nb = 1024, 4200
+    x = synth.cfloat_batch(n, nb, seed=77, max_tones=2)
+    fc = 2e9 + 6e6 * np.arange(nb)
+    thr = _clear_threshold(oracle_mod, n, [x], 9.0)
+    o = oracle_mod.Oracle(n, FS, thr)
+    o.params.trigger_count = 3
+    _, h_ref, t_ref = o.run(x, fc, want_power=False, threads=8)
+    c_ref = np.bincount(h_ref["seq_id"].astype(np.int64), minlength=nb)
+    assert t_ref.any() and not t_ref.all()
+    d = _to_dev(torch_cuda, x)
+    with Plan(n, FS, thr, max_batch=nb, max_hits=len(h_ref) + 64, flags=capi.OUT_HITS, trigger_count=3) as plan:
+        for count in (4096, 4097, nb, 4096):        # stores, DMA, DMA, stores
+            plan.submit_device(0, d, count, fc[:count])
+            _, h, t = plan.collect(0, want_hits=False)
+            assert h is None and np.array_equal(t, t_ref[:count]), count
+        for count in (nb, 4096, nb):                 # with records: the first builds its list on demand, the next two eagerly
+            plan.submit_device(1, d, count, fc[:count])
+            _, h, t = plan.collect(1, hit_cap=len(h_ref) + 64)
+            _assert_hits_equal(h, h_ref[h_ref["seq_id"] < count])
+            assert np.array_equal(t, t_ref[:count])
+            assert np.array_equal(np.bincount(h["seq_id"].astype(np.int64), minlength=count), c_ref[:count])
+
+
 def test_special_inputs(torch_cuda, oracle_mod):
     """all-zero buffer (-inf everywhere, no hits), a unit impulse (flat spectrum), full-scale DC."""
     n = 4096

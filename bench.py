@@ -369,15 +369,15 @@ def abi_bench_legs(n, nb, kind, threshold, steps, depth):
     if not os.path.exists(exe):
         return {"error": "scanner_amd/host/abi_bench has not been built (python -m scanner_amd.build)"}
     out = {}
-    for mode, d in (("view", depth), ("copy", depth), ("view", 2), ("counts", 2)):
+    for mode, d, ho in (("view", depth, 0), ("copy", depth, 0), ("view", 2, 0), ("counts", 2, 0), ("view", depth, 1), ("view", 4, 1)):
         cmd = [exe, "--n", str(n), "--batch", str(nb), "--kind", kind, "--threshold", str(threshold), "--steps", str(steps),
-               "--depth", str(d), "--mode", mode]
+               "--depth", str(d), "--mode", mode, "--hits-only", str(ho)]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
                 return {"error": f"abi_bench --mode {mode} exited {r.returncode}: {r.stderr[-300:]}"}
-            out[f"{mode}_depth{d}"] = json.loads(line[-1])
+            out[f"{mode}_depth{d}" + ("_hits_only" if ho else "")] = json.loads(line[-1])
         except Exception as e:  # a missing leg must not cost the run its line
             return {"error": str(e)[:300]}
     return out
@@ -941,6 +941,12 @@ def main():
                                                   "note": "the same loop with scn_collect copying the records into the caller's buffer (one core's memcpy "
                                                           "of ~1.6 MB out of pinned memory per step)"},
                     "counts_only_same_harness": {"value": legs["counts_depth2"]["value"], "ms_per_step": legs["counts_depth2"]["ms_per_step"]},
+                    "hits_only_plan": {"value": legs[f"view_depth{min(args.records_depth, 3)}_hits_only"]["value"],
+                                       "ms_per_step": legs[f"view_depth{min(args.records_depth, 3)}_hits_only"]["ms_per_step"],
+                                       "submits_in_flight": legs[f"view_depth{min(args.records_depth, 3)}_hits_only"]["submits_in_flight"],
+                                       "four_in_flight": {"value": legs["view_depth4_hits_only"]["value"], "ms_per_step": legs["view_depth4_hits_only"]["ms_per_step"]},
+                                       "note": "the same loop on a plan without SCN_OUT_SPECTRUM (the reference prints records, not spectra: "
+                                               "what ProcessSamples::ThreadWorker creates); on its own byte count, never mixed into value"},
                     "python_torch_runtime": records,
                     "note": "value = the records loop of a C++ caller.  python_torch_runtime = the same loops driven from this Python "
                             "process, whose HIP runtime (the one torch bundles) runs every device-to-host copy as a blit kernel beside "

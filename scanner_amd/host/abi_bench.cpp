@@ -78,6 +78,7 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 int main(int argc, char **argv) {
   uint32_t n = 4096, batch = 8192, steps = 300, warmup = 50, depth = 3, rotate = 4, extra_flags = 0;
   float threshold = 10.0f;
+  bool hits_only = false;
   std::string kind = "cfloat", mode = "copy", lib = "", host_log = "";
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string a = argv[i], v = argv[i + 1];
@@ -88,6 +89,7 @@ int main(int argc, char **argv) {
     else if (a == "--depth") depth = (uint32_t)atoi(v.c_str());
     else if (a == "--rotate") rotate = (uint32_t)atoi(v.c_str());
     else if (a == "--flags") extra_flags = (uint32_t)atoi(v.c_str());
+    else if (a == "--hits-only") hits_only = atoi(v.c_str()) != 0;  // 1: a plan without SCN_OUT_SPECTRUM, what ProcessSamples::ThreadWorker creates
     else if (a == "--threshold") threshold = (float)atof(v.c_str());
     else if (a == "--kind") kind = v;
     else if (a == "--mode") mode = v;
@@ -205,7 +207,7 @@ int main(int argc, char **argv) {
   d.threshold = threshold;
   d.max_batch = batch;
   d.max_hits = batch * std::max<uint32_t>(64u, n / 64u);
-  d.flags = SCN_OUT_SPECTRUM | SCN_OUT_HITS | extra_flags;
+  d.flags = (hits_only ? 0u : (uint32_t)SCN_OUT_SPECTRUM) | SCN_OUT_HITS | extra_flags;
   scn_plan *plan = nullptr;
   if (api.plan_create(&d, &plan) != SCN_OK) {
     fprintf(stderr, "abi_bench: scn_plan_create: %s\n", api.last_error());
@@ -261,7 +263,7 @@ int main(int argc, char **argv) {
     launch++;
     if (pending[s]) collect(s);
     const double t0 = now();
-    if (api.submit_device(plan, (int)s, d_in[r], batch, fc.data(), seq.data(), static_cast<float *>(d_out[r])) != SCN_OK && !rc) {
+    if (api.submit_device(plan, (int)s, d_in[r], batch, fc.data(), seq.data(), hits_only ? nullptr : static_cast<float *>(d_out[r])) != SCN_OK && !rc) {
       fprintf(stderr, "abi_bench: submit: %s\n", api.last_error());
       rc = 3;
     }

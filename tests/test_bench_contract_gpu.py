@@ -56,6 +56,7 @@ def test_bench_line_single_process():
     # the records legs: from a C++ child on the system HIP runtime (value), and from this torch process beside it
     assert r["value"] > 0 and r["hits_per_step"] > 0 and "scn_hits_view" in r["path"] and r["hip_runtime_version"] > 0
     assert r["copied_out_by_scn_collect"]["value"] > 0 and r["two_in_flight"]["value"] > 0
+    assert r["hits_only_plan"]["value"] > 0 and r["hits_only_plan"]["four_in_flight"]["value"] > 0   # the worker's kind of plan
     py = r["python_torch_runtime"]
     assert py["value"] > 0 and py["collect_hits"] > 0 and py["collect_with_records_us"] > 0
     assert d["roofline"]["kernel"].startswith("scn_fft_kernel<16, SCN_K_FLOAT_COMPLEX")

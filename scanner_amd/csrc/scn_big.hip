@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 3) void scn_big_cols_kernel(ScnBigArgs args) {
   }
   for (uint32_t b = g; b < args.n_buffers; b += G) {
     __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)b * N * 8u + j * 2048u, N * 8u - j * 2048u);
+    if (j == 0 && t == 0 && args.per_buffer_hits) args.per_buffer_hits[b] = 0;  // the row kernel (the next launch) counts into it
     int dc_re = 0, dc_im = 0;
     if (DC) {
       dc_re = (int)((uint32_t)args.dc_sums[2 * b] / N);  // int32 /= uint32, utility.cpp:77-78
@@ -443,10 +444,8 @@ hipError_t scn_launch_big(uint32_t n, int kind, bool dc, bool hits, bool spec, c
   if ((!hits && !spec) || !scn_big_size_supported(n)) return hipErrorInvalidValue;
   if (dc && kind != SCN_K_FLOAT_COMPLEX && !a.dc_sums) return hipErrorInvalidValue;
   hipError_t e = hipSuccess;
-  if (hits) {
-    e = hipMemsetAsync(a.per_buffer_hits, 0, sizeof(uint32_t) * a.n_buffers, s);
-    if (e != hipSuccess) return e;
-  }
+  // (the per-buffer counters are zeroed by the column kernel's tile-0 workgroups: a memset of its own was a third dependent
+  //  launch, ~5 us of a 200 us step)
   const uint32_t ct = n / 4096u;  // column tiles
   const size_t lds = 16 * BP * sizeof(v2f);
   uint32_t G = (uint32_t)(num_cus * 3) / ct;

@@ -138,7 +138,7 @@ struct ScnBigArgs {
   uint32_t dc_ignore, i_lo, i_hi;
   ScnDevHit *hits;            // [n_buffers][hit_region]
   uint32_t hit_region;
-  uint32_t *per_buffer_hits;  // [n_buffers], zeroed by the launcher
+  uint32_t *per_buffer_hits;  // [n_buffers], zeroed by the column kernel (tile 0), counted into by the row kernel
   int *dc_sums;               // [n_buffers][2] scratch for DC removal of integer samples (zeroed by the launcher), or nullptr
 };
 hipError_t scn_launch_big(uint32_t n, int kind, bool correct_dc, bool hits, bool spectrum, const ScnBigArgs &args, int num_cus, hipStream_t stream);

@@ -78,6 +78,18 @@ def test_loads_and_reports_errors(built_lib):
     assert L.scn_plan_create(C.byref(d), C.byref(h)) == capi.E_INVALID
 
 
+def test_size_paths(built_lib):
+    """scn_size_path needs no device: every power of two from 16 to 16384 has a fused kernel, 32768 / 65536 the four-step
+    pair, the other sizes from 17 to 65535 Bluestein, nothing else is planned (the GPU suite walks the fused list)."""
+    for k in range(4, 15):
+        assert capi.size_path(1 << k) == capi.PATH_FUSED, 1 << k
+    assert capi.size_path(32768) == capi.size_path(65536) == capi.PATH_FOUR_STEP
+    for n in (17, 100, 1000, 4097, 65535):
+        assert capi.size_path(n) == capi.PATH_BLUESTEIN, n
+    for n in (0, 1, 8, 15, 65537, 1 << 17):
+        assert capi.size_path(n) == capi.PATH_UNSUPPORTED, n
+
+
 def test_no_gpu_means_loud_failure(built_lib):
     import torch
 

@@ -285,6 +285,38 @@ __device__ __forceinline__ float scn_select_output(const VEC &pw, uint32_t o) { 
   return t[0];
 }
 
+// scn_record_hits_segment: the form for the kernels in which a wave holds SEVERAL buffers (16 .. 512 points): the hits of one
+// buffer sit in T consecutive lanes (T = 1 .. 32, a power of two, aligned).  `dbv` holds the dB values of the lane's NB outputs
+// (db_of_power), `hm` its hit mask (dB > threshold, keep mask applied).  A record's slot in the buffer's region is the number
+// of hits in the lanes before it (an inclusive prefix sum over the segment: log2 T cross-lane reads) plus its rank in its own
+// lane -- no atomic, no counter in LDS; the segment's total is the buffer's count.  (Until round 4 every hit took its slot
+// with its own LDS atomic on the buffer's counter -- the hits of one buffer on ONE address -- and evaluated its dB value in
+// the trip: 30 of a 256-point launch's 82 us with the bench's eight hits per buffer.)  Region order does not matter: the
+// compaction kernel ranks a buffer's records by their bins (scn_hits.hip).
+template <int T, int NB, typename VEC, typename ARGS, typename BINI>
+__device__ __forceinline__ uint32_t scn_record_hits_segment(const VEC &dbv, uint32_t hm, const ARGS &args, uint32_t buf, uint32_t t, BINI bin_i) {
+  static_assert(T >= 1 && T <= 32 && (T & (T - 1)) == 0, "a segment is a power of two of lanes inside a wave");
+  const uint32_t cnt = (uint32_t)__builtin_popcount(hm);
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int off = 1; off < T; off <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)inc, off, T);
+    inc += t >= (uint32_t)off ? v : 0u;
+  }
+  const uint32_t total = T == 1 ? inc : (uint32_t)__shfl((int)inc, T - 1, T);
+  uint32_t pos = inc - cnt;
+  ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
+  while (__ballot(hm != 0u)) {  // one hit per lane per trip; the value comes out of the registers through the select tree
+    const bool act = hm != 0u;
+    const uint32_t o = act ? (uint32_t)__builtin_ctz(hm) : 0u;
+    hm &= hm - 1u;
+    const float d = scn_select_output<NB>(dbv, o);
+    if (act && pos < args.hit_region) region[pos] = ScnDevHit{bin_i((int)o), d};
+    pos += 1u;
+  }
+  return total;
+}
+
 // HAVE_MASK: the caller collected the candidate bits (`cand`, before the keep mask) while it produced the outputs.
 template <int NB, bool IS_DB, bool PURE = false, bool HAVE_MASK = false, typename VEC, typename ARGS, typename BINI>
 __device__ __forceinline__ void scn_record_hits_lanes(VEC &pw, const float (&gmax)[4], uint32_t keepmask, const ARGS &args, int *count, uint32_t buf,

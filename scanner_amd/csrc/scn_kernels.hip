@@ -483,16 +483,81 @@ __global__ __launch_bounds__(16 * M, Geo<M>::WAVES_PER_SIMD) void scn_fft_kernel
 //           pass 2's outputs are the spectrum (thread t stores its own bins t + 16 q: 64-byte runs per buffer)
 // One buffer descriptor spans the workgroup's SLOTS consecutive buffers (a wave holds two or four of them, so a per-buffer
 // descriptor would not be wave-uniform); slots past the end of the batch read zeros and store nothing (range check).
-// Hits: a wave is no longer one buffer, so slots in a buffer's region come from one LDS atomic per HIT (rare) on the slot's
-// counter instead of one per wave.  These sizes ran the staged double-precision path (scn_generic.hip) at 40 Gsamples/s.
+// Hits: a wave is no longer one buffer; a buffer's records take their places by a prefix sum over its T lanes, no atomic
+// (scn_record_hits_segment).  These sizes ran the staged double-precision path (scn_generic.hip) at 40 Gsamples/s.
 // ------------------------------------------------------------------------------------
 namespace {
+// K4 + K5 of the kernels in which a wave holds several buffers (scn_fft_small_kernel, scn_fft_tiny_kernel).  Thread t of a
+// buffer's T lanes owns 16 outputs; output o is bin t + joff_of(o), its power power_at(o).  The dB map as everywhere
+// (db_of_power: product form, exact form for strong bins -- evaluated in the waves that hold one); the values stay in
+// registers, a hit is a dB value above the threshold (strict >, process.cpp:54) inside the keep mask, and the buffer's
+// records take their places by a prefix sum over its T lanes (scn_record_hits_segment).  A hits-only kernel forms the dB
+// values only in the waves that hold a candidate by linear power.
+template <int T, bool SPEC, bool HITS, int AUX_ST, typename POWER, typename JOFF>
+__device__ __forceinline__ void scn_small_db_store_record(POWER power_at, JOFF joff_of, __amdgpu_buffer_rsrc_t rout, uint32_t st_voff,
+                                                          const ScnFftArgs &args, uint32_t buf, bool valid, uint32_t keepmask, uint32_t t, uint32_t n) {
+  v16f pw, dbv;
+  float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int o = 0; o < 16; o++) {
+    const float q = power_at(o);
+    pw[o] = q;
+    gmax[o >> 2] = fmaxf(gmax[o >> 2], q);
+    if constexpr (SPEC) {
+      // (the store takes the value just computed, in the loop that computes it: written as a second loop `dbv[o] = db_fast(pw[o]);
+      //  store(dbv[o])`, hipcc 7.2 stored element 0's value sixteen times -- caught by tests/test_dispatch_gpu.py)
+      const float d = db_fast(q);
+      dbv[o] = d;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 4u * joff_of(o), AUX_ST);
+    }
+  }
+  const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
+  const bool any_cand = HITS && __ballot(valid && pmax > args.p_lo) != 0ull;  // wave-uniform
+  if (SPEC || any_cand) {
+    if constexpr (!SPEC) {
+#pragma unroll
+      for (int o = 0; o < 16; o++) dbv[o] = db_fast(pw[o]);
+    }
+    if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+          for (int o = 4 * g; o < 4 * g + 4; o++) {
+            const float q = pw[o];
+            if (__ballot(q >= SCN_P_EXACT_FROM)) {
+              const float d = db_exact(q);
+              dbv[o] = q >= SCN_P_EXACT_FROM ? d : dbv[o];
+              if constexpr (SPEC)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 4u * joff_of(o), AUX_ST);
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (HITS) {
+    uint32_t total = 0;
+    if (any_cand) {
+      uint32_t hm = 0;
+#pragma unroll
+      for (int o = 0; o < 16; o++) hm |= (dbv[o] > args.threshold) ? (1u << o) : 0u;
+      hm &= valid ? keepmask : 0u;
+      total = scn_record_hits_segment<T, 16>(dbv, hm, args, buf, t, [&](int o) -> uint32_t { return (t + joff_of(o)) ^ (n / 2); });
+    }
+    if (t == 0 && valid) {
+      args.per_buffer_hits[buf] = total;
+      if (args.host_hits) args.host_hits[buf] = total;
+    }
+  }
+}
+
 template <int M>
 struct GeoSmall {
   static constexpr uint32_t N = 256u * M, T = 16u * M, SLOTS = 256u / T;
   static constexpr uint32_t P1 = T + M, P2 = 256u + 16u / M;
   static constexpr uint32_t EXCH = (16u * P1 > M * P2) ? 16u * P1 : M * P2;  // slots per buffer
-  static constexpr uint32_t LDS_BYTES = SLOTS * EXCH * 8u + T * 8u + SLOTS * 4u + 16u;
+  static constexpr uint32_t LDS_BYTES = SLOTS * EXCH * 8u + T * 8u + 16u;
   static constexpr uint32_t WG_PER_CU = 3;
 };
 }  // namespace
@@ -510,7 +575,6 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
   const uint32_t tid = threadIdx.x, t = tid % T, slot = tid / T;
   v2f *lds = reinterpret_cast<v2f *>(smem_raw) + slot * G::EXCH;                     // this buffer's exchange area
   v2f *lds_tw2 = reinterpret_cast<v2f *>(smem_raw) + SLOTS * G::EXCH;                // [16][M], shared by the slots
-  int *lds_hits = reinterpret_cast<int *>(lds_tw2 + T);                              // [SLOTS]
   const uint32_t p2 = t / M, c2 = t % M;
   const uint32_t buf_bytes = L::kBufBytes(N);
 
@@ -540,7 +604,6 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
 #pragma unroll
   for (int a = 0; a < 16; a++) win[a] = args.window[T * a + t] * args.scale;
   if (slot == 0) lds_tw2[t] = args.twiddle[(16 * p2 * c2) & (N - 1)];  // W_(16 M)^(c q) = W_N^(16 c q), entry q*M + c
-  if (tid < SLOTS) lds_hits[tid] = 0;
   __syncthreads();
 
   v2f *w1 = lds + t;                      // + p*P1
@@ -627,67 +690,12 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
         v[2 * u + 1] = a - b;  // r = 1
       }
     }
-    // ---- K4 (see scn_fft_kernel) ----
-    v16f pw;
-    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // ---- K4, K5 (a wave holds several buffers: scn_small_db_store_record) ----
     const uint32_t nvalid = args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS;
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, (SPEC && args.power_db) ? nvalid * 4u * N : 0u);
-    const uint32_t st_voff = (slot * N + t) * 4u;
-#pragma unroll
-    for (int o = 0; o < 16; o++) {
-      const float q = power_of(v[M == 1 ? OUT16(o) : o]);
-      pw[o] = q;
-      gmax[o >> 2] = fmaxf(gmax[o >> 2], q);
-      if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 4u * joff_of(o), AUX_ST);
-    }
-    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
-    if constexpr (SPEC) {
-      if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
-#pragma unroll
-            for (int o = 4 * g; o < 4 * g + 4; o++) {
-              const float q = pw[o];
-              if (__ballot(q >= SCN_P_EXACT_FROM)) {
-                const float d = db_exact(q);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 4u * joff_of(o), AUX_ST);
-              }
-            }
-          }
-        }
-      }
-    }
-    // ---- K5: a wave holds several buffers here, so every hit takes its slot of the region with its own LDS atomic ----
-    if (HITS) {
-      if (__ballot(valid && pmax > args.p_lo)) {
-        uint32_t cand = 0;
-#pragma unroll
-        for (int o = 0; o < 16; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
-        cand &= valid ? keepmask : 0u;
-        ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-        while (__ballot(cand != 0u)) {  // one candidate per lane per trip (scn_record_hits_lanes; here a lane's counter is its slot's)
-          const bool act = cand != 0u;
-          const uint32_t o = act ? (uint32_t)__builtin_ctz(cand) : 0u;
-          cand &= cand - 1u;
-          const float q = scn_select_output<16>(pw, o);
-          float d = db_fast(q);
-          if (__ballot(act && q >= SCN_P_EXACT_FROM)) d = q >= SCN_P_EXACT_FROM ? db_exact(q) : d;
-          if (act && d > args.threshold) {  // strict >, process.cpp:54
-            const uint32_t pos = (uint32_t)atomicAdd(&lds_hits[slot], 1);
-            if (pos < args.hit_region) region[pos] = ScnDevHit{(t + joff_of((int)o)) ^ (N / 2), d};
-          }
-        }
-      }
-    }
-    __syncthreads();  // exchange areas free again; the slots' hit counters final
-    if (HITS && t == 0) {
-      if (valid) {
-        args.per_buffer_hits[buf] = (uint32_t)lds_hits[slot];
-        if (args.host_hits) args.host_hits[buf] = (uint32_t)lds_hits[slot];
-      }
-      lds_hits[slot] = 0;  // (the next recording is three barriers away)
-    }
+    scn_small_db_store_record<(int)T, SPEC, HITS, AUX_ST>([&](int o) -> float { return power_of(v[M == 1 ? OUT16(o) : o]); }, joff_of, rout,
+                                                          (slot * N + t) * 4u, args, buf, valid, keepmask, t, N);
+    __syncthreads();  // exchange areas free again
   }
 }
 
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
 //   pass 2  thread c': the R-point DFTs over c for ITS 16 / R values of p = c' + R m; output o = R m + r is bin c' + R m + 16 r
 //   R = 1: one thread holds the whole buffer, there is no exchange at all.
 // A 256-thread workgroup carries SLOTS = 256 / R consecutive buffers per iteration (4096 samples, as everywhere), under one
-// descriptor like scn_fft_small_kernel, hits with the slot's own LDS counter like there.  The exchange is [p][R + 1] per
+// descriptor like scn_fft_small_kernel, hits by the same prefix sum over the buffer's lanes.  The exchange is [p][R + 1] per
 // buffer with R + 16 slots of padding between buffers: both sides conflict-free (16-lane write groups, 32-lane read groups;
 // found by enumeration).  Global loads and stores move runs of R samples / R bins per buffer -- 64 bytes at 128 points, one
 // element at 16: the small end of this family is bound by the number of memory requests, not by bytes.
@@ -712,7 +720,7 @@ struct GeoTiny {
   static constexpr uint32_t N = 16u * R, T = R, SLOTS = 256u / R;
   static constexpr uint32_t P1 = R + 1u;
   static constexpr uint32_t EXCH = R == 1 ? 0u : 16u * P1 + R;  // slots per buffer
-  static constexpr uint32_t LDS_BYTES = SLOTS * EXCH * 8u + SLOTS * 4u + 16u;
+  static constexpr uint32_t LDS_BYTES = SLOTS * EXCH * 8u + 16u;
   static constexpr uint32_t WG_PER_CU = 3;
 };
 }  // namespace
@@ -729,7 +737,6 @@ __global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const uint32_t tid = threadIdx.x, t = tid % R, slot = tid / R;
   v2f *lds = reinterpret_cast<v2f *>(smem_raw) + slot * G::EXCH;                  // this buffer's exchange area
-  int *lds_hits = reinterpret_cast<int *>(reinterpret_cast<v2f *>(smem_raw) + SLOTS * G::EXCH);  // [SLOTS]
   const uint32_t buf_bytes = L::kBufBytes(N);
 
   auto in_rsrc = [&](uint32_t first) {  // the iteration's SLOTS consecutive buffers (zero records past the end of the batch)
@@ -754,11 +761,6 @@ __global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
   float win[16];
 #pragma unroll
   for (int a = 0; a < 16; a++) win[a] = args.window[R * a + t] * args.scale;
-  if (HITS) {
-    if (tid < SLOTS) lds_hits[tid] = 0;
-    __syncthreads();
-  }
-
   auto joff_of = [](int o) -> uint32_t { return R * ((uint32_t)o / R) + 16u * ((uint32_t)o % R); };  // output o is bin t + joff_of(o)
   uint32_t keepmask = 0;
   if (HITS) {
@@ -837,67 +839,12 @@ __global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
         }
       }
     }
-    // ---- K4 (see scn_fft_kernel) ----
-    v16f pw;
-    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // ---- K4, K5 (scn_small_db_store_record) ----
     const uint32_t nvalid = args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS;
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, (SPEC && args.power_db) ? nvalid * 4u * N : 0u);
-    const uint32_t st_voff = (slot * N + t) * 4u;
-#pragma unroll
-    for (int o = 0; o < 16; o++) {
-      const float q = power_of(x[o]);
-      pw[o] = q;
-      gmax[o >> 2] = fmaxf(gmax[o >> 2], q);
-      if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 4u * joff_of(o), AUX_ST);
-    }
-    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
-    if constexpr (SPEC) {
-      if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
-#pragma unroll
-            for (int o = 4 * g; o < 4 * g + 4; o++) {
-              const float q = pw[o];
-              if (__ballot(q >= SCN_P_EXACT_FROM)) {
-                const float d = db_exact(q);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 4u * joff_of(o), AUX_ST);
-              }
-            }
-          }
-        }
-      }
-    }
-    // ---- K5: every hit takes its slot of the buffer's region with its own LDS atomic (scn_fft_small_kernel) ----
-    if (HITS) {
-      if (__ballot(valid && pmax > args.p_lo)) {
-        uint32_t cand = 0;
-#pragma unroll
-        for (int o = 0; o < 16; o++) cand |= (pw[o] > args.p_lo) ? (1u << o) : 0u;
-        cand &= valid ? keepmask : 0u;
-        ScnDevHit *const region = args.hits + (size_t)buf * args.hit_region;
-        while (__ballot(cand != 0u)) {
-          const bool act = cand != 0u;
-          const uint32_t o = act ? (uint32_t)__builtin_ctz(cand) : 0u;
-          cand &= cand - 1u;
-          const float q = scn_select_output<16>(pw, o);
-          float d = db_fast(q);
-          if (__ballot(act && q >= SCN_P_EXACT_FROM)) d = q >= SCN_P_EXACT_FROM ? db_exact(q) : d;
-          if (act && d > args.threshold) {  // strict >, process.cpp:54
-            const uint32_t pos = (uint32_t)atomicAdd(&lds_hits[slot], 1);
-            if (pos < args.hit_region) region[pos] = ScnDevHit{(t + joff_of((int)o)) ^ (N / 2), d};
-          }
-        }
-      }
-    }
-    if (R > 1) __syncthreads();  // exchange areas free again; the slots' hit counters final (R = 1: a slot is one thread's own)
-    if (HITS && t == 0) {
-      if (valid) {
-        args.per_buffer_hits[buf] = (uint32_t)lds_hits[slot];
-        if (args.host_hits) args.host_hits[buf] = (uint32_t)lds_hits[slot];
-      }
-      lds_hits[slot] = 0;  // (the next recording is a barrier away)
-    }
+    scn_small_db_store_record<R, SPEC, HITS, AUX_ST>([&](int o) -> float { return power_of(x[o]); }, joff_of, rout, (slot * N + t) * 4u, args,
+                                                     buf, valid, keepmask, t, N);
+    if (R > 1) __syncthreads();  // exchange areas free again
   }
 }
 

@@ -493,9 +493,10 @@ namespace {
 // registers, a hit is a dB value above the threshold (strict >, process.cpp:54) inside the keep mask, and the buffer's
 // records take their places by a prefix sum over its T lanes (scn_record_hits_segment).  A hits-only kernel forms the dB
 // values only in the waves that hold a candidate by linear power.
-template <int T, bool SPEC, bool HITS, int AUX_ST, typename POWER, typename JOFF>
-__device__ __forceinline__ void scn_small_db_store_record(POWER power_at, JOFF joff_of, __amdgpu_buffer_rsrc_t rout, uint32_t st_voff,
-                                                          const ScnFftArgs &args, uint32_t buf, bool valid, uint32_t keepmask, uint32_t t, uint32_t n) {
+// store(o, d, pred): where output o's dB value goes if pred (global memory for 256 / 512 points, the LDS tile below that).
+template <int T, bool SPEC, bool HITS, typename POWER, typename JOFF, typename STORE>
+__device__ __forceinline__ void scn_small_db_store_record(POWER power_at, JOFF joff_of, STORE store, const ScnFftArgs &args, uint32_t buf, bool valid,
+                                                          uint32_t keepmask, uint32_t t, uint32_t n) {
   v16f pw, dbv;
   float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -508,7 +509,7 @@ __device__ __forceinline__ void scn_small_db_store_record(POWER power_at, JOFF j
       //  store(dbv[o])`, hipcc 7.2 stored element 0's value sixteen times -- caught by tests/test_dispatch_gpu.py)
       const float d = db_fast(q);
       dbv[o] = d;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, st_voff, 4u * joff_of(o), AUX_ST);
+      store(o, d, true);
     }
   }
   const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
@@ -528,8 +529,7 @@ __device__ __forceinline__ void scn_small_db_store_record(POWER power_at, JOFF j
             if (__ballot(q >= SCN_P_EXACT_FROM)) {
               const float d = db_exact(q);
               dbv[o] = q >= SCN_P_EXACT_FROM ? d : dbv[o];
-              if constexpr (SPEC)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 4u * joff_of(o), AUX_ST);
+              if constexpr (SPEC) store(o, d, q >= SCN_P_EXACT_FROM);
             }
           }
         }
@@ -693,8 +693,11 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
     // ---- K4, K5 (a wave holds several buffers: scn_small_db_store_record) ----
     const uint32_t nvalid = args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS;
     __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, (SPEC && args.power_db) ? nvalid * 4u * N : 0u);
-    scn_small_db_store_record<(int)T, SPEC, HITS, AUX_ST>([&](int o) -> float { return power_of(v[M == 1 ? OUT16(o) : o]); }, joff_of, rout,
-                                                          (slot * N + t) * 4u, args, buf, valid, keepmask, t, N);
+    const uint32_t st_voff = (slot * N + t) * 4u;
+    scn_small_db_store_record<(int)T, SPEC, HITS>(
+        [&](int o) -> float { return power_of(v[M == 1 ? OUT16(o) : o]); }, joff_of,
+        [&](int o, float d, bool pred) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, pred ? st_voff : 0x80000000u, 4u * joff_of(o), AUX_ST); },
+        args, buf, valid, keepmask, t, N);
     __syncthreads();  // exchange areas free again
   }
 }
@@ -708,20 +711,76 @@ __global__ __launch_bounds__(256, 3) void scn_fft_small_kernel(ScnFftArgs args) 
 //   pass 1  thread c of a buffer: the 16-point DFT over a of its 16 samples, * W_N^(c p) -> LDS [p][c]
 //   pass 2  thread c': the R-point DFTs over c for ITS 16 / R values of p = c' + R m; output o = R m + r is bin c' + R m + 16 r
 //   R = 1: one thread holds the whole buffer, there is no exchange at all.
-// A 256-thread workgroup carries SLOTS = 256 / R consecutive buffers per iteration (4096 samples, as everywhere), under one
-// descriptor like scn_fft_small_kernel, hits by the same prefix sum over the buffer's lanes.  The exchange is [p][R + 1] per
-// buffer with R + 16 slots of padding between buffers: both sides conflict-free (16-lane write groups, 32-lane read groups;
-// found by enumeration).  Global loads and stores move runs of R samples / R bins per buffer -- 64 bytes at 128 points, one
-// element at 16: the small end of this family is bound by the number of memory requests, not by bytes.
+// A 256-thread workgroup carries SLOTS = 256 / R consecutive buffers per iteration: one CHUNK of 4096 samples, contiguous in
+// memory on both sides.  A thread's own samples and bins are runs of R elements per buffer (one element at 16 points), so the
+// chunk crosses LDS on its way in and on its way out and every global access is the 1024-point kernel's: thread tid loads
+// elements 256 a + tid of the chunk (512 / 256 / 128 bytes per wave instruction) into a tile [slot][N + R] -- the R elements of
+// padding make the gather of x[R a + c] conflict-free for every R --, gathers its 16 samples from there; the dB values go
+// back through a tile of the same shape and leave as 256-byte runs.  (The first form of this kernel loaded and stored its
+// runs of R directly: 744 / 214 / 119 us per 33.5 M samples at 16 / 64 / 128 points against 74 at 1024.)  One LDS region
+// serves as raw tile, exchange and dB tile in turn: six barriers per iteration (four at 16 points).
+// Hits by the prefix sum over the buffer's lanes, like scn_fft_small_kernel.  The exchange is [p][R + 1] per buffer with
+// R + 16 slots of padding between buffers: both sides conflict-free (16-lane write groups, 32-lane read groups; found by
+// enumeration).
 // ------------------------------------------------------------------------------------
 namespace {
 template <int R>
 struct GeoTiny {
   static constexpr uint32_t N = 16u * R, T = R, SLOTS = 256u / R;
   static constexpr uint32_t P1 = R + 1u;
-  static constexpr uint32_t EXCH = R == 1 ? 0u : 16u * P1 + R;  // slots per buffer
-  static constexpr uint32_t LDS_BYTES = SLOTS * EXCH * 8u + 16u;
+  static constexpr uint32_t EXCH = R == 1 ? 0u : 16u * P1 + R;  // 8-byte slots per buffer
+  static constexpr uint32_t PITCH = N + R;                       // elements per buffer in the raw tile and in the dB tile
+  static constexpr uint32_t TILE_BYTES = SLOTS * PITCH * 8u;     // (raw samples of up to 8 bytes)
+  static constexpr uint32_t LDS_BYTES = (TILE_BYTES > SLOTS * EXCH * 8u ? TILE_BYTES : SLOTS * EXCH * 8u) + 16u;
   static constexpr uint32_t WG_PER_CU = 3;
+};
+
+// the chunk's raw elements through the LDS tile, per wire format: thread tid loads element 256 a + tid (a < 16; the planar
+// format: two 16-bit elements, 256 (2a) + tid and 256 (2a + 1) + tid, of the chunk's I / Q blocks), stage() writes what it
+// loaded to [slot][PITCH], gather() returns sample j of buffer `slot` in RawLoader's register form.
+template <int KIND, int R>
+struct TinyStage {
+  typedef GeoTiny<R> G;
+  typedef RawLoader<KIND> L;
+  static constexpr bool PLANAR = KIND == SCN_K_SHORT;
+  typedef typename L::raw_t reg_t;  // (planar: two 16-bit elements packed)
+  template <int AUX>
+  static __device__ __forceinline__ reg_t load(__amdgpu_buffer_rsrc_t r, uint32_t tid, int a) {
+    if constexpr (PLANAR) {
+      const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b16(r, tid * 2u, 256u * 2u * (2u * (uint32_t)a), AUX);
+      const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b16(r, tid * 2u, 256u * 2u * (2u * (uint32_t)a + 1u), AUX);
+      return (int)((lo & 0xffffu) | (hi << 16));
+    } else {
+      return L::template load<AUX>(r, G::N, tid, 256u * (uint32_t)a);
+    }
+  }
+  static __device__ __forceinline__ void stage(char *tile, uint32_t tid, int a, reg_t v) {
+    if constexpr (PLANAR) {  // per buffer: I[N] then Q[N]; tile: I at [slot][0 .. N), Q at [slot][PITCH .. PITCH + N), 16-bit elements
+      unsigned short *t16 = reinterpret_cast<unsigned short *>(tile);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t e = 256u * (2u * (uint32_t)a + h) + tid, s = e / (2u * G::N), j = e % (2u * G::N);
+        t16[s * 2u * G::PITCH + (j < G::N ? j : G::PITCH + j - G::N)] = (unsigned short)(h ? (uint32_t)v >> 16 : (uint32_t)v & 0xffffu);
+      }
+    } else {
+      const uint32_t e = 256u * (uint32_t)a + tid, idx = (e / G::N) * G::PITCH + e % G::N;
+      if constexpr (KIND == SCN_K_FLOAT_COMPLEX) reinterpret_cast<v2f *>(tile)[idx] = v;
+      else if constexpr (KIND == SCN_K_SHORT_COMPLEX) reinterpret_cast<int *>(tile)[idx] = v;
+      else reinterpret_cast<unsigned short *>(tile)[idx] = (unsigned short)v;
+    }
+  }
+  static __device__ __forceinline__ typename L::raw_t gather(const char *tile, uint32_t slot, uint32_t j) {
+    if constexpr (PLANAR) {
+      const unsigned short *t16 = reinterpret_cast<const unsigned short *>(tile) + slot * 2u * G::PITCH;
+      return (int)((uint32_t)t16[j] | ((uint32_t)t16[G::PITCH + j] << 16));
+    } else if constexpr (KIND == SCN_K_FLOAT_COMPLEX) {
+      return reinterpret_cast<const v2f *>(tile)[slot * G::PITCH + j];
+    } else if constexpr (KIND == SCN_K_SHORT_COMPLEX) {
+      return reinterpret_cast<const int *>(tile)[slot * G::PITCH + j];
+    } else {
+      return (int)reinterpret_cast<const unsigned short *>(tile)[slot * G::PITCH + j];
+    }
+  }
 };
 }  // namespace
 
@@ -730,25 +789,27 @@ __global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
   static_assert(R == 1 || R == 2 || R == 4 || R == 8, "16, 32, 64 or 128 points");
   static_assert(HITS || SPEC, "a kernel that reports nothing");
   typedef GeoTiny<R> G;
+  typedef TinyStage<KIND, R> S;
   constexpr int AUX_LD = SCN_AUX_LD;
   constexpr int AUX_ST = SCN_AUX_ST;
-  constexpr uint32_t N = G::N, SLOTS = G::SLOTS, P1 = G::P1;
+  constexpr uint32_t N = G::N, SLOTS = G::SLOTS, P1 = G::P1, PITCH = G::PITCH;
   typedef RawLoader<KIND> L;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const uint32_t tid = threadIdx.x, t = tid % R, slot = tid / R;
-  v2f *lds = reinterpret_cast<v2f *>(smem_raw) + slot * G::EXCH;                  // this buffer's exchange area
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw) + slot * G::EXCH;  // this buffer's exchange area
+  float *tile_out = reinterpret_cast<float *>(smem_raw);          // the dB tile [slot][PITCH]
   const uint32_t buf_bytes = L::kBufBytes(N);
 
-  auto in_rsrc = [&](uint32_t first) {  // the iteration's SLOTS consecutive buffers (zero records past the end of the batch)
+  auto in_rsrc = [&](uint32_t first) {  // the iteration's chunk: SLOTS consecutive buffers (zero records past the end of the batch)
     const bool ok = first < args.n_buffers;
     const uint32_t nb = ok ? (args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS) : 0u;
     return make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)(ok ? first : 0u) * buf_bytes, nb * buf_bytes);
   };
-  typename L::raw_t raw[16];
-  auto load_group = [&](const __amdgpu_buffer_rsrc_t &r, int a_lo, int a_hi) {  // (slot offset per lane, R a wave-uniform: see scn_fft_small_kernel)
+  typename S::reg_t raw[16];  // the NEXT chunk's elements 256 a + tid, fetched while this one is transformed
+  auto load_group = [&](const __amdgpu_buffer_rsrc_t &r, int a_lo, int a_hi) {
 #pragma unroll
     for (int a = 0; a < 16; a++)
-      if (a >= a_lo && a < a_hi) raw[a] = L::template load<AUX_LD>(r, N, t + slot * (KIND == SCN_K_SHORT ? 2u * N : N), R * a);
+      if (a >= a_lo && a < a_hi) raw[a] = S::template load<AUX_LD>(r, tid, a);
   };
   uint32_t first = blockIdx.x * SLOTS;
   load_group(in_rsrc(first), 0, 16);
@@ -776,13 +837,22 @@ __global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
   for (; first < args.n_buffers; first += gridDim.x * SLOTS) {
     const uint32_t buf = first + slot;
     const bool valid = buf < args.n_buffers;
+    // ---- the chunk into the raw tile, this thread's 16 samples out of it ----
+#pragma unroll
+    for (int a = 0; a < 16; a++) S::stage(smem_raw, tid, a, raw[a]);
+    __syncthreads();  // barrier 1: raw tile complete
+    typename L::raw_t mine[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) mine[a] = S::gather(smem_raw, slot, R * (uint32_t)a + t);
+    const __amdgpu_buffer_rsrc_t rn = in_rsrc(first + gridDim.x * SLOTS);
+    load_group(rn, 0, 8);
     int dc_re = 0, dc_im = 0;
     if (DC) {  // integer mean with the reference's int32 /= uint32 quirk (utility.cpp:77-78), summed over the R lanes of this buffer
       int sr = 0, si = 0;
 #pragma unroll
       for (int a = 0; a < 16; a++) {
         int re, im;
-        L::ints(raw[a], re, im);
+        L::ints(mine[a], re, im);
         sr += re;
         si += im;
       }
@@ -796,13 +866,12 @@ __global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
     }
     cf v[16];
 #pragma unroll
-    for (int a = 0; a < 16; a++) v[a] = L::conv(raw[a], dc_re, dc_im, 1.0f) * win[a];
-    const __amdgpu_buffer_rsrc_t rn = in_rsrc(first + gridDim.x * SLOTS);
-    load_group(rn, 0, 8);
+    for (int a = 0; a < 16; a++) v[a] = L::conv(mine[a], dc_re, dc_im, 1.0f) * win[a];
 
     // ---- pass 1 ----
     fft16(v);
     cf x[16];  // output o = R m + r
+    __syncthreads();  // barrier 2: every gather done, the region becomes the exchange (R = 1: the dB tile)
     if constexpr (R == 1) {
 #pragma unroll
       for (int o = 0; o < 16; o++) x[o] = v[OUT16(o)];
@@ -814,7 +883,7 @@ __global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
         if (p) y = cmul(y, tw1[p]);
         lds[p * P1 + t] = to_v2f(y);
       }
-      __syncthreads();
+      __syncthreads();  // barrier 3
       // ---- pass 2: R-point DFTs over c, for p = t + R m ----
 #pragma unroll
       for (int m = 0; m < 16 / R; m++)
@@ -838,13 +907,28 @@ __global__ __launch_bounds__(256, 3) void scn_fft_tiny_kernel(ScnFftArgs args) {
           for (int r = 0; r < 8; r++) x[8 * m + r] = z[OUT8(r)];
         }
       }
+      if constexpr (SPEC) __syncthreads();  // barrier 4: every exchange read done, the region becomes the dB tile
     }
-    // ---- K4, K5 (scn_small_db_store_record) ----
-    const uint32_t nvalid = args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS;
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, (SPEC && args.power_db) ? nvalid * 4u * N : 0u);
-    scn_small_db_store_record<R, SPEC, HITS, AUX_ST>([&](int o) -> float { return power_of(x[o]); }, joff_of, rout, (slot * N + t) * 4u, args,
-                                                     buf, valid, keepmask, t, N);
-    if (R > 1) __syncthreads();  // exchange areas free again
+    // ---- K4, K5 (scn_small_db_store_record); the dB values into the tile, then out as whole lines ----
+    float *const my_tile = tile_out + slot * PITCH + t;
+    scn_small_db_store_record<R, SPEC, HITS>(
+        [&](int o) -> float { return power_of(x[o]); }, joff_of,
+        [&](int o, float d, bool pred) {
+          if (pred) my_tile[joff_of(o)] = d;
+        },
+        args, buf, valid, keepmask, t, N);
+    if constexpr (SPEC) {
+      __syncthreads();  // barrier 5: dB tile complete
+      const uint32_t nvalid = args.n_buffers - first < SLOTS ? args.n_buffers - first : SLOTS;
+      __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)first * N, args.power_db ? nvalid * 4u * N : 0u);
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const uint32_t e = 256u * (uint32_t)u + tid;  // bin e of the chunk: 256 consecutive bytes per wave instruction
+        const float d = tile_out[(e / N) * PITCH + e % N];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, tid * 4u, 1024u * (uint32_t)u, AUX_ST);
+      }
+    }
+    __syncthreads();  // barrier 6: the region is free for the next chunk
   }
 }
 

@@ -17,6 +17,8 @@ if [ -n "$SCN_PROF_MORE" ]; then   # the other wire formats and sizes (not BASEL
   bash scripts/prof.sh ${TAG}_n512cfloat --n 512 --batch 65536 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n256cfloat --n 256 --batch 131072 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n128cfloat --n 128 --batch 262144 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n64cfloat --n 64 --batch 262144 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n16cfloat --n 16 --batch 524288 > /dev/null 2>&1
   SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n65536cfloat --n 65536 --batch 512 > /dev/null 2>&1
   SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n32768cfloat --n 32768 --batch 1024 > /dev/null 2>&1
 fi

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 shapes_path = os.path.join(ROOT, "profiles", "measured_shapes.json")
 shapes = json.load(open(shapes_path)) if os.path.exists(shapes_path) else {}
-for shape in ("c1", "c2", "c3", "c4shape", "c5", "n256cfloat", "n128cfloat", "n4096int16", "n4096int8", "n16384cfloat", "n16384int16", "n8192cfloat", "n512cfloat", "n65536cfloat", "n32768cfloat"):
+for shape in ("c1", "c2", "c3", "c4shape", "c5", "n256cfloat", "n128cfloat", "n64cfloat", "n16cfloat", "n4096int16", "n4096int8", "n16384cfloat", "n16384int16", "n8192cfloat", "n512cfloat", "n65536cfloat", "n32768cfloat"):
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{shape}")
     if not os.path.exists(os.path.join(d, "summary.txt")):
         print("missing", d)

@@ -98,6 +98,22 @@ def test_worker_slot_ring_against_a_fake_plan(host_build, tmp_path, san):
     assert "worker ring tests ok" in out.stdout
 
 
+def test_abi_bench_refuses_what_it_does_not_understand(host_build):
+    """bench.py's C++ child (the records legs): an unknown option or a depth outside the plan's slots is an error before
+    anything touches the GPU, and without a GPU it says so instead of printing a line."""
+    exe = os.path.join(HOST, "abi_bench")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "--no-such-option", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "unknown argument" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([exe, "--depth", "9"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "--depth" in r.stderr
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "--steps", "1"], capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_reference_call_sites_compile(host_build, tmp_path):
     """The wiring of scan.cpp:211-239 written against the reference's names compiles unchanged."""
     src = tmp_path / "wiring.cpp"

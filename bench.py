@@ -52,7 +52,17 @@ def parse():
                          "power-management stall follows around launch 700-800, scripts/drift.py); 0 disables")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=8192)
-    ap.add_argument("--kind", default="cfloat", choices=["cfloat", "int16", "int8"])
+    ap.add_argument("--kind", default="cfloat", choices=["cfloat", "int16", "int16p", "int8"],
+                    help="wire format (int16p: planar int16, the SDRplay layout of utility.cpp:9-32)")
+    ap.add_argument("--plan-mode", default="both", choices=["both", "hits", "spectrum"],
+                    help="what the main leg's plan reports: both (SCN_OUT_SPECTRUM|SCN_OUT_HITS, the default and the only mode `value` "
+                         "of the driver's line is quoted on), hits (SCN_OUT_HITS alone: what ProcessSamples::ThreadWorker creates -- no "
+                         "spectrum is stored, the algorithmic bytes are the raw samples alone), spectrum (SCN_OUT_SPECTRUM alone)")
+    ap.add_argument("--dc", action="store_true", help="integer formats: remove the integer mean first (utility.cpp:70-79, correctDC)")
+    ap.add_argument("--time-domain", action="store_true",
+                    help="the reference CLI's default mode (scan.cpp:87, process.cpp:203-237): per-buffer max / min dB, no FFT")
+    ap.add_argument("--no-configs-leg", action="store_true",
+                    help="skip the short legs for BASELINE configs C3, the C4 per-GPU share and C5 that ride on the default C2 line (`configs`)")
     ap.add_argument("--threshold", type=float, default=None,
                     help="dB; default: 10 dB at 4096 points and the same margin over the noise mean at every other size "
                          "(10 + 5 log10(n / 4096): a bin's noise power grows with n, and a fixed 10 dB sits UNDER the noise mean of a "
@@ -92,7 +102,7 @@ def parse():
     return args
 
 
-def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s):
+def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s, dc=False):
     """Times the oracle (CPU restatement of process.cpp/fft.cpp/utility.cpp, its own FFT --
     NOT FFTW) on a bounded sample of the same buffers.  Checker code used as the reported
     baseline only; never on the product path."""
@@ -101,7 +111,7 @@ def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s):
     O.build()
     O.set_fft_mode(False)  # the float radix-2 FFT: FFTW computes in float too; the double-internal mode is for parity
     n = args.n
-    o = O.Oracle(n, FS, args.threshold, kind=kind_oracle, enob=enob)
+    o = O.Oracle(n, FS, args.threshold, kind=kind_oracle, enob=enob, correct_dc=dc)
     ncores = os.cpu_count() or 1
     tmax = min(8, ncores)  # the reference's cap, process.h:49
     res = {}
@@ -130,32 +140,20 @@ def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s):
     }
 
 
-def welch_main(args):
-    """C5: every rank processes its own stream (replicas, no collective).  A step = one submit of
-    --welch-psd PSDs = (n_psd*16 + 1) * 32768 complex samples, device-resident (rotated over R
-    streams past the Infinity Cache) or, with --welch-pinned, staged from pinned host memory
-    through the captured hipGraph (PCIe-bound)."""
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+def welch_leg(torch, dev, local_rank, seed, npsd, steps, warmup, rotate=0, pinned=False, sync=None):
+    """C5 steps on this GPU: a step = one submit of `npsd` PSDs = (npsd*16 + 1) * 32768 complex samples, device-resident (rotated
+    over R streams past the Infinity Cache) or, with `pinned`, staged from pinned host memory through the captured hipGraph
+    (PCIe-bound).  Returns (seconds for `steps` steps, new samples per step); sync() brackets the timed region (N > 1)."""
     from scanner_amd import WelchPlan
 
-    N, K, npsd = 65536, 16, args.welch_psd
+    N, K = 65536, 16
     plan = WelchPlan(N, K, max_psd=npsd, device_id=local_rank)
     m = plan.samples(npsd)
     new_samples = npsd * K * (N // 2)
-    R = args.rotate or max(2, -(-(3 << 29) // (m * 8)))
+    R = rotate or max(2, -(-(3 << 29) // (m * 8)))
     g = torch.Generator(device=dev)
-    g.manual_seed(5 + rank)
-    if args.welch_pinned:
+    g.manual_seed(seed)
+    if pinned:
         for s in range(2):
             hb = plan.host_buffer(s)
             hb[:m] = (torch.randn((m, 2), generator=g, device=dev) * 0.05).cpu().numpy().view(np.complex64).reshape(-1)
@@ -169,7 +167,7 @@ def welch_main(args):
         s = k & 1
         if pending[s]:
             plan.collect(s, want_psd=False)
-        if args.welch_pinned:
+        if pinned:
             plan.submit(s, npsd)
         else:
             plan.submit_device(s, xs[k % R], npsd, d_psd_db=outs[k % R], sync_producer=False)
@@ -181,33 +179,61 @@ def welch_main(args):
                 plan.collect(s, want_psd=False)
                 pending[s] = False
 
-    for k in range(args.warmup):
+    for k in range(warmup):
         step(k)
     drain()
-    if world > 1:
-        dist.barrier()
+    if sync:
+        sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         step(k)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if sync:
+        sync()
     elapsed = time.perf_counter() - t0
+    plan.close()
+    return elapsed, new_samples
+
+
+def welch_roofline(elapsed, steps, new_samples, npsd):
+    N, K = 65536, 16
+    algo = new_samples * 8 + npsd * N * 4  # 8 B per NEW sample + 4N/K per segment
+    ms = elapsed / steps * 1e3
+    achieved = algo / (ms * 1e-3) / 1e9
+    prof = _tracked(f"welch/{N}/{K}/{npsd}")
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_is": "frac_wall (host wall time per step: the Welch plan exposes no stream to put events on)",
+         "kernel": "scn_welch_cols_kernel + scn_welch_rows_kernel (two-pass four-step FFT: the work "
+                   "buffer round trip and the 50% overlap re-read are NOT algorithmic bytes)",
+         "kernels_avg_us_rocprof": prof.get("kernels"), "algorithmic_bytes_per_launch": algo}
+    r.update(roofline_from_profile(prof, algo))
+    return r, ms
+
+
+def welch_main(args):
+    """C5: every rank processes its own stream (replicas, no collective)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    npsd = args.welch_psd
+    elapsed, new_samples = welch_leg(torch, dev, local_rank, 5 + rank, npsd, args.steps, args.warmup, args.rotate, args.welch_pinned,
+                                     sync=dist.barrier if world > 1 else None)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     if rank == 0:
-        algo = new_samples * 8 + npsd * N * 4  # 8 B per NEW sample + 4N/K per segment
-        ms = elapsed / args.steps * 1e3
-        achieved = algo / (ms * 1e-3) / 1e9
-        prof = {}
-        try:
-            prof = _tracked(f"welch/{N}/{K}/{npsd}")
-        except Exception:
-            pass
+        roof, ms = welch_roofline(elapsed, args.steps, new_samples, npsd)
         emit({
             "metric": "Msamples/s (new complex samples through 65536-pt 50%-overlap Welch PSD)",
             "value": round(world * new_samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
@@ -216,18 +242,125 @@ def welch_main(args):
             "config": {"workload": f"C5: 65536-pt 50%-overlap Welch PSD, K=16, {npsd} PSDs per submit, Blackman-Harris, "
                                    f"{'pinned host staging + hipGraph replay' if args.welch_pinned else 'stream resident in HBM'}; "
                                    f"independent stream per GPU (replicas)",
-                       "n": N, "segments_per_psd": K, "psd_per_submit": npsd, "pinned": bool(args.welch_pinned)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("hbm_bytes_per_step"),
-                         "kernel": "scn_welch_cols_kernel + scn_welch_rows_kernel (two-pass four-step FFT: the work "
-                                   "buffer round trip and the 50% overlap re-read are NOT algorithmic bytes)",
-                         "kernels_avg_us_rocprof": prof.get("kernels"), "traffic_source": prof.get("source"),
-                         "algorithmic_bytes_per_launch": algo},
+                       "n": 65536, "segments_per_psd": 16, "psd_per_submit": npsd, "pinned": bool(args.welch_pinned)},
+            "roofline": roof,
         })
-    plan.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def quick_leg(torch, dev, local_rank, n, kind_name, nb, threshold, steps, make_input, fc, seq, overlap=False, depth=2, settle_s=0.15):
+    """One BASELINE configuration beside the headline, short and settled: `steps` launches of `nb` buffers through the prepared C-ABI
+    calls (scn_submit_device / scn_collect for counts and trigger flags), inputs and spectra rotated past the Infinity Cache, HIP
+    events on the stream(s) the kernels are launched on.  Returns the leg's object for the line's `configs`."""
+    import ctypes as C
+
+    from scanner_amd import Plan, capi
+
+    kind = {"cfloat": capi.KIND_FLOAT_COMPLEX, "int16": capi.KIND_SHORT_COMPLEX, "int8": capi.KIND_BYTE_COMPLEX}[kind_name]
+    bps = capi.BYTES_PER_SAMPLE[kind] + 4
+    R = max(2, -(-(3 << 29) // (nb * n * bps)))
+    raws = [make_input(r) for r in range(R)]
+    outs = [torch.empty((nb, n), dtype=torch.float32, device=dev) for _ in range(R)]
+    torch.cuda.synchronize()
+    flags = capi.OUT_SPECTRUM | capi.OUT_HITS | (capi.PLAN_OVERLAP_SLOTS if overlap else 0)
+    plan = Plan(n, FS, threshold, kind=kind, enob=8 if kind_name == "int8" else 12, max_batch=nb, max_hits=nb * max(64, n // 64),
+                device_id=local_rank, flags=flags)
+    streams = [torch.cuda.ExternalStream(plan.slot_stream_handle(s) if overlap else plan.stream_handle, device=dev) for s in range(depth if overlap else 1)]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    prep = [(C.c_void_p(raws[r].data_ptr()), nb, vp(fc), vp(seq), C.c_void_p(outs[r].data_ptr())) for r in range(R)]
+    pending = [False] * depth
+    state = {"launch": 0}
+
+    def run(k_steps):
+        for _ in range(k_steps):
+            s = state["launch"] % depth
+            if pending[s]:
+                plan.collect_counts(s)
+            plan.submit_prepared(s, *prep[state["launch"] % R])
+            pending[s] = True
+            state["launch"] += 1
+
+    def drain():
+        for j in range(depth):
+            s = (state["launch"] + j) % depth
+            if pending[s]:
+                plan.collect_counts(s)
+                pending[s] = False
+
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < settle_s:  # the GPU is warm from the headline legs: a short settle on this shape
+        run(50)
+    drain()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    e0.record(streams[0])
+    for e, st in zip(e1, streams):
+        e.record(st)
+    run(20)
+    drain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record(streams[0])
+    run(steps)
+    for e, st in zip(e1, streams):
+        e.record(st)
+    drain()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ev_ms = max(e0.elapsed_time(e) for e in e1) / steps
+    plan.close()
+    algo = nb * n * bps
+    leg = {"value": round(nb * n * steps / wall / 1e6, 1), "unit": "Msamples/s", "steps": steps, "ms_per_step": round(wall / steps * 1e3, 5),
+           "kernel": kernel_name(n, kind_name), "kernel_avg_ms": round(ev_ms, 5),
+           "algorithmic_bytes_per_launch": algo, "frac": round(algo / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "frac_is": "frac_event", "frac_wall": round(algo * steps / wall / 1e9 / HBM_PEAK_GBS, 4),
+           "threshold_db": threshold, "submits_in_flight": depth, "rotating_batches": R}
+    leg.update(roofline_from_profile(tracked_profile(n, kind_name, nb), algo))
+    return leg
+
+
+def config_legs(torch, dev, local_rank, steps=200):
+    """BASELINE configs C3, the C4 per-GPU share and C5 on the same box in the same run as the C2 headline (N = 1 only): short settled
+    legs, reported under `configs`, never in `value`."""
+    from scanner_amd import capi, synth
+
+    legs = {}
+    try:
+        # C3: 8192-pt FFT on int16 interleaved IQ, batch 4096 (on-GPU convert + window + FFT + log-power + threshold)
+        n, nb = 8192, 4096
+        thr = round(10.0 + 5.0 * np.log10(n / 4096.0), 2)
+        _, fc = capi.frequency_table(FS, 0.0, nb * USE_BW * FS, USE_BW, 0.0)
+        seq = np.arange(nb, dtype=np.uint64)
+
+        def c3_in(r):
+            x = synth.cfloat_batch_torch(n, nb, seed=3 + 1000 * r, device=dev)
+            return torch.clamp(torch.round(x * 2047.0), -2048, 2047).to(torch.int16).contiguous()
+
+        legs["c3"] = dict(quick_leg(torch, dev, local_rank, n, "int16", nb, thr, steps, c3_in, fc, seq),
+                          workload="C3: 8192-pt FFT on int16 interleaved IQ, batch 4096 resident in HBM, spectrum + hits, one stream, two in flight")
+        # C4 per-GPU share: the first 2048 of the 16384 centres (what rank 0 of 8 sweeps), one 4096-pt cfloat buffer per centre, a
+        # launch per sweep, every slot on its own stream, three in flight (bench.py --config c4 --centres 2048 --sweeps-per-launch 1)
+        n, nb, n_centres = 4096, 2048, 16384
+        _, fc = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0, shard=0, n_shards=8)
+        seq = np.arange(nb, dtype=np.uint64)
+        centres, i0 = synth.c4_emitters(n_centres, n)
+        legs["c4_share"] = dict(quick_leg(torch, dev, local_rank, n, "cfloat", nb, 10.0, 3 * steps,
+                                          lambda r: synth.c4_shard_torch(n, 0, nb, centres, i0, seed=4 + 1000 * r, device=dev), fc, seq,
+                                          overlap=True, depth=3),
+                                workload="C4 per-GPU share at 8 GPUs: centres [0, 2048) of the 16384-centre table x 4096-pt cfloat, a launch per "
+                                         "sweep, each slot on its own stream (SCN_PLAN_OVERLAP_SLOTS), three in flight: launches overlap, so the "
+                                         "step is shorter than one kernel's own begin-to-end time (frac_kernel_rocprof)")
+        # C5: 65536-pt 50%-overlap Welch PSD, 32 PSDs per submit, stream resident in HBM
+        el, new = welch_leg(torch, dev, local_rank, 5, 32, max(50, steps // 2), 10)
+        roof, ms = welch_roofline(el, max(50, steps // 2), new, 32)
+        legs["c5"] = dict({"value": round(new / (ms * 1e-3) / 1e6, 1), "unit": "Msamples/s (new samples)", "steps": max(50, steps // 2),
+                           "ms_per_step": round(ms, 5)}, **roof,
+                          workload="C5: 65536-pt 50%-overlap Welch PSD, K=16, 32 PSDs per submit, stream resident in HBM")
+    except Exception as e:  # a side leg must not cost the run its line
+        legs["error"] = f"{type(e).__name__}: {e}"[:300]
+    return legs
 
 
 _RESULT_FD = None
@@ -383,20 +516,25 @@ def abi_bench_legs(n, nb, kind, threshold, steps, depth):
     return out
 
 
-def kernel_name(n, kind, hits=True, spectrum=True):
+KIND_CPP = {"cfloat": "SCN_K_FLOAT_COMPLEX", "int16": "SCN_K_SHORT_COMPLEX", "int16p": "SCN_K_SHORT", "int8": "SCN_K_BYTE_COMPLEX"}
+
+
+def kernel_name(n, kind, hits=True, spectrum=True, dc=False, time_domain=False):
     """the kernel's name as rocprofv3 prints it: template arguments <.., KIND, DC, HITS, SPEC> (scn_kernels.hip)"""
-    k = {"cfloat": "SCN_K_FLOAT_COMPLEX", "int16": "SCN_K_SHORT_COMPLEX", "int8": "SCN_K_BYTE_COMPLEX"}[kind]
-    h, sp = ("true" if hits else "false"), ("true" if spectrum else "false")
+    k = KIND_CPP[kind]
+    h, sp, d = ("true" if hits else "false"), ("true" if spectrum else "false"), ("true" if dc and kind != "cfloat" else "false")
+    if time_domain:
+        return f"scn_time_domain_wave_kernel<{k}, {d}>"
     if n in (16, 32, 64, 128):  # 1, 2, 4 or 8 threads per buffer
-        return f"scn_fft_tiny_kernel<{n // 16}, {k}, false, {h}, {sp}>"
+        return f"scn_fft_tiny_kernel<{n // 16}, {k}, {d}, {h}, {sp}>"
     if n in (256, 512):  # several buffers per workgroup
-        return f"scn_fft_small_kernel<{n // 256}, {k}, false, {h}, {sp}>"
+        return f"scn_fft_small_kernel<{n // 256}, {k}, {d}, {h}, {sp}>"
     if n == 8192:
-        return f"scn_fft8k_kernel<{k}, false, {h}, {sp}>"
+        return f"scn_fft8k_kernel<{k}, {d}, {h}, {sp}>"
     if n == 16384:  # 32 x 16 x 32, pass 3 in double
-        return f"scn_fft16k2_kernel<{k}, false, {h}, {sp}>"
+        return f"scn_fft16k2_kernel<{k}, {d}, {h}, {sp}>"
     if n in (1024, 2048, 4096):
-        return f"scn_fft_kernel<{n // 256}, {k}, false, {h}, {sp}>"
+        return f"scn_fft_kernel<{n // 256}, {k}, {d}, {h}, {sp}>"
     if n == 65536:
         return f"scn_big_cols_kernel<{k}, 65536, false> + scn_big_rows_kernel<{h}, {sp}> (four-step 256 x 256, scn_big.hip: the work buffer's round trip is not algorithmic traffic)"
     if n == 32768:
@@ -404,10 +542,31 @@ def kernel_name(n, kind, hits=True, spectrum=True):
     return "scn_gen_load_kernel + scn_gen_stage_kernel x log4(n) + scn_gen_finish_kernel (the staged path, scn_generic.hip)"
 
 
-def tracked_profile(n, kind, nb):
+def shape_key(n, kind, nb, mode="both", dc=False, time_domain=False):
+    """key of a launch shape in profiles/measured_shapes.json: size / wire format / buffers per launch, then whatever differs
+    from the default plan (spectrum + hits, no DC removal, frequency domain)"""
+    return f"{n}/{kind}/{nb}" + ("/td" if time_domain else "" if mode == "both" else "/" + mode) + ("/dc" if dc else "")
+
+
+def tracked_profile(n, kind, nb, mode="both", dc=False, time_domain=False):
     """Numbers that come from their own rocprofv3 passes (scripts/prof.sh -> profiles/measured_shapes.json): the PMC
     traffic per launch and the kernel-trace average duration; only valid for the launch shape they were collected on."""
-    return _tracked(f"{n}/{kind}/{nb}")
+    return _tracked(shape_key(n, kind, nb, mode, dc, time_domain))
+
+
+CLOCK_GHZ, N_SIMD = 2.4, 1024  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+
+
+def roofline_from_profile(prof, algo_bytes):
+    """the fields of a roofline object that come from a tracked profile of THIS build (null otherwise): PMC traffic, the kernel's
+    own begin-to-end time under rocprofv3, and -- the second bound, for launches that are not HBM-bound -- valu_frac = the share of
+    the chip's VALU issue slots the launch used: SQ_INSTS_VALU (wave instructions) x 4 cycles / (kernel time x clock x SIMDs)"""
+    us = prof.get("kernel_avg_us")
+    return {"traffic": prof.get("hbm_bytes_per_launch", prof.get("hbm_bytes_per_step")),
+            "kernel_avg_us_rocprof": us,
+            "frac_kernel_rocprof": round(algo_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us else None,
+            "valu_frac": prof.get("valu_frac"), "valu_frac_is": "SQ_INSTS_VALU x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs)" if prof.get("valu_frac") else None,
+            "traffic_source": prof.get("source"), "traffic_build": prof.get("build"), "traffic_stale": prof.get("stale")}
 
 
 def _tracked(key):
@@ -457,10 +616,15 @@ def main():
     if c4:
         args.n, args.kind = 4096, "cfloat"
     n = args.n
-    kind = {"cfloat": capi.KIND_FLOAT_COMPLEX, "int16": capi.KIND_SHORT_COMPLEX, "int8": capi.KIND_BYTE_COMPLEX}[args.kind]
-    enob = {"cfloat": 12, "int16": 12, "int8": 8}[args.kind]
+    kind = {"cfloat": capi.KIND_FLOAT_COMPLEX, "int16": capi.KIND_SHORT_COMPLEX, "int16p": capi.KIND_SHORT, "int8": capi.KIND_BYTE_COMPLEX}[args.kind]
+    enob = {"cfloat": 12, "int16": 12, "int16p": 12, "int8": 8}[args.kind]
+    td = bool(args.time_domain)
+    if td:
+        args.plan_mode = "hits"  # (nothing but two floats per buffer comes back)
+    want_spec, want_hit = args.plan_mode != "hits", args.plan_mode != "spectrum"
+    dc = bool(args.dc) and args.kind != "cfloat"
     in_bytes = capi.BYTES_PER_SAMPLE[kind]
-    algo_bytes_per_sample = in_bytes + 4  # raw sample in + one float dB out
+    algo_bytes_per_sample = in_bytes + (4 if want_spec else 0)  # raw sample in + one float dB out; hits-only: the samples alone
 
     # this rank's shard of the frequency table (frequencyTable.cpp:9-37), contiguous range
     if c4:
@@ -501,6 +665,8 @@ def main():
             x = synth.cfloat_batch_torch(n, nb, seed=2 + rank + 1000 * r, device=dev)
         if kind == capi.KIND_SHORT_COMPLEX:
             raws.append(torch.clamp(torch.round(x * 2047.0), -2048, 2047).to(torch.int16).contiguous())
+        elif kind == capi.KIND_SHORT:  # planar: I[n] then Q[n] per buffer
+            raws.append(torch.clamp(torch.round(x * 2047.0), -2048, 2047).to(torch.int16).permute(0, 2, 1).contiguous())
         elif kind == capi.KIND_BYTE_COMPLEX:
             raws.append(torch.clamp(torch.round(x * 127.0), -128, 127).to(torch.int8).contiguous())
         else:
@@ -528,9 +694,12 @@ def main():
     # caller; overlapped, the next launch's workgroups take the CUs as they come free: 25.9 us (scanner_amd/host/abi_bench,
     # profiles/r04_experiments.md section 3).  The C2-sized launches keep the single-stream plan (see the `overlap` leg).
     c4_overlap = c4 and S == 1 and nb < 8192
-    main_flags = capi.OUT_SPECTRUM | capi.OUT_HITS | (capi.PLAN_OVERLAP_SLOTS if c4_overlap else 0)
+    mode_flags = (capi.OUT_SPECTRUM if want_spec else 0) | (capi.OUT_HITS if want_hit else 0)
+    flag_names = "|".join(f for f, on in (("SCN_OUT_SPECTRUM", want_spec), ("SCN_OUT_HITS", want_hit)) if on)
+    main_flags = mode_flags | (capi.PLAN_OVERLAP_SLOTS if c4_overlap else 0)
     main_depth = 3 if c4_overlap else 2
-    plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank, flags=main_flags)
+    plan = Plan(n, FS, args.threshold, kind=kind, enob=enob, correct_dc=dc, max_batch=nb, max_hits=hit_cap, device_id=local_rank, flags=main_flags,
+                mode=capi.MODE_TIME_DOMAIN if td else capi.MODE_FREQUENCY_DOMAIN)
     ext = torch.cuda.ExternalStream(plan.stream_handle, device=dev)
     slot_streams = [torch.cuda.ExternalStream(plan.slot_stream_handle(s), device=dev) for s in range(main_depth)] if c4_overlap else [ext]
 
@@ -544,7 +713,7 @@ def main():
         # counts-only loops with a launch per chunk go through the prepared calls (two ctypes calls per launch, every
         # argument a C value made here once): Python's own cost per step must stay below a 24 us launch
         import ctypes as C
-        fast = S == 1 and not want_records
+        fast = S == 1 and not want_records and not td
         if fast:
             vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
             prep = [[(C.c_void_p(raws[r][lo:hi].data_ptr()), hi - lo, vp(fc[lo:hi]), vp(seq[lo:hi]),
@@ -553,6 +722,10 @@ def main():
 
         def collect(s):
             tc0 = time.perf_counter()
+            if td:  # time-domain plans: max / min dB and the above-threshold flag per buffer (process.cpp:203-237)
+                pl.collect_time_domain(s)
+                pending[s] = False
+                return
             if zero_copy:  # counts + trigger flags from scn_collect, the records read in place (scn_hits_view)
                 pl.collect(s, want_power=False, want_hits=False)
                 h = pl.hits_view(s)
@@ -618,7 +791,7 @@ def main():
 
         return step, drain, state
 
-    step, drain, main_state = make_loop(plan, False, depth=main_depth)
+    step, drain, main_state = make_loop(plan, False, spectrum=want_spec, depth=main_depth)
 
     # The driver times as few as 20 steps (1.5 ms), so everything that is not a step stays out of the region AND out of the gap in
     # front of it: the events exist (a torch event creates its HIP event at the first record), no stream-context switches, no
@@ -686,6 +859,8 @@ def main():
     # the extra legs (reported beside the contract leg, never in `value`) time their own number of steps: a 20-step region is
     # mostly its own start and end, and these legs exist to show steady-state rates
     leg_steps = max(args.steps, 200)
+    if args.plan_mode != "both" or td:  # the side legs compare against the default plan: they ride on the default line only
+        args.no_records_leg = args.no_overlap_leg = args.no_hits_only_leg = args.no_configs_leg = True
 
     def timed_leg(pl, want_records, warm, zero_copy=False, spectrum=True, depth=2):
         st, dr, state = make_loop(pl, want_records, zero_copy, spectrum, depth)
@@ -695,13 +870,21 @@ def main():
         torch.cuda.synchronize()
         state["hits"] = 0
         state["collect_s"], state["collects"] = 0.0, 0
+        # launch-to-launch time on the stream the kernels are launched on (a single-stream plan: its own stream)
+        lst = torch.cuda.ExternalStream(pl.stream_handle, device=dev)
+        le0, le1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if world > 1:
             dist.barrier()
+        l0 = state["launch"]
         t2 = time.perf_counter()
+        le0.record(lst)
         for k in range(leg_steps):
             st(k)
+        state["flush"]()
+        le1.record(lst)
         dr()
         torch.cuda.synchronize()
+        state["event_ms_per_launch"] = le0.elapsed_time(le1) / max(1, state["launch"] - l0)
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t2
@@ -768,12 +951,22 @@ def main():
     if not args.no_hits_only_leg:
         plan3 = Plan(n, FS, args.threshold, kind=kind, enob=enob, max_batch=nb, max_hits=hit_cap, device_id=local_rank,
                      flags=capi.OUT_HITS)
-        el5, _ = timed_leg(plan3, False, min(args.warmup, 20), spectrum=False)
+        el5, st5 = timed_leg(plan3, False, min(args.warmup, 20), spectrum=False)
         in_bytes = algo_bytes_per_sample - 4
+        ho_ms = st5["event_ms_per_launch"]
+        ho_algo = nb * n * in_bytes
         hits_only = {"value": round(world * shard * n * leg_steps / el5 / 1e6, 1), "unit": "Msamples/s", "steps": leg_steps,
                      "ms_per_step": round(el5 / leg_steps * 1e3, 5), "algorithmic_bytes_per_sample": in_bytes,
+                     "algorithmic_bytes_per_launch": ho_algo,
                      "frac_of_hbm_peak_wall": round(shard * n * in_bytes * leg_steps / el5 / 1e9 / HBM_PEAK_GBS, 4),
+                     # the kernel ProcessSamples::ThreadWorker's plans run (scanner_amd/host/process.cpp): by name, its launch-to-launch
+                     # time on the plan's stream (HIP events) and, from this build's own rocprofv3 passes, its begin-to-end time,
+                     # PMC traffic and VALU issue share
+                     "kernel": kernel_name(n, args.kind, True, False), "kernel_avg_ms": round(ho_ms, 5),
+                     "frac": round(ho_algo / (ho_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frac_is": "frac_event",
                      "plan_flags": "SCN_OUT_HITS", "note": "wall clock over the same steps; not used for value/roofline"}
+        if rank == 0:
+            hits_only.update(roofline_from_profile(tracked_profile(n, args.kind, nb, "hits"), ho_algo))
         plan3.close()
 
     # What a plain device-to-device copy reaches on this box in this run: torch's copy kernel over buffers no
@@ -799,6 +992,9 @@ def main():
     tg0 = time.perf_counter()
     parts = []
     for j, (lo, hi) in enumerate(chunks):
+        if td or not want_hit:  # nothing to gather: a time-domain plan reports two floats per buffer, a spectrum-only plan no records
+            parts.append(np.zeros(0, capi.HIT_DTYPE))
+            continue
         plan.submit_device(j & 1, raw[lo:hi], hi - lo, fc[lo:hi], seq[lo:hi], sync_producer=False)
         parts.append(plan.collect(j & 1, want_power=False, want_hits=True)[1])
     hits = np.concatenate(parts) if len(parts) > 1 else parts[0]
@@ -816,7 +1012,7 @@ def main():
             try:
                 torch.cuda.set_device(dev)  # (the current device is per thread)
                 with sweep.HitGather(dev) as g:
-                    if len(chunks) == 1:  # the sweep's list is one collected slot: send it from where the compaction kernel left it
+                    if len(chunks) == 1 and want_hit and not td:  # the sweep's list is one collected slot: send it from where the compaction kernel left it
                         res["hits"], res["per_rank"] = g.gather_device(plan, 0)
                         how = "scn_gather_hits_device (the slot's device list, no host staging)"
                     else:
@@ -864,9 +1060,10 @@ def main():
     wall_launch_ms = elapsed / launches * 1e3
 
     if rank == 0:
-        prof = tracked_profile(n, args.kind, nb)
+        prof = tracked_profile(n, args.kind, nb, args.plan_mode, dc, td)
         out = {
-            "metric": "Msamples/s (complex samples through convert->window->FFT->dB->threshold)",
+            "metric": ("Msamples/s (complex samples through convert->max/min dB->threshold: time-domain mode, process.cpp:203-237)" if td else
+                       "Msamples/s (complex samples through convert->window->FFT->dB->threshold)"),
             "value": round(value, 1),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -885,11 +1082,14 @@ def main():
                              (", each slot on its own stream (SCN_PLAN_OVERLAP_SLOTS), three in flight" if c4_overlap else "") +
                              f", emitters planted on {len(centres)} centres, "
                              if c4 else
-                             f"{config_tag}: {n}-pt FFT+power+threshold, batch {nb} {args.kind} buffers per GPU resident in HBM, ") +
+                             f"{config_tag}: {n}-pt " + ("time-domain max/min dB + threshold" if td else "FFT+power+threshold") +
+                             f", batch {nb} {args.kind} buffers per GPU resident in HBM, " +
+                             ("" if args.plan_mode == "both" else f"plan reports {flag_names} only, ") + ("integer-mean DC removal on, " if dc else "")) +
                             f"Blackman-Harris, fs={FS} Hz, threshold {args.threshold} dB; frequency table range-sharded over "
                             f"{world} GPU(s); {settle_steps} untimed settle steps (>= {args.settle} s, until the launch time is steady) before the {args.warmup} warm-up steps",
                 "n": n, "batch_per_gpu": shard, "buffers_per_launch": nb, "sample_kind": args.kind,
-                "parallelism": f"table-shard x{world}", "plan_flags": "SCN_OUT_SPECTRUM|SCN_OUT_HITS" + ("|SCN_PLAN_OVERLAP_SLOTS" if c4_overlap else ""),
+                "parallelism": f"table-shard x{world}", "plan_flags": flag_names + ("|SCN_PLAN_OVERLAP_SLOTS" if c4_overlap else ""),
+                "plan_mode": args.plan_mode, "correct_dc": dc, "time_domain": td,
                 "rotating_batches": R, "footprint_MiB": round(R * step_bytes / 2**20),
             },
             "swept_GHz_per_s": round(buffers_per_s * USE_BW * FS / 1e9, 1),
@@ -897,7 +1097,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("hbm_bytes_per_launch"),
-                "kernel": kernel_name(n, args.kind), "kernel_avg_ms": round(kernel_ms, 5),
+                "kernel": kernel_name(n, args.kind, want_hit, want_spec, dc, td), "kernel_avg_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_sample": algo_bytes_per_sample,
                 "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                 # the same bytes over three clocks, side by side: HIP events launch-to-launch on the plan's stream (what
@@ -911,9 +1111,8 @@ def main():
                 "frac_is": "frac_event",
                 "frac_event": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_wall": round(algo_bytes_per_launch / (wall_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "frac_kernel_rocprof": (round(algo_bytes_per_launch / (prof["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                                        if prof.get("kernel_avg_us") else None),
-                "traffic_source": prof.get("source"), "traffic_build": prof.get("build"), "traffic_stale": prof.get("stale"),
+                # + from this build's own rocprofv3 passes: frac_kernel_rocprof, valu_frac (the second bound), traffic_source / _build / _stale
+                **{k: v for k, v in roofline_from_profile(prof, algo_bytes_per_launch).items() if k != "traffic"},
             },
             "threshold_db": args.threshold,
             "hit_density": round(len(all_hits) / max(1, samples_per_step * 0.7485), 6),  # hits per EVALUATED bin (the mask of process.cpp:46-52 keeps 3066 of 4096)
@@ -963,14 +1162,18 @@ def main():
         out["with_hit_records"] = records
         out["overlap"] = overlap
         out["hits_only"] = hits_only
-        if not args.no_cpu_baseline and world == 1:
+        if world == 1 and not c4 and not args.no_configs_leg and (n, args.kind, nb) == (4096, "cfloat", 8192):
+            out["configs"] = config_legs(torch, dev, local_rank)  # C3, the C4 per-GPU share and C5 beside the C2 headline
+        # the reference's CPU path beside the GPU number, in the same run on the same box: on rank 0 at every N (north_star; the
+        # other ranks wait at the closing barrier meanwhile -- it is outside every timed region)
+        if not args.no_cpu_baseline and not td:
             host = raw[: min(shard, 4096)].cpu().numpy()
-            okind = {"cfloat": 4, "int16": 3, "int8": 1}[args.kind]
+            okind = {"cfloat": 4, "int16": 3, "int16p": 2, "int8": 1}[args.kind]
             if args.kind == "cfloat":
                 host = host.view(np.complex64).reshape(host.shape[0], n)
             args.batch = shard
-            out["cpu_baseline"] = cpu_baseline(args, host, okind, enob, args.cpu_seconds)
-        elif world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, host, okind, enob, args.cpu_seconds, dc)
+        else:
             out["cpu_baseline"] = None
         emit(out)
     else:

@@ -14,6 +14,7 @@ LIB = os.path.join(HERE, "libscanner_hip.so")
 SOURCES = ["scn_kernels.hip", "scn_generic.hip", "scn_big.hip", "scn_hits.hip", "scn_welch.hip", "scn_gather.hip", "scn_api.hip"]
 HEADERS = ["scn_kernels.h", "scn_device.h", os.path.join("..", "..", "include", "scanner_hip.h")]
 ARCH = "gfx950"
+KERNEL_TUS = 8  # scn_kernels.hip is compiled once per SCN_TU value (its SCN_TU_COUNT): one group of fused sizes each, side by side
 
 
 def hipcc():
@@ -35,12 +36,17 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+HASH_FILE = LIB + ".hash"  # source_hash() of the sources the library beside it was built from
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    """The library is current iff the hash recorded beside it at build time equals the hash of the sources as they are now --
+    the same identity the profiling evidence is stamped with (profiles/measured_shapes.json).  Modification times are not
+    consulted: a pushed tree whose .so is newer than an edited source would otherwise run stale kernels under a current hash."""
+    if not os.path.exists(LIB) or not os.path.exists(HASH_FILE):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(HASH_FILE) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False, defines=(), out=None):
@@ -49,25 +55,35 @@ def build(force=False, verbose=False, defines=(), out=None):
     target = out or LIB
     if not out and not force and not _stale():
         return LIB
-    objs = []
+    built_from = source_hash()
+    objs, cmds = [], []
     tag = "" if not out else "." + os.path.basename(out).replace(".so", "")
-    for src in SOURCES:
-        obj = os.path.join(os.path.dirname(out) if out else CSRC, src.replace(".hip", tag + ".o"))  # variants keep their objects beside them
+    units = [(src, None) for src in SOURCES if src != "scn_kernels.hip"] + [("scn_kernels.hip", tu) for tu in range(KERNEL_TUS)]
+    for src, tu in sorted(units, key=lambda u: u[1] is None):  # the fused-kernel units first: the 8192- / 16384-point ones take longest
+        suffix = tag + ("" if tu is None else f".tu{tu}") + ".o"
+        obj = os.path.join(os.path.dirname(out) if out else CSRC, src.replace(".hip", suffix))  # variants keep their objects beside them
         # -fno-slp-vectorize: keep the FFT butterflies as scalar f32 ops.  On gfx950 a packed
         # v_pk_*_f32 issues in the same 4 cycles as two scalar ops, and the SLP-packed stream
         # needs ~180 extra v_mov/v_pk_mov per FFT to pair registers (measured: 801 vs 668 VALU
         # instructions in the loop body).
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-fno-slp-vectorize", *[f"-D{d}" for d in defines],
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
+               "-fno-slp-vectorize", *[f"-D{d}" for d in defines], *([] if tu is None else [f"-DSCN_TU={tu}"]),
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        cmds.append(cmd)
         objs.append(obj)
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1)) as pool:  # one hipcc per translation unit, side by side
+        list(pool.map(subprocess.check_call, cmds))
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    if not out:
+        with open(HASH_FILE, "w") as fh:
+            fh.write(built_from + "\n")
     return target
 
 

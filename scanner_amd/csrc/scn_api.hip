@@ -115,7 +115,13 @@ struct Slot {
 struct scn_plan {
   scn_plan_desc d;
   int num_cus = 0;
-  bool records_wanted = false;  // did the last scn_collect ask for hit records? (decides where the next list is built)
+  bool records_wanted = false;  // does the caller take hit records? (decides where the next list is built: scn_collect sets it)
+  // Callers that read the records in place (scn_collect for the counts, then scn_hits_view -- only when there ARE hits) never
+  // pass scn_collect a record buffer: the view marks the plan, and the mark wears off after four collects in a row that had
+  // hits and were not followed by a view.  (Until round 5 every scn_collect without a buffer cleared records_wanted, so after
+  // any batch without a detection the next submit was not eager and the first batch with hits built its list on demand, on
+  // the consumer's critical path.)
+  uint32_t view_age = 0xffffffffu;  // collects with hits since the last scn_hits_view (saturating; "never" at first)
   uint32_t predict = 0;         // records the next list is expected to hold (last total + a margin, scn_collect): the prefetch size
   uint32_t last_total = 0;      // the total before that: the margin grows with the change between consecutive batches
   // How the per-buffer counts reach the host.  false: a 4*n_buffers-byte copy on the d2h stream behind the kernel -- on
@@ -369,8 +375,13 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     // this submit's generation; the only thing that can still be using it is the list (compaction + copy) of the submit TWO
     // submits back ON THIS SLOT -- 2 x (slots in use) launches back on the plan -- wait for it on the host, where it never
     // blocks in practice
+    // -- and the list of the submit before this one on this slot, whose compaction output (d_list) and pinned copy (h_list)
+    // exist once per slot: its prefetch DMA rides the D2H stream, which nothing on the list stream is ordered behind, so the
+    // next compaction must not start while it may still be reading d_list (a caller that collected counts only has not
+    // waited for it).  Both waits are host-side queries of events that completed long ago in any steady loop.
     s.gen ^= 1u;
-    if (s.list_used[s.gen] && hipEventQuery(s.list_done[s.gen]) != hipSuccess) SCN_HIP(hipEventSynchronize(s.list_done[s.gen]));
+    for (uint32_t g = 0; g < 2; g++)
+      if (s.list_used[g] && hipEventQuery(s.list_done[g]) != hipSuccess) SCN_HIP(hipEventSynchronize(s.list_done[g]));
     // the header fields: read by the compaction kernel in place, over PCIe (two 8-byte reads per buffer that has hits;
     // staging copies cost ~7 us each plus ~10 us of cross-engine hand-off, on the list's critical path)
     double *h_fc = static_cast<double *>(s.h_meta) + (size_t)2u * p->d.max_batch * s.gen;
@@ -906,7 +917,8 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   if (total > 0x7fffffffu) return fail(SCN_E_INVALID, "%llu hits in one submit: split the batch", (unsigned long long)total);
   s.total_hits = (uint32_t)total;
   if (have_hits) {  // what the automatic mode goes by at the next submit
-    p->records_wanted = hits != nullptr;
+    if (total && p->view_age < 0xffffffffu) p->view_age++;
+    p->records_wanted = hits != nullptr || p->view_age <= 4u;
     // the prefetch covers this total + 1/16 + twice the change since the total before (the DMA's time is the records loop's
     // period on a hits-only plan: a flat 25 % margin cost 46 us per submit instead of 39; a short prediction costs one small
     // top-up copy at collect)
@@ -974,7 +986,8 @@ int scn_hits_view(scn_plan *p, int slot, const scn_hit **hits, uint32_t *n) {
   if (s.pending || !s.list_valid) return fail(SCN_E_STATE, "slot %d: no collected submit whose hit list is still available", slot);
   SCN_HIP(hipSetDevice(p->d.device_id));
   *n = std::min(s.total_hits, p->d.max_hits);
-  p->records_wanted = true;  // (a caller that reads the list through the view wants it built eagerly too)
+  p->view_age = 0;  // (a caller that reads the list through the view wants it built eagerly too)
+  p->records_wanted = true;
   if (*n && (st = fetch_list(p, s, *n))) return st;
   *hits = s.h_list;
   return SCN_OK;

@@ -376,7 +376,9 @@ __device__ __forceinline__ void scn_record_hits_lanes(VEC &pw, const float (&gma
         // point): a bin whose product-form value equals that of its thread-group's strong maximum gets the exact form of that
         // maximum -- so the two output modes report the same float for every bin, also when two distinct powers of a group
         // share a product-form value
-        const float gm = (o / GS) & 2u ? ((o / GS) & 1u ? gmax[3] : gmax[2]) : ((o / GS) & 1u ? gmax[1] : gmax[0]);
+        // (through the select tree, not `gmax[o / GS]`: hipcc turns the C++ selects into an indexed read of a PRIVATE array --
+        //  32 bytes of scratch, a scratch store per buffer and a scratch load per trip in every hits-only 16384-point kernel)
+        const float gm = scn_select_output<4>(gmax, o / GS);
         const bool ex = gm >= SCN_P_EXACT_FROM && d == db_fast(gm);
         if (__ballot(act && ex)) d = ex ? db_exact(gm) : d;
       }

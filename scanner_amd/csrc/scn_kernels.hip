@@ -29,6 +29,16 @@
 #include "scn_device.h"
 #include "scn_kernels.h"
 
+// Build-time split: every kernel here is a template, compiled where a launcher instantiates it.  scanner_amd/build.py compiles
+// this file once per SCN_TU value, side by side, each translation unit instantiating one group of sizes (a single hipcc run
+// over all 330 specialisations takes a minute, most of it in the 8192- and 16384-point kernels); without SCN_TU (-1) one
+// translation unit holds everything.
+#ifndef SCN_TU
+#define SCN_TU -1
+#endif
+#define SCN_IN_TU(x) (SCN_TU == -1 || SCN_TU == (x))
+#define SCN_TU_COUNT 8  // 0: 16 / 32 points, 1: 64 / 128, 2: 256 / 512, 3: 1024 / 2048, 4: 4096, 5: 8192, 6: 16384, 7: everything that is not a fused FFT kernel
+
 namespace {
 
 // ---- global memory access through buffer descriptors ---------------------------------
@@ -736,8 +746,10 @@ struct GeoTiny {
 };
 
 // the chunk's raw elements through the LDS tile, per wire format: thread tid loads element 256 a + tid (a < 16; the planar
-// format: two 16-bit elements, 256 (2a) + tid and 256 (2a + 1) + tid, of the chunk's I / Q blocks), stage() writes what it
-// loaded to [slot][PITCH], gather() returns sample j of buffer `slot` in RawLoader's register form.
+// format: ONE 32-bit load of the two neighbouring 16-bit elements 512 a + 2 tid (+1) of the chunk's I / Q blocks -- N is even, so
+// both lie in the same block of the same buffer; as two 16-bit loads packed in registers the prefetch held 32 registers
+// instead of 16 until the pack and these kernels spilled 9 .. 16 VGPRs), stage() writes what it loaded to [slot][PITCH],
+// gather() returns sample j of buffer `slot` in RawLoader's register form.
 template <int KIND, int R>
 struct TinyStage {
   typedef GeoTiny<R> G;
@@ -747,9 +759,7 @@ struct TinyStage {
   template <int AUX>
   static __device__ __forceinline__ reg_t load(__amdgpu_buffer_rsrc_t r, uint32_t tid, int a) {
     if constexpr (PLANAR) {
-      const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b16(r, tid * 2u, 256u * 2u * (2u * (uint32_t)a), AUX);
-      const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b16(r, tid * 2u, 256u * 2u * (2u * (uint32_t)a + 1u), AUX);
-      return (int)((lo & 0xffffu) | (hi << 16));
+      return __builtin_amdgcn_raw_buffer_load_b32(r, tid * 4u, 1024u * (uint32_t)a, AUX);
     } else {
       return L::template load<AUX>(r, G::N, tid, 256u * (uint32_t)a);
     }
@@ -759,7 +769,7 @@ struct TinyStage {
       unsigned short *t16 = reinterpret_cast<unsigned short *>(tile);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const uint32_t e = 256u * (2u * (uint32_t)a + h) + tid, s = e / (2u * G::N), j = e % (2u * G::N);
+        const uint32_t e = 512u * (uint32_t)a + 2u * tid + h, s = e / (2u * G::N), j = e % (2u * G::N);
         t16[s * 2u * G::PITCH + (j < G::N ? j : G::PITCH + j - G::N)] = (unsigned short)(h ? (uint32_t)v >> 16 : (uint32_t)v & 0xffffu);
       }
     } else {
@@ -1647,6 +1657,7 @@ __global__ __launch_bounds__(256) void scn_time_domain_wave_kernel(ScnTdArgs arg
   }
 }
 
+#if SCN_IN_TU(7)
 hipError_t scn_launch_time_domain(int kind, bool dc, const ScnTdArgs &a, int num_cus, hipStream_t s) {
   if (a.n_buffers == 0) return hipSuccess;
   void (*k)(ScnTdArgs) = nullptr;
@@ -1675,6 +1686,7 @@ hipError_t scn_launch_time_domain(int kind, bool dc, const ScnTdArgs &a, int num
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }
+#endif  // SCN_IN_TU(7)
 
 // ------------------------------------------------------------------------------------
 // K1 alone: raw wire format -> complex float (utility.cpp:9-84), for the triggered-capture path
@@ -1713,6 +1725,7 @@ __global__ __launch_bounds__(256) void scn_convert_kernel(const void *raw, scn_v
   }
 }
 
+#if SCN_IN_TU(7)
 hipError_t scn_launch_convert(int kind, bool dc, const void *raw, scn_v2f *out, uint32_t n, uint32_t n_buffers, float scale,
                               hipStream_t s) {
   if (n_buffers == 0) return hipSuccess;
@@ -1727,6 +1740,7 @@ hipError_t scn_launch_convert(int kind, bool dc, const void *raw, scn_v2f *out, 
   hipLaunchKernelGGL(k, dim3(n_buffers < 2048 ? n_buffers : 2048), dim3(256), 0, s, raw, out, n, n_buffers, scale);
   return hipGetLastError();
 }
+#endif  // SCN_IN_TU(7)
 
 // ------------------------------------------------------------------------------------
 // host-side launcher
@@ -1836,6 +1850,47 @@ static hipError_t launch_family(int kind, bool dc, bool hits, bool spec, const S
   }
 }
 
+// one launcher per translation unit (the sizes it instantiates), and the dispatcher over them
+#define SCN_FFT_LAUNCH_ARGS int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop
+#define SCN_FFT_LAUNCH_PASS kind, dc, hits, spec, args, num_cus, stream, stop
+hipError_t scn_launch_fft_tu0(uint32_t n, SCN_FFT_LAUNCH_ARGS);
+hipError_t scn_launch_fft_tu1(uint32_t n, SCN_FFT_LAUNCH_ARGS);
+hipError_t scn_launch_fft_tu2(uint32_t n, SCN_FFT_LAUNCH_ARGS);
+hipError_t scn_launch_fft_tu3(uint32_t n, SCN_FFT_LAUNCH_ARGS);
+hipError_t scn_launch_fft_tu4(uint32_t n, SCN_FFT_LAUNCH_ARGS);
+hipError_t scn_launch_fft_tu5(uint32_t n, SCN_FFT_LAUNCH_ARGS);
+hipError_t scn_launch_fft_tu6(uint32_t n, SCN_FFT_LAUNCH_ARGS);
+#if SCN_IN_TU(0)
+hipError_t scn_launch_fft_tu0(uint32_t n, SCN_FFT_LAUNCH_ARGS) {
+  return n == 16 ? launch_family<TinyFamily<1>>(SCN_FFT_LAUNCH_PASS) : launch_family<TinyFamily<2>>(SCN_FFT_LAUNCH_PASS);
+}
+#endif
+#if SCN_IN_TU(1)
+hipError_t scn_launch_fft_tu1(uint32_t n, SCN_FFT_LAUNCH_ARGS) {
+  return n == 64 ? launch_family<TinyFamily<4>>(SCN_FFT_LAUNCH_PASS) : launch_family<TinyFamily<8>>(SCN_FFT_LAUNCH_PASS);
+}
+#endif
+#if SCN_IN_TU(2)
+hipError_t scn_launch_fft_tu2(uint32_t n, SCN_FFT_LAUNCH_ARGS) {
+  return n == 256 ? launch_family<SmallFamily<1>>(SCN_FFT_LAUNCH_PASS) : launch_family<SmallFamily<2>>(SCN_FFT_LAUNCH_PASS);
+}
+#endif
+#if SCN_IN_TU(3)
+hipError_t scn_launch_fft_tu3(uint32_t n, SCN_FFT_LAUNCH_ARGS) {
+  return n == 1024 ? launch_family<NarrowFamily<4>>(SCN_FFT_LAUNCH_PASS) : launch_family<NarrowFamily<8>>(SCN_FFT_LAUNCH_PASS);
+}
+#endif
+#if SCN_IN_TU(4)
+hipError_t scn_launch_fft_tu4(uint32_t, SCN_FFT_LAUNCH_ARGS) { return launch_family<NarrowFamily<16>>(SCN_FFT_LAUNCH_PASS); }
+#endif
+#if SCN_IN_TU(5)
+hipError_t scn_launch_fft_tu5(uint32_t, SCN_FFT_LAUNCH_ARGS) { return launch_family<Family8k>(SCN_FFT_LAUNCH_PASS); }
+#endif
+#if SCN_IN_TU(6)
+hipError_t scn_launch_fft_tu6(uint32_t, SCN_FFT_LAUNCH_ARGS) { return launch_family<Family16k>(SCN_FFT_LAUNCH_PASS); }
+#endif
+
+#if SCN_IN_TU(7)
 hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus,
                           hipStream_t stream, hipEvent_t stop) {
   if (!hits && !spec) return hipErrorInvalidValue;
@@ -1843,17 +1898,13 @@ hipError_t scn_launch_fft(uint32_t n, int kind, bool dc, bool hits, bool spec, c
   // (256 / 512 points: one descriptor spans a workgroup's SLOTS buffers only, but the per-lane offsets are 32-bit)
   if (n < 1024 && (uint64_t)args.n_buffers * n * 8u > 0xffffffffull) return hipErrorInvalidValue;
   switch (n) {
-    case 16: return launch_family<TinyFamily<1>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 32: return launch_family<TinyFamily<2>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 64: return launch_family<TinyFamily<4>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 128: return launch_family<TinyFamily<8>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 256: return launch_family<SmallFamily<1>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 512: return launch_family<SmallFamily<2>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 1024: return launch_family<NarrowFamily<4>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 2048: return launch_family<NarrowFamily<8>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 4096: return launch_family<NarrowFamily<16>>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 8192: return launch_family<Family8k>(kind, dc, hits, spec, args, num_cus, stream, stop);
-    case 16384: return launch_family<Family16k>(kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 16: case 32: return scn_launch_fft_tu0(n, SCN_FFT_LAUNCH_PASS);
+    case 64: case 128: return scn_launch_fft_tu1(n, SCN_FFT_LAUNCH_PASS);
+    case 256: case 512: return scn_launch_fft_tu2(n, SCN_FFT_LAUNCH_PASS);
+    case 1024: case 2048: return scn_launch_fft_tu3(n, SCN_FFT_LAUNCH_PASS);
+    case 4096: return scn_launch_fft_tu4(n, SCN_FFT_LAUNCH_PASS);
+    case 8192: return scn_launch_fft_tu5(n, SCN_FFT_LAUNCH_PASS);
+    case 16384: return scn_launch_fft_tu6(n, SCN_FFT_LAUNCH_PASS);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1866,3 +1917,4 @@ void scn_tw1_layout(uint32_t n, uint32_t *rows, uint32_t *threads) {
   *rows = n == 16384 ? 31u : 15u;
   *threads = n == 16384 ? 512u : n / 16u;
 }
+#endif  // SCN_IN_TU(7)

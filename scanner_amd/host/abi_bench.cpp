@@ -242,9 +242,13 @@ int main(int argc, char **argv) {
       const scn_hit *v = nullptr;
       uint32_t nv = 0;
       st = api.hits_view(plan, (int)s, &v, &nv);
-      if (st == SCN_OK && nv) checksum += v[0].freq_hz + v[nv - 1].freq_hz;  // (touch the list: first and last record)
+      // the consumer READS every record (the reference formats each one, process.cpp:57): the whole pinned list is walked, as
+      // the copy mode pays a full memcpy of it -- first and last record alone would time the DMA landing, not the read
+      if (st == SCN_OK)
+        for (uint32_t k = 0; k < nv; k++) checksum += v[k].freq_hz + v[k].i;
     } else if (st == SCN_OK && mode == "copy" && nh) {
-      checksum += rec[0].freq_hz + rec[std::min<size_t>(nh, rec.size()) - 1].freq_hz;
+      const size_t nc = std::min<size_t>(nh, rec.size());
+      for (size_t k = 0; k < nc; k++) checksum += rec[k].freq_hz + rec[k].i;
     }
     if (st != SCN_OK && !rc) {
       fprintf(stderr, "abi_bench: collect: %s\n", api.last_error());

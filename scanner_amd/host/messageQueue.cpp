@@ -47,9 +47,9 @@ SampleQueue::SampleQueue(SampleKind kind, uint32_t enob, uint32_t sampleCount, u
                          bool correctDCOffset, bool doWrite)
     : m_kind(kind), m_enob(enob), m_sampleCount(sampleCount), m_bufferCount(bufferCount),
       m_correctDCOffset(correctDCOffset), m_doWrite(doWrite), m_bufferBytes(bytesPerSample(kind) * sampleCount),
-      m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_stagingCapacity(0), m_fillSlot(0),
+      m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_stagingCapacity(0), m_fillSlot(0), m_unstagedQueued(0),
       m_nextSequenceId(0), m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0),
-      m_writeShutdown(false), m_writeErrors(0), m_producerWaitNs(0) {
+      m_writeShutdown(false), m_writeErrors(0), m_producerWaitNs(0), m_stagedAppends(0), m_copiedAppends(0), m_queuedAtAttach(0) {
   assert(kind > Illegal && kind <= FloatComplex);  // messageQueue.h:163
   assert(bufferCount > 0);
   if (m_poolSize <= bufferCount) m_poolSize = bufferCount + 1;
@@ -110,12 +110,12 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
     m_notFull.wait(l);
     m_producerWaitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   };
-  bool staged = false;
-  if (!m_staging.empty()) {
-    // a place in the consumer's pinned slot: wait for room in the queue AND in a slot (the one being filled, or -- once that
-    // one is full or has been taken -- the next in the ring, as soon as the consumer has released it)
+  // a place in the consumer's pinned slot: wait for room in the queue AND in a slot (the one being filled, or -- once that
+  // one is full or has been taken -- the next in the ring, as soon as the consumer has released it).  False once there are no
+  // staging slots (never attached, or detached while waiting).
+  auto acquirePlace = [&]() -> bool {
     while (!m_staging.empty()) {
-      if (m_buffer.size() >= m_bufferCount) {
+      if (m_unstagedQueued || m_buffer.size() >= m_bufferCount) {  // (messages queued before the attach go first, through slots the consumer is given)
         timedWait(lock);
         continue;
       }
@@ -130,8 +130,7 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
         message->m_slot = m_fillSlot;
         message->m_staged = fs.base + (size_t)fs.fill * m_bufferBytes;
         fs.fill++;
-        staged = true;
-        break;
+        return true;
       }
       if (fs.state == StagingSlot::Open) {  // full and still queued: on to the next slot of the ring, once the consumer has released it
         const int next = (m_fillSlot + 1) % (int)m_staging.size();
@@ -142,7 +141,9 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
       }
       timedWait(lock);  // (the fill slot, or the one after a full one, is still in flight; ReleaseStaging and DetachStaging signal this too)
     }
-  }
+    return false;
+  };
+  const bool staged = acquirePlace();
   if (staged) {
     // The copy runs under the queue's lock: the consumer seals a slot by what is QUEUED, so a buffer must not be half-way
     // into a slot when that happens (1.6 us for a 32 KiB buffer; the consumer takes a whole batch per lock round trip).
@@ -156,7 +157,21 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
     memcpy(message->GetRawData(), a, aBytes);
     if (bBytes) memcpy(static_cast<unsigned char *>(message->GetRawData()) + aBytes, b, bBytes);
     lock.lock();
+    // The consumer may have attached its slots while this buffer was being copied outside the lock: it then takes a place in a
+    // slot like any later one (behind whatever was queued at the attach), so that from the attach on every NEW message is a
+    // staged one and the consumer never has to fit a copied message between slots the producer is writing to.
+    MessageType *const pooled = message;
+    while (m_staging.empty() && m_buffer.size() >= m_bufferCount) timedWait(lock);  // (room in the queue first: an attach may come while waiting)
+    if (acquirePlace()) {
+      memcpy(message->m_staged, pooled->GetRawData(), m_bufferBytes);
+      m_stagedAppends++;
+      Free(pooled);
+    } else {
+      message = pooled;
+      m_copiedAppends++;
+    }
   }
+  if (staged) m_stagedAppends++;
   MessageHeader &h = message->GetHeader();
   h.m_time = time;
   h.m_frequency = centerFrequency;
@@ -211,18 +226,27 @@ SampleQueue::MessageType *SampleQueue::TryGetNextSamples() {
 bool SampleQueue::AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot) {
   if (m_doWrite || nSlots < 2 || buffersPerSlot == 0) return false;  // (the capture writer's history needs storage of its own)
   std::unique_lock<std::mutex> lock(m_mutex);
-  if (!m_staging.empty() || !m_buffer.empty()) return false;  // one consumer, attached before anything is queued
+  if (!m_staging.empty()) return false;  // one consumer
+  // The documented start order is Start, StartStreaming, THEN StartProcessing (signalSource.h:5, scan.cpp:234-238), and a plan
+  // takes hundreds of milliseconds to create: the producer has almost always queued buffers by now, often a full queue of
+  // them.  (Until round 5 a non-empty queue refused the attach -- silently, so the zero-copy path all but never engaged.)
+  // Those messages stay what they are, pooled and unstaged; the consumer takes them first, a slot's worth at a time, into
+  // slots the queue reserves for it in ring order (TakeStagedBatch), and the producer opens no slot before the last of them
+  // is gone: at no time do the consumer's copy and the producer's append write to the same slot, and nothing is reordered.
   for (uint32_t i = 0; i < nSlots; i++) m_staging.push_back(StagingSlot{static_cast<unsigned char *>(slotBases[i]), 0, StagingSlot::Free});
   m_stagingMessages.clear();
   for (size_t i = 0; i < (size_t)nSlots * buffersPerSlot; i++) m_stagingMessages.emplace_back(new MessageType(0));  // headers only
   m_stagingCapacity = buffersPerSlot;
   m_fillSlot = 0;
+  m_unstagedQueued = m_buffer.size();
+  m_queuedAtAttach = m_buffer.size();
   return true;
 }
 
 void SampleQueue::DetachStaging() {
   std::unique_lock<std::mutex> lock(m_mutex);
   m_staging.clear();
+  m_unstagedQueued = 0;
   m_notFull.notify_all();  // a producer waiting for a slot goes on with the messages' own storage
 }
 
@@ -236,9 +260,27 @@ uint32_t SampleQueue::TakeStagedBatch(std::vector<MessageType *> &out, int *slot
   if (block && lingerMicros && !m_done && !m_buffer.empty() && m_buffer.size() < m_stagingCapacity)
     m_notEmpty.wait_until(lock, std::chrono::system_clock::now() + std::chrono::microseconds(lingerMicros));  // (system clock -> pthread_cond_timedwait: gcc 11's TSan does not know the steady-clock wait)
   if (m_buffer.empty()) return 0;
+  if (m_unstagedQueued && !m_staging.empty()) {
+    // messages queued before the attach: up to a slot's worth of them, oldest first, and the next slot of the ring to copy
+    // them into -- reserved (in flight) from here on; the producer opens no slot while any of them is left
+    const int rs = m_fillSlot;
+    uint32_t n = 0;
+    while (m_unstagedQueued && n < m_stagingCapacity) {
+      out.push_back(m_buffer.back());
+      m_buffer.pop_back();
+      m_unstagedQueued--;
+      n++;
+    }
+    m_staging[rs].state = StagingSlot::InFlight;
+    m_staging[rs].fill = 0;
+    m_fillSlot = (rs + 1) % (int)m_staging.size();
+    *slot = rs;
+    m_notFull.notify_all();
+    return n;
+  }
   const int s = m_buffer.back()->m_slot;
   uint32_t n = 0;
-  while (!m_buffer.empty() && m_buffer.back()->m_slot == s && (s >= 0 || n == 0)) {  // (an unstaged message travels alone)
+  while (!m_buffer.empty() && m_buffer.back()->m_slot == s && (s >= 0 || n == 0)) {  // (an unstaged message -- only after DetachStaging -- travels alone)
     out.push_back(m_buffer.back());
     m_buffer.pop_back();
     n++;

@@ -91,7 +91,8 @@ class SampleQueue {
   // returns to the producer with ReleaseStaging, after the consumer has collected its results.  Sequence ids, the discarded
   // warm-up sweep (messageQueue.h:67-72), the queue's bound and its blocking behaviour are unchanged; a staged message is
   // recycled as soon as it is processed (the history ring of the capture writer needs storage of its own: a queue built
-  // with doWrite refuses staging and keeps the copying path).
+  // with doWrite refuses staging and keeps the copying path).  Messages that were queued before the attach are handed out
+  // first, unstaged, a slot's worth at a time together with the slot reserved for them: the consumer copies those itself.
   bool AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot);
   void DetachStaging();  // the consumer is leaving: appends fall back to the messages' own storage
   uint32_t TakeStagedBatch(std::vector<MessageType *> &out, int *slot, bool block, uint32_t lingerMicros = 0);
@@ -114,6 +115,11 @@ class SampleQueue {
   uint32_t GetWriteErrorCount() const { return m_writeErrors; }  // files that could not be opened / short writes
   // seconds the producer has spent blocked in AppendSamples (queue full / no free staging slot): where a slow pipeline shows
   double GetProducerWaitSeconds() const { return m_producerWaitNs.load() * 1e-9; }
+  // which path the appends took: written straight into a consumer's pinned slot / copied into a pooled message; and how many
+  // messages were already queued when the consumer attached (the producer runs while the consumer is still creating its plan)
+  uint64_t GetStagedAppendCount() const { return m_stagedAppends.load(); }
+  uint64_t GetCopiedAppendCount() const { return m_copiedAppends.load(); }
+  uint64_t GetQueuedAtAttachCount() const { return m_queuedAtAttach.load(); }
 
  private:
   void SynchronizedAppend(const void *a, size_t aBytes, const void *b, size_t bBytes, double centerFrequency,
@@ -141,6 +147,7 @@ class SampleQueue {
   std::vector<std::unique_ptr<MessageType>> m_stagingMessages;  // [slot][place]: the message objects of the staged buffers
   uint32_t m_stagingCapacity;
   int m_fillSlot;
+  size_t m_unstagedQueued;  // messages queued before AttachStaging that the consumer has not taken yet (the oldest in the queue)
   uint64_t m_nextSequenceId;
   uint32_t m_iterationCount;
   std::atomic<bool> m_done;
@@ -160,5 +167,6 @@ class SampleQueue {
   bool m_writeShutdown;  // set by the destructor: the consumers are gone, drain what is there and stop
   std::atomic<uint32_t> m_writeErrors;
   std::atomic<uint64_t> m_producerWaitNs;
+  std::atomic<uint64_t> m_stagedAppends, m_copiedAppends, m_queuedAtAttach;
   Converter m_converter;
 };

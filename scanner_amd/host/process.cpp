@@ -45,7 +45,7 @@ ProcessSamples::ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_
       m_preTrigger(preTrigger), m_postTrigger(postTrigger), m_endSequenceId(0), m_writing(false), m_mode(mode),
       m_fileNameBase(fileNameBase), m_threshold(threshold), m_useBandWidth(useBandWidth), m_windowType(windowType),
       m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_pipeDepth(3), m_firstDevice(0), m_hitCount(0),
-      m_bufferCount(0), m_tWait(0), m_tSubmit(0), m_tCollect(0), m_tReport(0), m_failed(false) {
+      m_bufferCount(0), m_stagedWorkers(0), m_tWait(0), m_tSubmit(0), m_tCollect(0), m_tReport(0), m_failed(false) {
   (void)dcIgnoreWidth;  // the reference ignores it too and hard-codes 4 bins (process.cpp:86-88)
   assert(mode > Illegal && mode <= FrequencyDomain);  // process.cpp:99
   assert(threadCount <= MAX_THREADS);                 // process.cpp:100
@@ -146,7 +146,9 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   // One consumer: the queue writes the producer's buffers straight into the plan's pinned slots and a slot is submitted as
   // it is -- no copy in this thread (the reference's ThreadWorker copies every buffer, process.cpp:293; so did rounds 1-3 here).
   // Several consumers (or a capturing queue, whose history ring needs storage of its own) keep the copying path.
+  // (What the producer queued while this thread was creating its plan comes first, unstaged, with a slot reserved for it.)
   const bool staged = m_threadCount == 1 && kPipe >= 2 && q.AttachStaging((void *const *)stage, (uint32_t)kPipe, d.max_batch);
+  if (staged) m_stagedWorkers++;
 
   std::vector<double> fc(d.max_batch);
   std::vector<uint64_t> seq(d.max_batch);
@@ -244,6 +246,8 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
       int slot = -1;
       n = q.TakeStagedBatch(inflight[head], &slot, inFlight == 0, 40);
       if (!n && !inFlight) more = false;
+      // (The queue fills -- and, for messages queued before the attach, reserves -- its slots in ring order, the order this
+      //  thread submits them in; anything else means the slot about to be submitted is not the memory the samples are in.)
       if (n && slot != head) {
         Fail("ProcessSamples: the queue handed out staging slot " + std::to_string(slot) + ", the worker expected " + std::to_string(head));
         for (SampleQueue::MessageType *m : inflight[head]) q.MessageProcessed(m);
@@ -255,8 +259,10 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
         return abandon(plan);
       }
       for (uint32_t b = 0; b < n; b++) {
-        fc[b] = inflight[head][b]->GetHeader().m_frequency;
-        seq[b] = inflight[head][b]->GetHeader().m_sequenceId;
+        SampleQueue::MessageType *const m = inflight[head][b];
+        if (m->GetStagingSlot() < 0) memcpy(stage[head] + (size_t)b * bufBytes, m->GetRawData(), bufBytes);  // queued before the attach
+        fc[b] = m->GetHeader().m_frequency;
+        seq[b] = m->GetHeader().m_sequenceId;
       }
     } else if (more) {
       // block for the first message only while nothing is in flight; then take what is queued

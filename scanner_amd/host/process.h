@@ -50,6 +50,9 @@ class ProcessSamples {
   void SetPipelineDepth(uint32_t depth) { m_pipeDepth = depth; }
   uint64_t GetHitCount() const { return m_hitCount; }
   uint64_t GetBufferCount() const { return m_bufferCount; }
+  // consumer threads that run the zero-copy path (the queue writes into their plan's pinned slots, SampleQueue::AttachStaging);
+  // the others copy every message into a slot themselves
+  uint32_t GetStagedWorkerCount() const { return m_stagedWorkers; }
   // where the consumer threads' time went, summed over threads (seconds): waiting for the producer, in scn_submit, in
   // scn_collect / scn_hits_view (waiting for the GPU), reporting (printf, acks, recycling)
   struct WorkerTimes {
@@ -86,6 +89,7 @@ class ProcessSamples {
   uint32_t m_maxBatch, m_pipeDepth;
   int m_firstDevice;
   std::atomic<uint64_t> m_hitCount, m_bufferCount;
+  std::atomic<uint32_t> m_stagedWorkers;
   std::atomic<uint64_t> m_tWait, m_tSubmit, m_tCollect, m_tReport;  // nanoseconds, see GetWorkerTimes
   std::atomic<bool> m_failed;
   std::mutex m_errorMutex;

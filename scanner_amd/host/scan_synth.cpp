@@ -105,5 +105,9 @@ int main(int argc, char **argv) {
   const ProcessSamples::WorkerTimes wt = process.GetWorkerTimes();
   fprintf(stderr, "producer blocked %.3f s; consumer: waiting for samples %.3f s, scn_submit %.3f s, scn_collect %.3f s, reporting %.3f s\n",
           sampleQueue.GetProducerWaitSeconds(), wt.waitProducer, wt.submit, wt.collect, wt.report);
+  // which path the samples took: a silent fall-back to the copying worker is a different measurement
+  fprintf(stderr, "staging: %u of %u consumer thread(s) zero-copy; appends written into a pinned slot %lu, copied into a pooled message %lu, queued before the attach %lu\n",
+          process.GetStagedWorkerCount(), threads, (unsigned long)sampleQueue.GetStagedAppendCount(), (unsigned long)sampleQueue.GetCopiedAppendCount(),
+          (unsigned long)sampleQueue.GetQueuedAtAttachCount());
   return ok ? 0 : 1;
 }

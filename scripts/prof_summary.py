@@ -95,14 +95,24 @@ if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
     shape = {}
     try:  # the launch shape the counters belong to (bench.py only reports them for the same shape)
         cfg = json.loads(open(os.path.join(out, "bench_trace.json")).read().strip().splitlines()[-1])["config"]
-        shape = {k: cfg.get(k) for k in ("n", "sample_kind", "batch_per_gpu", "buffers_per_launch", "segments_per_psd", "psd_per_submit")}
+        shape = {k: cfg.get(k) for k in ("n", "sample_kind", "batch_per_gpu", "buffers_per_launch", "segments_per_psd", "psd_per_submit",
+                                         "plan_mode", "correct_dc", "time_domain")}
     except Exception:
         pass
     if len(per_kernel) > 1:  # several kernels make up one step (Welch: columns + rows): bytes per step = the sum
         fetch = sum(cs.get("FETCH_SIZE", 0) for cs in per_kernel.values()) * 1024 * 2
         write = sum(cs.get("WRITE_SIZE", 0) for cs in per_kernel.values()) * 1024
         print(f"hbm_bytes_per_step over {len(per_kernel)} kernels = {fetch + write:.4g}  (read {fetch:.4g}, write {write:.4g})")
+    # the second bound, for launches that are not HBM-bound: the share of the chip's VALU issue slots the launch used.  SQ_INSTS_VALU
+    # counts wave instructions; a 64-lane wave instruction occupies its 16-lane SIMD for 4 cycles (double-precision ones longer: a
+    # lower bound there); 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
+    k_us = sum(kernel_avg_us.values()) if kernel_avg_us else None
+    valu = summary.get("SQ_INSTS_VALU")
+    valu_frac = (valu * 4.0 / (k_us * 1e-6 * 2.4e9 * 1024)) if (valu and k_us) else None
+    if valu_frac is not None:
+        print(f"valu_frac = SQ_INSTS_VALU {valu:.4g} x 4 cycles / ({k_us:.2f} us x 2.4 GHz x 1024 SIMDs) = {valu_frac:.3f}")
     json.dump(dict({"hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write,
+                    "insts_valu": valu, "valu_frac": None if valu_frac is None else round(valu_frac, 4),
                     "kernel_avg_us": sum(kernel_avg_us.values()) if kernel_avg_us else None,
                     "kernels": {k: round(v, 3) for k, v in kernel_avg_us.items()},
                     "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 correction)",

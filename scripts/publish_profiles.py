@@ -11,7 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 shapes_path = os.path.join(ROOT, "profiles", "measured_shapes.json")
 shapes = json.load(open(shapes_path)) if os.path.exists(shapes_path) else {}
-for shape in ("c1", "c2", "c3", "c4shape", "c5", "n256cfloat", "n128cfloat", "n64cfloat", "n16cfloat", "n4096int16", "n4096int8", "n16384cfloat", "n16384int16", "n8192cfloat", "n512cfloat", "n65536cfloat", "n32768cfloat"):
+import glob
+
+found = sorted(os.path.basename(d)[len(f"prof_{tag}_"):] for d in glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_*")))
+for shape in found:  # every launch shape scripts/prof_all.sh profiled under this tag
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{shape}")
     if not os.path.exists(os.path.join(d, "summary.txt")):
         print("missing", d)
@@ -23,11 +26,14 @@ for shape in ("c1", "c2", "c3", "c4shape", "c5", "n256cfloat", "n128cfloat", "n6
         continue
     t = json.load(open(os.path.join(d, "pmc_traffic.json")))
     welch = t.get("segments_per_psd") is not None
+    mode = t.get("plan_mode") or "both"
     key = (f"welch/{t['n']}/{t['segments_per_psd']}/{t['psd_per_submit']}" if welch
-           else f"{t['n']}/{t['sample_kind']}/{t['buffers_per_launch']}")
+           else f"{t['n']}/{t['sample_kind']}/{t['buffers_per_launch']}" +  # = bench.py's shape_key
+                ("/td" if t.get("time_domain") else "" if mode == "both" else "/" + mode) + ("/dc" if t.get("correct_dc") else ""))
     entry = {("hbm_bytes_per_step" if welch else "hbm_bytes_per_launch"): int(round(t["hbm_bytes_per_launch"])),
              "read_bytes": int(round(t["read_bytes"])), "write_bytes": int(round(t["write_bytes"])),
              "kernel_avg_us": round(t["kernel_avg_us"], 3), "kernels": t["kernels"],
+             "insts_valu": t.get("insts_valu"), "valu_frac": t.get("valu_frac"),
              "source": f"profiles/{tag}_{shape}_rocprofv3_summary.txt",
              # which build the counters were taken on (the profiling run writes it; the current tree's hash otherwise)
              "build": t.get("build") or _build.source_hash(),

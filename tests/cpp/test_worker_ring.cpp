@@ -41,6 +41,9 @@ uint64_t g_tickets = 0, g_collected = 0;
 uint32_t g_hitsPerBuffer = 2;
 int g_failSubmitAt = -1;               // fail the k-th submit (1-based); -1: never
 int g_collectSleepUs = 0;              // "GPU time" a collect waits for
+int g_planCreateSleepUs = 0;           // a real plan takes hundreds of ms to create: the producer fills the queue meanwhile
+uint64_t g_stagedAppends = 0, g_copiedAppends = 0, g_queuedAtAttach = 0, g_buffers = 0;
+uint32_t g_stagedWorkers = 0;
 int g_submits = 0, g_maxInFlight = 0, g_inFlight = 0;
 thread_local std::string g_err;
 
@@ -60,6 +63,7 @@ int scn_device_count(int *count) {
   return SCN_OK;
 }
 int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
+  if (g_planCreateSleepUs) std::this_thread::sleep_for(std::chrono::microseconds(g_planCreateSleepUs));
   FakePlan *p = new FakePlan;
   p->d = *desc;
   const size_t per = desc->sample_kind == SCN_KIND_FLOAT_COMPLEX ? 8 : desc->sample_kind == SCN_KIND_BYTE_COMPLEX ? 2 : 4;
@@ -190,6 +194,11 @@ std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t s
     ok = source.Start() && source.StartStreaming(sweeps + 1, q);
     if (ok) ok = process.StartProcessing(q);
     source.StopStreaming();
+    g_stagedWorkers = process.GetStagedWorkerCount();
+    g_stagedAppends = q.GetStagedAppendCount();
+    g_copiedAppends = q.GetCopiedAppendCount();
+    g_queuedAtAttach = q.GetQueuedAtAttachCount();
+    g_buffers = process.GetBufferCount();
   }
   fflush(stdout);
   fclose(stdout);
@@ -213,13 +222,34 @@ int main() {
   g_hitsPerBuffer = 2;
   g_failSubmitAt = -1;
   g_collectSleepUs = 2000;  // (long against the producer's microseconds per buffer also on a loaded test host)
-  std::vector<uint64_t> got = run(256, 4, 64, 6, ok);
+  std::vector<uint64_t> got = run(256, 4, 64, 30, ok);  // (7 centres per sweep: 210 buffers)
   CHECK(ok);
   for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
   CHECK(g_violations.empty());
   CHECK(got.size() > 50 && got == g_expected);
   CHECK(g_maxInFlight == 3);  // kPipe of process.cpp
   const int fastSubmits = g_submits;
+  // WHICH path ran (a refused attach used to fall back to the copying worker silently, and the staged path was
+  // covered by timing luck): one zero-copy consumer, every append accounted for, and what was copied into a pooled message is
+  // exactly what the producer had queued before the consumer attached (plus at most the one append in flight across it)
+  CHECK(g_stagedWorkers == 1);
+  CHECK(g_stagedAppends + g_copiedAppends == g_buffers && g_stagedAppends > 0);
+  CHECK(g_copiedAppends == g_queuedAtAttach);
+
+  // 1b. the start order the reference documents (Start, StartStreaming, then StartProcessing) with a plan that takes its time
+  //     to create: the producer has FILLED the queue (64 messages, more than the ring's 3 x 4 places) when the consumer
+  //     attaches.  Those come first, copied by the worker into slots reserved for it; everything after is written in place.
+  g_planCreateSleepUs = 50000;
+  got = run(256, 4, 64, 40, ok);
+  g_planCreateSleepUs = 0;
+  CHECK(ok);
+  for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
+  CHECK(g_violations.empty());
+  CHECK(got.size() > 50 && got == g_expected);
+  fprintf(stderr, "1b: staged workers %u, queued at attach %lu, copied %lu, staged %lu, buffers %lu\n", g_stagedWorkers, (unsigned long)g_queuedAtAttach,
+          (unsigned long)g_copiedAppends, (unsigned long)g_stagedAppends, (unsigned long)g_buffers);
+  CHECK(g_stagedWorkers == 1 && g_queuedAtAttach == 64 && g_copiedAppends == 64);
+  CHECK(g_stagedAppends + g_copiedAppends == g_buffers && g_stagedAppends > 0);
 
   // 2. a slow producer (long buffers), an instant "GPU": the queue runs empty between batches, every batch is reported at once
   g_collectSleepUs = 0;
@@ -239,7 +269,7 @@ int main() {
   g_hitsPerBuffer = 2;
   g_collectSleepUs = 2000;  // (long against the producer's microseconds per buffer also on a loaded test host)
   g_failSubmitAt = fastSubmits / 2;
-  got = run(256, 4, 64, 6, ok);
+  got = run(256, 4, 64, 30, ok);
   CHECK(!ok);
   for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
   CHECK(g_violations.empty());

@@ -16,11 +16,11 @@ CONTRACT = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
             "config": dict}
 
 
-def run_bench(extra, env=None):
+def run_bench(extra, env=None, batch=("--batch", "512")):
     e = dict(os.environ)
     e.update(env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--settle",
-                          "0.05", "--batch", "512", "--cpu-seconds", "0.6"] + extra,
+                          "0.05", *batch, "--cpu-seconds", "0.6"] + extra,
                          capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -63,6 +63,13 @@ def test_bench_line_single_process():
     assert d["roofline"]["frac_wall"] <= d["roofline"]["frac_event"] * 1.05
     h = d["hits_only"]                                   # hits-only mode is reported separately, on its own byte count
     assert h["value"] > 0 and h["algorithmic_bytes_per_sample"] == 8 and h["plan_flags"] == "SCN_OUT_HITS"
+    # ... with the kernel the worker's plans run, by name, and its own clocks / counters like `roofline` has
+    assert h["kernel"] == "scn_fft_kernel<16, SCN_K_FLOAT_COMPLEX, false, true, false>" and h["kernel_avg_ms"] > 0
+    assert abs(h["frac"] - h["algorithmic_bytes_per_launch"] / (h["kernel_avg_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
+    for k in ("frac_kernel_rocprof", "traffic", "valu_frac", "traffic_source", "traffic_build", "traffic_stale"):
+        assert k in h, k
+    assert "valu_frac" in d["roofline"] and "frac_kernel_rocprof" in d["roofline"]
+    assert "configs" not in d                            # (they ride on the default C2 line only: this run has --batch 512)
     assert d["roofline"]["measured_copy_GBs"] > 500      # a device-to-device copy measured in the same run
 
 
@@ -78,3 +85,34 @@ def test_bench_line_through_torch_distributed_one_rank():
     g = d["gather"]                                                                        # the C-ABI's RCCL gather, not torch's
     assert g["transport"].startswith("scn_gather_hits") and g["globally_ordered"] is True
     assert g["per_rank"] == [d["final_sweep_hits"]]
+
+
+def test_default_line_carries_a_leg_per_baseline_config():
+    """`python bench.py` (C2) also times C3, the C4 per-GPU share and C5 on the same box in the same run"""
+    d = run_bench(["--no-records-leg", "--no-overlap-leg", "--no-copy-ref"], batch=())
+    check_common(d)
+    assert d["config"]["buffers_per_launch"] == 8192 and d["config"]["workload"].startswith("C2:")
+    c = d["configs"]
+    assert "error" not in c, c
+    for leg, kern in (("c3", "scn_fft8k_kernel<SCN_K_SHORT_COMPLEX, false, true, true>"),
+                      ("c4_share", "scn_fft_kernel<16, SCN_K_FLOAT_COMPLEX, false, true, true>"), ("c5", "scn_welch_cols_kernel")):
+        g = c[leg]
+        assert g["value"] > 0 and g["ms_per_step"] > 0 and 0 < g["frac"] < 1 and g["kernel"].startswith(kern) and g["workload"]
+        for k in ("frac_kernel_rocprof", "traffic", "traffic_source", "traffic_build", "traffic_stale", "algorithmic_bytes_per_launch"):
+            assert k in g, (leg, k)
+    assert c["c3"]["algorithmic_bytes_per_launch"] == 4096 * 8192 * 8 and c["c4_share"]["algorithmic_bytes_per_launch"] == 2048 * 4096 * 12
+    assert c["c4_share"]["submits_in_flight"] == 3
+
+
+def test_bench_on_the_workers_kind_of_plan_and_in_time_domain_mode():
+    """what scripts/prof_all.sh profiles for the product's own worker: a hits-only plan (with DC removal), the time-domain kernel"""
+    d = run_bench(["--n", "8192", "--kind", "int16", "--plan-mode", "hits", "--dc", "--no-cpu-baseline"])
+    check_common(d)
+    assert d["roofline"]["kernel"] == "scn_fft8k_kernel<SCN_K_SHORT_COMPLEX, true, true, false>"
+    assert d["roofline"]["algorithmic_bytes_per_sample"] == 4 and d["config"]["plan_flags"] == "SCN_OUT_HITS"
+    assert d["config"]["plan_mode"] == "hits" and d["config"]["correct_dc"] is True and d["final_sweep_hits"] > 0
+    assert d["hits_only"] is None and d["overlap"] is None and d["with_hit_records"] is None
+    d = run_bench(["--n", "8192", "--kind", "int8", "--time-domain", "--no-cpu-baseline"])
+    check_common(d)
+    assert d["roofline"]["kernel"] == "scn_time_domain_wave_kernel<SCN_K_BYTE_COMPLEX, false>"
+    assert d["roofline"]["algorithmic_bytes_per_sample"] == 2 and d["config"]["time_domain"] is True

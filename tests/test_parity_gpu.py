@@ -143,6 +143,59 @@ def test_hip_against_an_independent_float32_fft(torch_cuda, n):
     assert [(int(s), int(i)) for s, i in zip(h["seq_id"], h["i"])] == want and len(want) > 0
 
 
+def test_one_slot_alternating_counts_only_and_records_collects(torch_cuda, oracle_mod):
+    """The ordered list and its pinned copy exist ONCE per slot while regions and counts have two generations (scn_api.hip): a
+    caller that collects counts only on one submit and reads records on the next -- through scn_collect, through scn_hits_view,
+    with batches without any detection in between -- must always see the records of THAT submit (the ordering of the
+    prefetch DMA against the slot's next compaction; the eager / on-demand decision across scn_collect and scn_hits_view)."""
+    n, nb = 4096, 48
+    batches = [synth.cfloat_batch(n, nb, seed=300 + k, sigma=0.05) for k in range(4)]
+    quiet = (synth.cfloat_batch(n, nb, seed=299, sigma=0.05, max_tones=0) * np.float32(1e-3)).astype(np.complex64)   # nothing above the threshold
+    fc = 1e9 + 6e6 * np.arange(nb)
+    thr = tol.pick_threshold(np.concatenate([oracle_mod.Oracle(n, FS, 1e9).run(x)[0] for x in batches]), n, start=12.0)   # guard-band-free
+    refs = [oracle_mod.Oracle(n, FS, thr).run(x, fc, np.arange(nb, dtype=np.uint64) + 1000 * k)[1] for k, x in enumerate(batches)]
+    assert all(len(r) > 20 for r in refs)
+    devs = [_to_dev(torch_cuda, x) for x in batches]
+    dquiet = _to_dev(torch_cuda, quiet)
+    with Plan(n, FS, thr, max_batch=nb, max_hits=1 << 16) as plan:
+        def submit(k):
+            plan.submit_device(0, devs[k], nb, fc, np.arange(nb, dtype=np.uint64) + 1000 * k)
+
+        def same(h, k):
+            # (spectra are held to the bar elsewhere; here: the records are those of submit k, in order)
+            return len(h) == len(refs[k]) and np.array_equal(h["seq_id"], refs[k]["seq_id"]) and np.array_equal(h["i"], refs[k]["i"])
+
+        order = [0, 1, 2, 3, 1, 0, 3, 2, 2, 1]
+        for step, k in enumerate(order):       # ONE slot: every submit re-uses d_list / h_list of the one before
+            submit(k)
+            how = step % 3
+            if how == 0:                         # counts only: nobody waits for this submit's list
+                _, h, _ = plan.collect(0, want_power=False, want_hits=False)
+                assert h is None and plan.last_n_hits == len(refs[k])
+            elif how == 1:                       # records copied out by scn_collect
+                _, h, _ = plan.collect(0, want_power=False, want_hits=True, hit_cap=1 << 16)
+                assert same(h, k), (step, k)
+            else:                                # counts from scn_collect, records read in place
+                plan.collect(0, want_power=False, want_hits=False)
+                assert same(plan.hits_view(0), k), (step, k)
+        # a reader of the view stays an eager one across batches without detections (it never calls the view for those)
+        for k in (0, 1):
+            submit(k)
+            plan.collect(0, want_power=False, want_hits=False)
+            assert same(plan.hits_view(0), k)
+            plan.submit_device(0, dquiet, nb, fc)
+            plan.collect(0, want_power=False, want_hits=False)
+            assert plan.last_n_hits == 0 and len(plan.hits_view(0)) == 0
+        submit(2)
+        plan.collect(0, want_power=False, want_hits=False)
+        assert same(plan.hits_view(0), 2)
+        # the view is a window on memory the next submit may overwrite: a copy taken now stays what it was
+        keep = plan.hits_view(0).copy()
+        submit(3)
+        plan.collect(0, want_power=False, want_hits=False)
+        assert same(plan.hits_view(0), 3) and same(keep, 2)
+
+
 def test_pinned_double_buffered_submit(torch_cuda, oracle_mod):
     """scn_host_buffer + scn_submit on both slots (the replacement of sampleBuffer.cpp's
     staging), results identical to the device-resident path and to the oracle."""
@@ -586,19 +639,80 @@ def test_integer_kinds_4096(torch_cuda, oracle_mod, kind, enob, dc):
     assert np.array_equal(t, t_ref)
 
 
-def test_dc_quirk_negative_mean(torch_cuda, oracle_mod):
-    """utility.cpp:77-78: int32 /= uint32 turns a negative sum into a huge positive 'mean'.
-    The HIP path must reproduce the same (nonsensical) samples, hence the same spectrum."""
-    n, nb = 4096, 3
-    rng = np.random.default_rng(4)
-    raw = rng.integers(-300, 100, size=(nb, n, 2)).astype(np.int16)     # mean < 0 on both rails
-    raw[2] = -raw[2]                                                     # and one positive-mean buffer
-    o = oracle_mod.Oracle(n, FS, 1e9, kind=capi.KIND_SHORT_COMPLEX, enob=12, correct_dc=True)
-    c = o.convert(raw[0])
-    assert c.real.max() < -500                                           # the quirk is in play: 'mean' ~ 2^32/N
-    (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, capi.KIND_SHORT_COMPLEX, raw,
-                                                 np.zeros(nb), None, 1e9, 12, True)
-    tol.compare_spectra(p, p_ref)
+def _negative_sum_buffers(n, nb, kind, seed):
+    """raw integer buffers whose I and Q sums are NEGATIVE on both rails (the `int32 /= uint32` of utility.cpp:77-78 then yields a
+    'mean' of ~2^32 / n), mixed with buffers that are negative on one rail only and with ordinary positive-mean ones, so that the
+    lanes of one wave / the slots of one workgroup hold different cases side by side"""
+    rng = np.random.default_rng(seed)
+    lo, hi = (-100, 40) if kind == capi.KIND_BYTE_COMPLEX else (-300, 100)
+    raw = rng.integers(lo, hi, size=(nb, n, 2)).astype(np.int8 if kind == capi.KIND_BYTE_COMPLEX else np.int16)
+    raw[2::5] = -raw[2::5]                    # positive on both rails
+    raw[3::5, :, 1] = -raw[3::5, :, 1]        # I negative, Q positive
+    raw[4::5, :, 0] = -raw[4::5, :, 0]        # I positive, Q negative
+    if kind == capi.KIND_SHORT:
+        raw = np.ascontiguousarray(np.moveaxis(raw, -1, -2))   # planar: I[n] then Q[n]
+    return raw
+
+
+# one size per kernel family, each with its own DC reduction: tiny (a segmented shuffle over R lanes), small (over T lanes),
+# narrow (wave sums through LDS), 8192 (two samples per lane and load), 16384 (half a buffer prefetched), the four-step pair
+# (scn_big_dc_kernel: a pass of its own over the raw samples), Bluestein (scn_gen_load_kernel)
+@pytest.mark.parametrize("kind,enob", [(capi.KIND_SHORT_COMPLEX, 12), (capi.KIND_SHORT, 12), (capi.KIND_BYTE_COMPLEX, 8)],
+                         ids=["int16", "int16planar", "int8"])
+@pytest.mark.parametrize("n", [64, 256, 1024, 4096, 8192, 16384, 32768, 1000])
+def test_dc_quirk_negative_mean(torch_cuda, oracle_mod, n, kind, enob):
+    """utility.cpp:77-78: int32 /= uint32 turns a negative sum into a huge positive 'mean'.  Every kernel family must reproduce the
+    same (nonsensical) samples, hence the same spectrum and the same detections -- bit for bit wherever the spectrum tolerance
+    itself cannot move a bin across the threshold (tolerances.flip_unsafe)."""
+    nb = {64: 331, 256: 83, 1024: 41, 4096: 13, 8192: 11, 16384: 7, 32768: 5, 1000: 12}[n]
+    raw = _negative_sum_buffers(n, nb, kind, seed=4 + n)
+    o = oracle_mod.Oracle(n, FS, 1e9, kind=kind, enob=enob, correct_dc=True)
+    c = o.convert(raw[0].reshape(-1))
+    assert abs(c.real).min() > 30 and abs(c.imag).min() > 30         # the quirk is in play: a 'mean' of ~2^32 / n on both rails
+    assert abs(o.convert(raw[2].reshape(-1)).real).max() < 2          # ... and an ordinary buffer beside it
+    p_ref, _, _ = o.run(raw, threads=4)
+    ev = tol.evaluated_mask(n)
+    # (a quirk buffer is one huge constant: by the parity metric -- relative to max(bin, buffer mean) -- ALL its other bins are
+    #  within the tolerance of any threshold, so bit-exact records can only be demanded of the ordinary buffers beside them; the
+    #  threshold makes half of THEIR evaluated bins detections)
+    thr = float(np.median(p_ref[2::5][:, ev]))
+    fc = 88e6 + 6e6 * np.arange(nb)
+    (p, h, t), (p_ref, h_ref, t_ref) = _run_both(torch_cuda, oracle_mod, n, kind, raw, fc, None, thr, enob, True, max_hits=nb * n)
+    print(n, tol.compare_spectra(p, p_ref))
+    unsafe = tol.flip_unsafe(p_ref, thr)
+
+    def safe(a):
+        return a[~unsafe[a["seq_id"].astype(np.int64), (a["i"].astype(np.int64) + n // 2) % n]]
+
+    g, r = safe(h), safe(h_ref)
+    assert len(r) > len(p_ref[2::5]) * ev.sum() // 4 and len(h_ref) > len(r) and len(g) == len(r), (len(g), len(r), len(h), len(h_ref))
+    for f in ("seq_id", "i", "freq_hz"):
+        assert np.array_equal(g[f], r[f]), f
+    cnt = np.bincount(h_ref["seq_id"].astype(np.int64), minlength=nb)
+    trig_safe = (cnt + unsafe[:, ev].sum(axis=1) <= 1047) | (cnt - unsafe[:, ev].sum(axis=1) > 1047)
+    assert np.array_equal(t[trig_safe], t_ref[trig_safe])
+
+
+@pytest.mark.parametrize("kind,enob", [(capi.KIND_SHORT_COMPLEX, 12), (capi.KIND_SHORT, 12), (capi.KIND_BYTE_COMPLEX, 8)],
+                         ids=["int16", "int16planar", "int8"])
+@pytest.mark.parametrize("n", [8192, 1004])   # the streaming one-wave-per-buffer form, and the per-sample form (n not a multiple of 8)
+def test_dc_quirk_negative_mean_time_domain(torch_cuda, oracle_mod, n, kind, enob):
+    """the same quirk through the time-domain kernels' own DC reduction (process.cpp:203-237 behind utility.cpp:70-79)"""
+    nb = 40
+    raw = _negative_sum_buffers(n, nb, kind, seed=9 + n)
+    o = oracle_mod.Oracle(n, FS, 0.0, kind=kind, enob=enob, correct_dc=True)
+    flat = raw.reshape(nb, -1)
+    ref = [o.time_domain(o.convert(flat[b]), threshold=20.0) for b in range(nb)]
+    ref_max, ref_min = np.array([r[1] for r in ref], np.float32), np.array([r[2] for r in ref], np.float32)
+    ref_hit = np.array([r[0] for r in ref], np.uint8)
+    assert ref_max[0] > 22 and ref_max[2] < 10 and 0 < ref_hit.sum() < nb    # quirk buffers are ~2^32 / n in size, the others are not
+    with Plan(n, FS, 20.0, kind=kind, enob=enob, correct_dc=True, max_batch=64, mode=capi.MODE_TIME_DOMAIN) as plan:
+        plan.submit_device(0, _to_dev(torch_cuda, raw), nb, np.arange(nb) * 1e6)
+        mx, mn, ab = plan.collect_time_domain(0)
+    fin = np.isfinite(ref_min)
+    assert np.array_equal(np.isfinite(mn), fin)
+    assert np.abs(mx - ref_max).max() < 1e-4 and np.abs(mn[fin] - ref_min[fin]).max(initial=0) < 2e-3
+    assert np.array_equal(ab, ref_hit)
 
 
 # ---------------------------------------------------------------------------------------

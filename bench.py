@@ -502,7 +502,7 @@ def abi_bench_legs(n, nb, kind, threshold, steps, depth):
     if not os.path.exists(exe):
         return {"error": "scanner_amd/host/abi_bench has not been built (python -m scanner_amd.build)"}
     out = {}
-    for mode, d, ho in (("view", depth, 0), ("copy", depth, 0), ("view", 2, 0), ("counts", 2, 0), ("view", depth, 1), ("view", 4, 1)):
+    for mode, d, ho in (("view", depth, 0), ("copy", depth, 0), ("view", 2, 0), ("counts", 2, 0), ("view", depth, 1), ("view", 4, 1), ("landed", depth, 0), ("landed", 4, 1)):
         cmd = [exe, "--n", str(n), "--batch", str(nb), "--kind", kind, "--threshold", str(threshold), "--steps", str(steps),
                "--depth", str(d), "--mode", mode, "--hits-only", str(ho)]
         try:
@@ -535,6 +535,12 @@ def kernel_name(n, kind, hits=True, spectrum=True, dc=False, time_domain=False):
         return f"scn_fft16k2_kernel<{k}, {d}, {h}, {sp}>"
     if n in (1024, 2048, 4096):
         return f"scn_fft_kernel<{n // 256}, {k}, {d}, {h}, {sp}>"
+    import re
+
+    plans = open(os.path.join(ROOT, "scanner_amd", "csrc", "scn_mixed_plans.h")).read()
+    m = re.search(r"X\(%d, (\d+), (\d+), (\d+), (\d+), (\d+), \d+\)" % n, plans)
+    if m:  # a mixed-radix fused kernel (scn_mixed.hip); DC removal is a runtime branch there
+        return f"scn_fft_mixed_kernel<GeoMixed<{n}, {m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>, {k}, {h}, {sp}>"
     if n == 65536:
         return f"scn_big_cols_kernel<{k}, 65536, false> + scn_big_rows_kernel<{h}, {sp}> (four-step 256 x 256, scn_big.hip: the work buffer's round trip is not algorithmic traffic)"
     if n == 32768:
@@ -1132,7 +1138,7 @@ def main():
                     "value": v["value"], "unit": "Msamples/s", "steps": v["steps"], "ms_per_step": v["ms_per_step"],
                     "hits_per_step": v["hits_per_step"], "submits_in_flight": v["submits_in_flight"],
                     "path": "C++ consumer (scanner_amd/host/abi_bench, a child process on the system HIP runtime): scn_submit_device, "
-                            "scn_collect for counts + trigger flags, the ordered records read in place through scn_hits_view -- what "
+                            "scn_collect for counts + trigger flags, the ordered records read in place through scn_hits_view, EVERY record of every list -- what "
                             "ProcessSamples::ThreadWorker does (scanner_amd/host/process.cpp)",
                     "hip_runtime_version": v["hip_runtime_version"],
                     "two_in_flight": {"value": legs["view_depth2"]["value"], "ms_per_step": legs["view_depth2"]["ms_per_step"]},
@@ -1140,6 +1146,11 @@ def main():
                                                   "note": "the same loop with scn_collect copying the records into the caller's buffer (one core's memcpy "
                                                           "of ~1.6 MB out of pinned memory per step)"},
                     "counts_only_same_harness": {"value": legs["counts_depth2"]["value"], "ms_per_step": legs["counts_depth2"]["ms_per_step"]},
+                    # round 4's figures stopped the clock when the list had LANDED in pinned memory (first and last record touched); from
+                    # round 5 on `value` has the consumer read every record, as the reference's consumer formats every one
+                    "landed_only": {"value": legs[f"landed_depth{min(args.records_depth, 3)}"]["value"], "ms_per_step": legs[f"landed_depth{min(args.records_depth, 3)}"]["ms_per_step"],
+                                    "hits_only_plan_four_in_flight": legs["landed_depth4_hits_only"]["value"],
+                                    "note": "the same loops with only the first and the last record of each list read: when the DMA has landed, not when the consumer has read it"},
                     "hits_only_plan": {"value": legs[f"view_depth{min(args.records_depth, 3)}_hits_only"]["value"],
                                        "ms_per_step": legs[f"view_depth{min(args.records_depth, 3)}_hits_only"]["ms_per_step"],
                                        "submits_in_flight": legs[f"view_depth{min(args.records_depth, 3)}_hits_only"]["submits_in_flight"],

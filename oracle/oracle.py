@@ -189,6 +189,7 @@ def lib():
             C.POINTER(Params), C.c_int, u32, C.c_int, vp, u32, vp, vp, vp, vp, C.c_uint64, vp, u32]
         L.scn_oracle_welch.argtypes = [vp, u32, u32, u32, vp]
         L.scn_oracle_set_fft_mode.argtypes = [C.c_int]
+        L.scn_oracle_set_direct_dft.argtypes = [C.c_int]
         L.scn_oracle_get_fft_mode.restype = C.c_int
         L.scn_oracle_hackrf_interpolate.restype = C.c_double
         L.scn_oracle_hackrf_interpolate.argtypes = [vp, u32, u32, C.POINTER(u32)]
@@ -301,6 +302,12 @@ def frequency_table(sample_rate, start, stop, use_bandwidth=0.75, dc_ignore_widt
     out = np.empty(cnt, np.float64)
     L.scn_oracle_frequency_table(sample_rate, start, stop, use_bandwidth, dc_ignore_width, _p(out), cnt)
     return out
+
+
+def set_direct_dft(direct):
+    """Lengths that are not powers of two: False (default) = the DFT sum factored over the prime factors of n, in double;
+    True = the sum as written, O(n^2), in double.  Applies to Oracle objects created afterwards."""
+    lib().scn_oracle_set_direct_dft(1 if direct else 0)
 
 
 def set_fft_mode(accurate):

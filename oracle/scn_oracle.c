@@ -140,7 +140,8 @@ void scn_oracle_window_apply(float *s, const float *w, uint32_t n) {
  * same definition (sign -1, unnormalised, natural order). */
 struct scn_oracle_fft {
   uint32_t n, log2n;
-  int direct;      /* n is not a power of two: the DFT sum itself, in double (FFTW plans any n, fft.cpp:4-11) */
+  int direct;      /* n is not a power of two (FFTW plans any n, fft.cpp:4-11): 1 = the DFT sum itself, O(n^2), in double;
+                      2 = the same sum factored over n's prime factors (recursive decimation in time, any radix), in double */
   float *in, *out; /* fftwIn / fftwOut of fft.h:14-15 */
   float *tw;       /* n/2 complex twiddles */
   double *twd;     /* the same in double, and a double work array, for the accurate mode */
@@ -159,6 +160,11 @@ struct scn_oracle_fft {
 static int g_fft_accurate = 1;
 void scn_oracle_set_fft_mode(int accurate) { g_fft_accurate = accurate ? 1 : 0; }
 int scn_oracle_get_fft_mode(void) { return g_fft_accurate; }
+/* Lengths that are not powers of two: by default the DFT sum factored over the prime factors of n (O(n * sum of the factors):
+ * a 12000-point buffer costs what 25 radix passes cost, not 1.4e8 multiply-adds); with direct = 1 plans created from then on
+ * evaluate the sum as written, O(n^2) -- the two are held against each other in tests/test_oracle.py. */
+static int g_direct_dft = 0;
+void scn_oracle_set_direct_dft(int direct) { g_direct_dft = direct ? 1 : 0; }
 
 scn_oracle_fft *scn_oracle_fft_create(uint32_t n) {
   if (n < 2) return NULL;
@@ -168,10 +174,11 @@ scn_oracle_fft *scn_oracle_fft_create(uint32_t n) {
   while ((1u << f->log2n) < n) f->log2n++;
   if ((n & (n - 1)) != 0) { /* any other length: Y[k] = sum_j X[j] exp(-2 pi i j k / n) evaluated as written, O(n^2), in
                                double with one rounding to float -- small sizes in the tests only */
-    f->direct = 1;
+    f->direct = g_direct_dft ? 1 : 2;
     f->in = (float *)malloc(sizeof(float) * 2 * n);
     f->out = (float *)malloc(sizeof(float) * 2 * n);
     f->twd = (double *)malloc(sizeof(double) * 2 * n);
+    f->work = (double *)malloc(sizeof(double) * 2 * n * 2); /* input and output of the factored form, in double */
     const double pi_ = 3.14159265358979323846;
     for (uint32_t k = 0; k < n; k++) {
       double a = -2.0 * pi_ * (double)k / (double)n;
@@ -259,7 +266,51 @@ static void fft_execute_direct(scn_oracle_fft *f) {
   }
 }
 
+/* out[0 .. n) = DFT_n of in[0], in[stride], in[2 stride], ... : n = p m with p the smallest prime factor of n; the p
+ * sub-transforms of length m over the samples r, r + p, r + 2 p, ... first, then X[k + q m] = sum_r Y_r[k] W_n^(r (k + q m)).
+ * tw holds W_N^e for the top-level N; W_n^e = W_N^(e N / n). */
+static void fft_factored(const double *in, double *out, uint32_t n, uint32_t stride, const double *tw, uint32_t N) {
+  if (n == 1) {
+    out[0] = in[0];
+    out[1] = in[1];
+    return;
+  }
+  uint32_t p = 2;
+  while (n % p) p++; /* (n prime: p = n, m = 1 -- the plain sum) */
+  const uint32_t m = n / p, scale = N / n;
+  for (uint32_t r = 0; r < p; r++) fft_factored(in + 2 * (size_t)r * stride, out + 2 * (size_t)r * m, m, stride * p, tw, N);
+  double *t = (double *)malloc(sizeof(double) * 2 * p);
+  for (uint32_t k = 0; k < m; k++) {
+    for (uint32_t r = 0; r < p; r++) {
+      t[2 * r] = out[2 * ((size_t)r * m + k)];
+      t[2 * r + 1] = out[2 * ((size_t)r * m + k) + 1];
+    }
+    for (uint32_t q = 0; q < p; q++) {
+      double sr = 0.0, si = 0.0;
+      const uint32_t kk = k + q * m;
+      uint32_t e = 0; /* (r * kk) mod n, stepped */
+      for (uint32_t r = 0; r < p; r++) {
+        const double wr = tw[2 * (size_t)e * scale], wi = tw[2 * (size_t)e * scale + 1];
+        sr += t[2 * r] * wr - t[2 * r + 1] * wi;
+        si += t[2 * r] * wi + t[2 * r + 1] * wr;
+        e += kk;
+        if (e >= n) e -= n;
+      }
+      out[2 * (size_t)kk] = sr;
+      out[2 * (size_t)kk + 1] = si;
+    }
+  }
+  free(t);
+}
+
 static void fft_execute(scn_oracle_fft *f) {
+  if (f->direct == 2) {
+    double *in = f->work, *out = f->work + 2 * (size_t)f->n;
+    for (uint32_t i = 0; i < 2 * f->n; i++) in[i] = (double)f->in[i];
+    fft_factored(in, out, f->n, 1, f->twd, f->n);
+    for (uint32_t i = 0; i < 2 * f->n; i++) f->out[i] = (float)out[i];
+    return;
+  }
   if (f->direct) {
     fft_execute_direct(f);
     return;

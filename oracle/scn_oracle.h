@@ -90,6 +90,9 @@ void scn_oracle_fft_destroy(scn_oracle_fft *f);
  * the stand-in for FFTW's accuracy class that parity is judged against; 0 a textbook radix-2 FFT in float
  * (what bench.py's cpu_baseline times, and a second opinion in the tests).  See scn_oracle.c. */
 void scn_oracle_set_fft_mode(int accurate);
+/* lengths that are not powers of two: 0 (default) = the DFT sum factored over n's prime factors, 1 = the sum as written, O(n^2);
+ * applies to plans created afterwards */
+void scn_oracle_set_direct_dft(int direct);
 int scn_oracle_get_fft_mode(void);
 /* memcpy in -> execute -> memcpy out, as fft.cpp:22-24 */
 void scn_oracle_fft_process(scn_oracle_fft *f, float *dest, const float *src);

@@ -11,10 +11,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libscanner_hip.so")
-SOURCES = ["scn_kernels.hip", "scn_generic.hip", "scn_big.hip", "scn_hits.hip", "scn_welch.hip", "scn_gather.hip", "scn_api.hip"]
-HEADERS = ["scn_kernels.h", "scn_device.h", os.path.join("..", "..", "include", "scanner_hip.h")]
+SOURCES = ["scn_kernels.hip", "scn_mixed.hip", "scn_generic.hip", "scn_big.hip", "scn_hits.hip", "scn_welch.hip", "scn_gather.hip", "scn_api.hip"]
+HEADERS = ["scn_kernels.h", "scn_device.h", "scn_mixed_dft.h", "scn_mixed_plans.h", "scn_gather_protocol.h", os.path.join("..", "..", "include", "scanner_hip.h")]
 ARCH = "gfx950"
-KERNEL_TUS = 8  # scn_kernels.hip is compiled once per SCN_TU value (its SCN_TU_COUNT): one group of fused sizes each, side by side
+# files compiled once per value of a macro, side by side, each translation unit instantiating one group of sizes
+SPLIT = {"scn_kernels.hip": ("SCN_TU", 8), "scn_mixed.hip": ("SCN_MIXED_TU", 4)}
 
 
 def hipcc():
@@ -58,8 +59,8 @@ def build(force=False, verbose=False, defines=(), out=None):
     built_from = source_hash()
     objs, cmds = [], []
     tag = "" if not out else "." + os.path.basename(out).replace(".so", "")
-    units = [(src, None) for src in SOURCES if src != "scn_kernels.hip"] + [("scn_kernels.hip", tu) for tu in range(KERNEL_TUS)]
-    for src, tu in sorted(units, key=lambda u: u[1] is None):  # the fused-kernel units first: the 8192- / 16384-point ones take longest
+    units = [(src, None) for src in SOURCES if src not in SPLIT] + [(src, tu) for src, (_, count) in SPLIT.items() for tu in range(count)]
+    for src, tu in sorted(units, key=lambda u: u[1] is None):  # the fused-kernel units first: they take longest
         suffix = tag + ("" if tu is None else f".tu{tu}") + ".o"
         obj = os.path.join(os.path.dirname(out) if out else CSRC, src.replace(".hip", suffix))  # variants keep their objects beside them
         # -fno-slp-vectorize: keep the FFT butterflies as scalar f32 ops.  On gfx950 a packed
@@ -67,7 +68,7 @@ def build(force=False, verbose=False, defines=(), out=None):
         # needs ~180 extra v_mov/v_pk_mov per FFT to pair registers (measured: 801 vs 668 VALU
         # instructions in the loop body).
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
-               "-fno-slp-vectorize", *[f"-D{d}" for d in defines], *([] if tu is None else [f"-DSCN_TU={tu}"]),
+               "-fno-slp-vectorize", *[f"-D{d}" for d in defines], *([] if tu is None else [f"-D{SPLIT[src][0]}={tu}"]),
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -131,6 +131,7 @@ struct scn_plan {
   // kernel stores each count to pinned host memory as well (one 4-byte PCIe write per buffer; costs a 4096-point launch
   // ~4 us of completion latency, measured in round 1, and the 8192-point ones less than the late copy did).
   bool direct_counts = false;
+  bool mixed = false;    // a fused kernel of scn_mixed.hip: the sizes 2^a 3^b 5^c of scn_mixed_plans.h
   bool generic = false;  // no fused kernel for this size: the staged path of scn_generic.hip
   bool big = false;      // 65536 / 32768 points: the four-step pair of scn_big.hip
   uint32_t fft_m = 0, log2m = 0;     // ... and its transform length: n for a power of two, >= 2n - 1 for Bluestein
@@ -485,11 +486,13 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     ga.hit_region = p->hit_region;
     ga.per_buffer_hits = a.per_buffer_hits;
     SCN_HIP(scn_launch_generic((int)p->d.sample_kind, p->d.correct_dc != 0, hits, ga, p->num_cus, s.stream));
+  } else if (p->mixed) {
+    SCN_HIP(scn_launch_mixed(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, d_power != nullptr, a, p->num_cus, s.stream, in_packet ? after : nullptr));
   } else {
     // (a hits-only plan handed a caller's spectrum destination runs the full kernel)
     SCN_HIP(scn_launch_fft(n, (int)p->d.sample_kind, p->d.correct_dc != 0, hits, d_power != nullptr, a, p->num_cus, s.stream, in_packet ? after : nullptr));
   }
-  if (!p->generic && !p->big && scn_uses_queue((int)p->d.sample_kind, p->d.n))
+  if (!p->generic && !p->big && !p->mixed && scn_uses_queue((int)p->d.sample_kind, p->d.n))
     for (uint32_t x = 0; x < 8; x++) s.work_base[x] += scn_work_shard_count(nb, x);  // what this launch adds (wrapping, like the device side)
   if (hits && nb) {
     if (after && !in_packet) SCN_HIP(hipEventRecord(after, s.stream));
@@ -573,7 +576,7 @@ int scn_device_count(int *count) {
 
 int scn_size_path(uint32_t n, uint32_t *path) {
   if (!path) return fail(SCN_E_INVALID, "null argument");
-  *path = scn_fft_size_supported(n) ? SCN_PATH_FUSED
+  *path = (scn_fft_size_supported(n) || scn_mixed_size_supported(n)) ? SCN_PATH_FUSED
           : scn_big_size_supported(n) ? SCN_PATH_FOUR_STEP
           : scn_generic_size_supported(n) ? SCN_PATH_STAGED
           : scn_bluestein_size_supported(n) ? SCN_PATH_BLUESTEIN
@@ -604,7 +607,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
   if (d.mode != SCN_MODE_FREQUENCY_DOMAIN && d.mode != SCN_MODE_TIME_DOMAIN)
     return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
-  if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !scn_generic_size_supported(d.n) &&
+  if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !scn_mixed_size_supported(d.n) && !scn_generic_size_supported(d.n) &&
       !scn_bluestein_size_supported(d.n))
     return fail(SCN_E_INVALID, "unsupported FFT size %u (16 to 65536)", d.n);
   if (d.n == 0 || d.n > (1u << 24)) return fail(SCN_E_INVALID, "bad sample count %u", d.n);
@@ -645,7 +648,8 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     SCN_TRY(hipGetDeviceProperties(&prop, d.device_id));
     p->num_cus = prop.multiProcessorCount;
     p->big = d.mode == SCN_MODE_FREQUENCY_DOMAIN && scn_big_size_supported(d.n);
-    p->generic = d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !p->big;
+    p->mixed = d.mode == SCN_MODE_FREQUENCY_DOMAIN && scn_mixed_size_supported(d.n);  // a fused kernel of scn_mixed.hip (2^a 3^b 5^c)
+    p->generic = d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !p->big && !p->mixed;
     p->direct_counts = d.n >= 8192 && !p->generic && !p->big;  // (the fused kernels from 8192 points up store the counts to pinned memory themselves)
     SCN_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     SCN_TRY(hipStreamCreateWithFlags(&p->h2d_stream, hipStreamNonBlocking));
@@ -737,11 +741,12 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
     }
     // the same values, regrouped per thread of the fused kernel: entry (p-1, t) = W_n^(t p), t < n/16
     uint32_t tw1_rows = 15, nthreads = 1;  // (only the fused kernels read it)
-    if (!p->generic && !p->big) scn_tw1_layout(d.n, &tw1_rows, &nthreads);
+    if (p->mixed) scn_mixed_layout(d.n, &tw1_rows, &nthreads);
+    else if (!p->generic && !p->big) scn_tw1_layout(d.n, &tw1_rows, &nthreads);
     std::vector<float> tw1(2 * (size_t)tw1_rows * nthreads);
     for (uint32_t pp = 1; pp <= tw1_rows; pp++)
       for (uint32_t t = 0; t < nthreads; t++) {
-        const uint32_t m = (t * pp) & (tn - 1);
+        const uint32_t m = (uint32_t)(((uint64_t)t * pp) % tn);
         tw1[2 * ((size_t)(pp - 1) * nthreads + t)] = tw[2 * m];
         tw1[2 * ((size_t)(pp - 1) * nthreads + t) + 1] = tw[2 * m + 1];
       }

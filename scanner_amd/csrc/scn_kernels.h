@@ -164,3 +164,10 @@ static inline float scn_hit_prefilter(float threshold) {
 }
 bool scn_fft_size_supported(uint32_t n);
 void scn_tw1_layout(uint32_t n, uint32_t *rows, uint32_t *threads);  // shape of ScnFftArgs::tw1_table for a fused size
+
+// The fused kernels for the sizes 2^a 3^b 5^c that are not powers of two (scn_mixed.hip, scn_mixed_plans.h): same arguments, same
+// outputs.  tw1_table: `rows` rows of `threads` entries, entry (p - 1, t) = W_n^(t p) (scn_mixed_layout); twiddle: W_n^m, m < n.
+bool scn_mixed_size_supported(uint32_t n);
+bool scn_mixed_layout(uint32_t n, uint32_t *rows, uint32_t *threads);
+hipError_t scn_launch_mixed(uint32_t n, int kind, bool correct_dc, bool hits, bool spectrum, const ScnFftArgs &args, int num_cus,
+                            hipStream_t stream, hipEvent_t stop = nullptr);

@@ -39,133 +39,8 @@
 #define SCN_IN_TU(x) (SCN_TU == -1 || SCN_TU == (x))
 #define SCN_TU_COUNT 8  // 0: 16 / 32 points, 1: 64 / 128, 2: 256 / 512, 3: 1024 / 2048, 4: 4096, 5: 8192, 6: 16384, 7: everything that is not a fused FFT kernel
 
-namespace {
-
-// ---- global memory access through buffer descriptors ---------------------------------
-// A raw buffer resource (SGPR descriptor, wave-uniform base) + one per-lane VGPR offset
-// + scalar/immediate offsets: the 16 strided accesses of a thread cost no address VGPRs.
-//
-// Cache-policy immediates of the buffer instructions on gfx950: bit0 = sc0, bit1 = nt, bit4 = sc1.
-// Both streams are touched exactly once, so both are non-temporal: measured with inputs AND outputs
-// rotated over 1.5 GiB (nothing can live in the 256 MiB Infinity Cache), a no-compute skeleton
-// of this kernel's traffic moves 5.66 TB/s with the default policy and 6.40 TB/s with nt on both
-// (scripts/membw.hip); the FFT kernel itself gains 4-5 %.
-constexpr int SCN_AUX_LD = 2;
-constexpr int SCN_AUX_ST = 2;
-
-template <int KIND>
-struct RawLoader;
-
-// float I,Q interleaved: 8 B per sample
-template <>
-struct RawLoader<SCN_K_FLOAT_COMPLEX> {
-  static constexpr uint32_t kBufBytes(uint32_t n) { return 8u * n; }
-  typedef v2f raw_t;
-  template <int AUX>
-  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
-    // (the builtin returns a GCC-style vector; bit_cast, never assign it to an ext_vector)
-    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, t * 8u, idx0 * 8u, AUX));
-  }
-  // two consecutive samples idx0 + 2t, idx0 + 2t + 1 in one 16-byte load (the wide 8192-point kernel's lane pairs)
-  template <int AUX>
-  static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {
-    typedef float v4f_t __attribute__((ext_vector_type(4)));
-    const v4f_t v = __builtin_bit_cast(v4f_t, __builtin_amdgcn_raw_buffer_load_b128(r, t * 16u, idx0 * 8u, AUX));
-    r0 = v2f{v.x, v.y};
-    r1 = v2f{v.z, v.w};
-  }
-  static __device__ __forceinline__ void ints(raw_t, int &re, int &im) { re = im = 0; }
-  static __device__ __forceinline__ cf conv(raw_t r, int, int, float) { return from_v2f(r); }
-};
-
-// int16 I,Q interleaved: 4 B per sample
-template <>
-struct RawLoader<SCN_K_SHORT_COMPLEX> {
-  static constexpr uint32_t kBufBytes(uint32_t n) { return 4u * n; }
-  typedef int raw_t;
-  template <int AUX>
-  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
-    return __builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, idx0 * 4u, AUX);
-  }
-  template <int AUX>
-  static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {
-    typedef int v2i_t __attribute__((ext_vector_type(2)));
-    const v2i_t v = __builtin_bit_cast(v2i_t, __builtin_amdgcn_raw_buffer_load_b64(r, t * 8u, idx0 * 4u, AUX));
-    r0 = v.x;
-    r1 = v.y;
-  }
-  static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
-    re = (int)(short)(r & 0xffff);
-    im = r >> 16;
-  }
-  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im, float scale) {
-    int re, im;
-    ints(r, re, im);
-    // float(source - dc) * onebymax, utility.cpp:81-82 (wrapping int arithmetic)
-    return cf{(float)(int)((uint32_t)re - (uint32_t)dc_re) * scale,
-              (float)(int)((uint32_t)im - (uint32_t)dc_im) * scale};
-  }
-};
-
-// int8 I,Q interleaved: 2 B per sample
-template <>
-struct RawLoader<SCN_K_BYTE_COMPLEX> {
-  static constexpr uint32_t kBufBytes(uint32_t n) { return 2u * n; }
-  typedef int raw_t;
-  template <int AUX>
-  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0) {
-    // (only bytes 0 and 1 of the register are ever read -- by the SDWA converts of conv() --, so the 16-bit load is taken as it
-    // comes: widening it in C++ costs a v_and_b32 per sample that buffer_load_ushort has already done)
-    int v;
-    const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, AUX);
-    asm("" : "=v"(v) : "0"(h));
-    return v;
-  }
-  template <int AUX>
-  static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {
-    const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, idx0 * 2u, AUX);
-    r0 = (int)(v & 0xffffu);
-    r1 = (int)(v >> 16);
-  }
-  static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
-    re = (int)(signed char)(r & 0xff);
-    im = (int)(signed char)((r >> 8) & 0xff);
-  }
-  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im, float scale) {
-    int re, im;
-    ints(r, re, im);
-    return cf{(float)(int)((uint32_t)re - (uint32_t)dc_re) * scale,
-              (float)(int)((uint32_t)im - (uint32_t)dc_im) * scale};
-  }
-};
-
-// int16 planar: I[n] then Q[n] per buffer; packed into the SHORT_COMPLEX register form
-template <>
-struct RawLoader<SCN_K_SHORT> {
-  static constexpr uint32_t kBufBytes(uint32_t n) { return 4u * n; }
-  typedef int raw_t;
-  template <int AUX>
-  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t n, uint32_t t, uint32_t idx0) {
-    int re = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, idx0 * 2u, AUX);
-    int im = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, t * 2u, (n + idx0) * 2u, AUX);
-    return (re & 0xffff) | (im << 16);
-  }
-  template <int AUX>
-  static __device__ __forceinline__ void load2(__amdgpu_buffer_rsrc_t r, uint32_t n, uint32_t t, uint32_t idx0, raw_t &r0, raw_t &r1) {
-    const uint32_t re = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, idx0 * 2u, AUX);        // I[2t], I[2t+1]
-    const uint32_t im = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, t * 4u, (n + idx0) * 2u, AUX);  // Q[2t], Q[2t+1]
-    r0 = (int)((re & 0xffffu) | (im << 16));
-    r1 = (int)((re >> 16) | (im & 0xffff0000u));
-  }
-  static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) {
-    RawLoader<SCN_K_SHORT_COMPLEX>::ints(r, re, im);
-  }
-  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im, float scale) {
-    return RawLoader<SCN_K_SHORT_COMPLEX>::conv(r, dc_re, dc_im, scale);
-  }
-};
-
-}  // namespace
+// (RawLoader<KIND>, the wire-format loaders of K1, and the cache policy of the two streams live in scn_device.h: the mixed-radix
+// kernels of scn_mixed.hip use them too)
 
 // ------------------------------------------------------------------------------------
 // Fused kernel for N = 256*M points, M in {4, 8, 16} (N = 1024 / 2048 / 4096).

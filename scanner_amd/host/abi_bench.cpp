@@ -10,7 +10,7 @@
 // (process.cpp:272-314); bench.py runs this program as a child and reports both.
 //
 //   abi_bench [--n 4096] [--batch 8192] [--kind cfloat|int16|int8] [--threshold 10] [--steps 300] [--warmup 50]
-//             [--depth 3] [--mode counts|copy|view] [--rotate 4] [--flags extra plan flags] [--lib libscanner_hip.so]
+//             [--depth 3] [--mode counts|copy|view|landed] [--rotate 4] [--flags extra plan flags] [--lib libscanner_hip.so]
 // prints one JSON line.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
@@ -100,7 +100,7 @@ int main(int argc, char **argv) {
       return 2;
     }
   }
-  if (depth < 1 || depth > SCN_NUM_SLOTS || rotate < 1 || (mode != "counts" && mode != "copy" && mode != "view")) {
+  if (depth < 1 || depth > SCN_NUM_SLOTS || rotate < 1 || (mode != "counts" && mode != "copy" && mode != "view" && mode != "landed")) {
     fprintf(stderr, "abi_bench: bad --depth / --rotate / --mode\n");
     return 2;
   }
@@ -237,15 +237,18 @@ int main(int argc, char **argv) {
     const double t0 = now();
     uint32_t nh = 0;
     int st = api.collect(plan, (int)s, nullptr, mode == "copy" ? rec.data() : nullptr, mode == "copy" ? (uint32_t)rec.size() : 0u, &nh, trig.data());
-    if (st == SCN_OK && mode == "view") {
+    if (st == SCN_OK && (mode == "view" || mode == "landed")) {
       if (!host_log.empty()) calls.push_back({'c', s, t0, now()});  // (scn_collect alone; the 'C' record is collect + view)
       const scn_hit *v = nullptr;
       uint32_t nv = 0;
       st = api.hits_view(plan, (int)s, &v, &nv);
       // the consumer READS every record (the reference formats each one, process.cpp:57): the whole pinned list is walked, as
       // the copy mode pays a full memcpy of it -- first and last record alone would time the DMA landing, not the read
-      if (st == SCN_OK)
+      // ("landed" touches the first and the last record only: the round-4 figure, when the list has arrived -- kept beside it)
+      if (st == SCN_OK && mode == "view")
         for (uint32_t k = 0; k < nv; k++) checksum += v[k].freq_hz + v[k].i;
+      else if (st == SCN_OK && nv)
+        checksum += v[0].freq_hz + v[nv - 1].freq_hz;
     } else if (st == SCN_OK && mode == "copy" && nh) {
       const size_t nc = std::min<size_t>(nh, rec.size());
       for (size_t k = 0; k < nc; k++) checksum += rec[k].freq_hz + rec[k].i;

@@ -44,7 +44,7 @@ ProcessSamples::ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_
     : m_writeData(false), m_sampleCount(numSamples), m_sampleRate(sampleRate), m_enob(enob), m_fileCounter(0),
       m_preTrigger(preTrigger), m_postTrigger(postTrigger), m_endSequenceId(0), m_writing(false), m_mode(mode),
       m_fileNameBase(fileNameBase), m_threshold(threshold), m_useBandWidth(useBandWidth), m_windowType(windowType),
-      m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_pipeDepth(3), m_firstDevice(0), m_hitCount(0),
+      m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_pipeDepth(4), m_firstDevice(0), m_hitCount(0),
       m_bufferCount(0), m_stagedWorkers(0), m_tWait(0), m_tSubmit(0), m_tCollect(0), m_tReport(0), m_failed(false) {
   (void)dcIgnoreWidth;  // the reference ignores it too and hard-codes 4 bins (process.cpp:86-88)
   assert(mode > Illegal && mode <= FrequencyDomain);  // process.cpp:99

@@ -44,7 +44,8 @@ class ProcessSamples {
   // knobs the reference hard-codes; set before StartProcessing
   void SetMaxBatch(uint32_t maxBatch) { m_maxBatch = maxBatch; }
   void SetDevice(int firstDevice) { m_firstDevice = firstDevice; }
-  // Submits a consumer thread keeps in flight (1 .. SCN_NUM_SLOTS, default 3).  Each slot in use holds its pinned staging
+  // Submits a consumer thread keeps in flight (1 .. SCN_NUM_SLOTS, default 4: a hits-only plan's 55 us kernel is shorter than what its record list needs on the D2H stream,
+  // so the fourth slot still pays -- 270 -> 326 Gsamples/s with every record read, profiles/r05_experiments.md).  Each slot in use holds its pinned staging
   // (max_batch buffers), two generations of hit regions (8 B x evaluated bins x max_batch each: 2 x 201 MB for a 8192 x
   // 4096-point batch) and its record lists: a host short of GPU memory trades depth for footprint here.
   void SetPipelineDepth(uint32_t depth) { m_pipeDepth = depth; }

@@ -218,7 +218,7 @@ std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t s
 
 int main() {
   bool ok = false;
-  // 1. a fast producer, a "GPU" that takes its time: the ring fills up (three submits in flight) and is drained oldest first
+  // 1. a fast producer, a "GPU" that takes its time: the ring fills up (four submits in flight) and is drained oldest first
   g_hitsPerBuffer = 2;
   g_failSubmitAt = -1;
   g_collectSleepUs = 2000;  // (long against the producer's microseconds per buffer also on a loaded test host)
@@ -227,7 +227,7 @@ int main() {
   for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
   CHECK(g_violations.empty());
   CHECK(got.size() > 50 && got == g_expected);
-  CHECK(g_maxInFlight == 3);  // kPipe of process.cpp
+  CHECK(g_maxInFlight == 4);  // kPipe of process.cpp (the default pipeline depth)
   const int fastSubmits = g_submits;
   // WHICH path ran (a refused attach used to fall back to the copying worker silently, and the staged path was
   // covered by timing luck): one zero-copy consumer, every append accounted for, and what was copied into a pooled message is
@@ -237,7 +237,7 @@ int main() {
   CHECK(g_copiedAppends == g_queuedAtAttach);
 
   // 1b. the start order the reference documents (Start, StartStreaming, then StartProcessing) with a plan that takes its time
-  //     to create: the producer has FILLED the queue (64 messages, more than the ring's 3 x 4 places) when the consumer
+  //     to create: the producer has FILLED the queue (64 messages, more than the ring's 4 x 4 places) when the consumer
   //     attaches.  Those come first, copied by the worker into slots reserved for it; everything after is written in place.
   g_planCreateSleepUs = 50000;
   got = run(256, 4, 64, 40, ok);

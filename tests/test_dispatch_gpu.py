@@ -24,6 +24,8 @@ FS = 8000000
 
 build.build()  # (collection needs scn_size_path; seconds when the library is current, and it needs no GPU)
 FUSED_SIZES = [1 << k for k in range(4, 17) if capi.size_path(1 << k) == capi.PATH_FUSED]
+# the mixed-radix fused kernels (scn_mixed.hip): every size the library runs fused that is not a power of two
+MIXED_SIZES = [n for n in range(17, 16384) if n & (n - 1) and capi.size_path(n) == capi.PATH_FUSED]
 FORMATS = [(capi.KIND_FLOAT_COMPLEX, 12, False)] + [(k, e, dc) for k, e in ((capi.KIND_SHORT_COMPLEX, 12), (capi.KIND_SHORT, 14),
                                                                              (capi.KIND_BYTE_COMPLEX, 8)) for dc in (False, True)]
 NAMES = {capi.KIND_FLOAT_COMPLEX: "cfloat", capi.KIND_SHORT_COMPLEX: "int16", capi.KIND_SHORT: "int16planar", capi.KIND_BYTE_COMPLEX: "int8"}
@@ -32,7 +34,8 @@ NAMES = {capi.KIND_FLOAT_COMPLEX: "cfloat", capi.KIND_SHORT_COMPLEX: "int16", ca
 def test_the_fused_sizes_are_the_documented_ones():
     assert FUSED_SIZES == [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
     assert capi.size_path(32768) == capi.size_path(65536) == capi.PATH_FOUR_STEP
-    assert capi.size_path(1000) == capi.size_path(17) == capi.size_path(65535) == capi.PATH_BLUESTEIN
+    assert MIXED_SIZES == [1000, 1200, 1500, 2000, 2400, 2500, 3000, 3600, 4000, 4800, 5000, 6000, 7200, 8000, 9000, 9600, 10000]
+    assert capi.size_path(1023) == capi.size_path(17) == capi.size_path(12000) == capi.size_path(65535) == capi.PATH_BLUESTEIN
     assert capi.size_path(8) == capi.size_path(65537) == capi.PATH_UNSUPPORTED
 
 
@@ -53,8 +56,13 @@ def _drop_guard_band(h, near, seq0, n):
     return h[~near[b, j]]
 
 
-@pytest.mark.parametrize("kind,enob,dc", FORMATS, ids=[f"{NAMES[k]}{'-dc' if dc else ''}" for k, _, dc in FORMATS])
-@pytest.mark.parametrize("n", FUSED_SIZES)
+# the mixed-radix sizes: every kernel of a size is (wire format) x (output mode) -- DC removal is a runtime branch there --, so four
+# formats per size reach all twelve (DC on for two of them); two sizes walk all seven combinations like the powers of two
+MIXED_FORMATS = [(capi.KIND_FLOAT_COMPLEX, 12, False), (capi.KIND_SHORT_COMPLEX, 12, True), (capi.KIND_SHORT, 14, False), (capi.KIND_BYTE_COMPLEX, 8, True)]
+CASES = [(n, *f) for n in FUSED_SIZES for f in FORMATS] + [(n, *f) for n in MIXED_SIZES for f in (FORMATS if n in (1000, 6000) else MIXED_FORMATS)]
+
+
+@pytest.mark.parametrize("n,kind,enob,dc", CASES, ids=[f"{n}-{NAMES[k]}{'-dc' if dc else ''}" for n, k, _, dc in CASES])
 def test_every_fused_specialisation_vs_oracle(built_lib, oracle_mod, n, kind, enob, dc):
     import torch
 

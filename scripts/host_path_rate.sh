@@ -4,7 +4,7 @@
 # scn_hits_view -> stdout (/dev/null).  Each configuration runs twice, N and 3N sweeps: the difference is the steady-state
 # rate (plan creation, pinning the slots and the discarded warm-up sweep are in both runs).
 cd "$GRAFT_REPO_ROOT/scanner_amd/host"
-run() { ./scan_synth "$@" --replay 64 --sigma 0.05 --threshold 30 --start 0 > /dev/null 2> /tmp/err.txt; grep -E "^seconds|^buffers|^producer" /tmp/err.txt; }
+run() { ./scan_synth "$@" --replay 64 --sigma 0.05 --threshold 30 --start 0 > /dev/null 2> /tmp/err.txt; grep -E "^seconds|^buffers|^producer|^staging" /tmp/err.txt; }
 pair() { n=$1; it=$2; shift 2
   a=$(run --n $n "$@" --niterations $it); b=$(run --n $n "$@" --niterations $((3 * it)))
   python3 - "$n" "$a" "$b" "$*" <<'PY'
@@ -15,6 +15,10 @@ f = lambda s: (int(re.search(r"buffers (\d+)", s).group(1)), float(re.search(r"s
 print(f"== --n {n} {what}: {ba} buffers in {ta:.3f} s, {bb} in {tb:.3f} s -> steady state {(bb - ba) * n / (tb - ta) / 1e6:.0f} Msamples/s "
       f"({(tb - ta) / (bb - ba) * 1e6:.2f} us per buffer); whole run {bb * n / tb / 1e6:.0f}")
 print("   " + [l for l in b.splitlines() if l.startswith("producer")][0])
+st = [l for l in b.splitlines() if l.startswith("staging")][0]
+print("   " + st)   # WHICH path ran: a silent fall-back to the copying worker is a different measurement
+if "--threads 1" in what:
+    assert st.startswith("staging: 1 of 1"), "one consumer must run the zero-copy path"
 PY
 }
 pair 8192 150 --kind short_complex --enob 12 --stop 24576e6 --batch 2048 --depth 8192 --threads 1

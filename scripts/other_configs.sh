@@ -17,6 +17,7 @@ run --n 4096 --batch 8192 --kind int16
 run --n 4096 --batch 8192 --kind int8
 run --n 4096 --batch 2048
 run --config c4
+run --config c4 --centres 2048 --sweeps-per-launch 1   # the C4 per-GPU share at 8 GPUs, a launch per sweep (overlapped slots, three in flight)
 run --n 8192 --batch 4096 --kind int8               # the reference's defaults: --count 8192 on a HackRF (int8)
 run --n 16384 --batch 2048
 run --n 16384 --batch 2048 --kind int16
@@ -30,7 +31,18 @@ run --n 32768 --batch 1024 --kind int16 --steps 200 --warmup 20
 run --n 128 --batch 262144                          # eight threads per buffer (scn_fft_tiny_kernel)
 run --n 64 --batch 262144
 run --n 16 --batch 524288                           # one thread per buffer
-run --n 1000 --batch 4096 --steps 20 --warmup 3      # Bluestein
+run --n 1000 --batch 32768                           # the mixed-radix fused kernels (scn_mixed.hip)
+run --n 1000 --batch 32768 --kind int16
+run --n 3000 --batch 11184
+run --n 5000 --batch 6710
+run --n 6000 --batch 5592
+run --n 6000 --batch 5592 --kind int16
+run --n 10000 --batch 3355
+run --n 8192 --batch 4096 --kind int16 --plan-mode hits    # what ProcessSamples::ThreadWorker's plans run at the reference's defaults
+run --n 8192 --batch 4096 --kind int8 --plan-mode hits
+run --n 8192 --batch 4096 --kind int16 --time-domain       # the CLI's default mode (scan.cpp:87)
+run --n 1023 --batch 4096 --steps 20 --warmup 3      # Bluestein (a size without a fused kernel)
+run --n 12000 --batch 2796 --steps 20 --warmup 3     # Bluestein: 5-smooth, but beyond the mixed-radix kernels' 10000
 run --welch --welch-psd 32 --steps 100 --warmup 10
 run --welch --welch-psd 8 --welch-pinned --steps 20 --warmup 3
 python3 - <<PY

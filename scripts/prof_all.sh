@@ -28,6 +28,9 @@ if [ -n "$SCN_PROF_MORE" ]; then   # the other wire formats and sizes (not BASEL
   bash scripts/prof.sh ${TAG}_n128cfloat --n 128 --batch 262144 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n64cfloat --n 64 --batch 262144 > /dev/null 2>&1
   bash scripts/prof.sh ${TAG}_n16cfloat --n 16 --batch 524288 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n1000cfloat --n 1000 --batch 32768 > /dev/null 2>&1      # the mixed-radix fused kernels (scn_mixed.hip)
+  bash scripts/prof.sh ${TAG}_n6000int16 --n 6000 --batch 5592 --kind int16 > /dev/null 2>&1
+  bash scripts/prof.sh ${TAG}_n10000cfloat --n 10000 --batch 3355 > /dev/null 2>&1
   SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n65536cfloat --n 65536 --batch 512 > /dev/null 2>&1
   SCN_PROF_KERNEL=scn_big bash scripts/prof.sh ${TAG}_n32768cfloat --n 32768 --batch 1024 > /dev/null 2>&1
 fi

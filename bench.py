@@ -722,7 +722,8 @@ def main():
         fast = S == 1 and not want_records and not td
         if fast:
             vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-            prep = [[(C.c_void_p(raws[r][lo:hi].data_ptr()), hi - lo, vp(fc[lo:hi]), vp(seq[lo:hi]),
+            # (ids that are simply the buffers' indices in the launch are not passed at all: the compaction kernel numbers them itself)
+            prep = [[(C.c_void_p(raws[r][lo:hi].data_ptr()), hi - lo, vp(fc[lo:hi]), None if (first == 0 and lo == 0) else vp(seq[lo:hi]),
                       C.c_void_p(outs[r][lo:hi].data_ptr()) if spectrum else None) for lo, hi in chunks] for r in range(R)]
             state["keep"] = [fc, seq]
 
@@ -780,7 +781,7 @@ def main():
                 state["launch"] += 1
                 if pending[s]:
                     collect(s)
-                pl.submit_device(s, raws[k % R][lo:hi], hi - lo, fc[lo:hi], seq[lo:hi], sync_producer=False,
+                pl.submit_device(s, raws[k % R][lo:hi], hi - lo, fc[lo:hi], None if (first == 0 and lo == 0) else seq[lo:hi], sync_producer=False,
                                  d_power_db=outs[k % R][lo:hi] if spectrum else None)
                 pending[s] = True
 

@@ -95,6 +95,7 @@ struct Slot {
   uint32_t prefetched = 0;          // leading records of the current list that are (being) copied to h_list
   hipEvent_t list_done[2] = {nullptr, nullptr};  // per generation: scan + compaction (+ prefetch) finished
   bool list_used[2] = {false, false};            // ... and whether that event has ever been recorded
+  bool seq_given[2] = {false, false};            // per generation: the submit came with sequence ids (else: the buffer's index)
   bool list_valid = false;          // regions, counts and offsets of the last collected submit are still on the device
   bool list_built = false;          // the scan + compaction of the pending / last submit have been enqueued
   uint32_t total_hits = 0;          // of the last collected submit
@@ -273,7 +274,7 @@ ScnCompactArgs compact_args(const scn_plan *p, const Slot &s, uint32_t first, ui
   c.counts = s.d_buf_hits[s.gen];
   c.offsets = s.d_offsets;
   c.center_freq = static_cast<const double *>(s.h_meta) + (size_t)2u * p->d.max_batch * s.gen;
-  c.seq_id = reinterpret_cast<const uint64_t *>(c.center_freq + p->d.max_batch);
+  c.seq_id = s.seq_given[s.gen] ? reinterpret_cast<const uint64_t *>(c.center_freq + p->d.max_batch) : nullptr;
   c.out = out;
   c.first = first;
   c.out_cap = std::min<uint32_t>(cap, 0x7fffffffu - first);  // first + out_cap must not wrap
@@ -388,7 +389,10 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     double *h_fc = static_cast<double *>(s.h_meta) + (size_t)2u * p->d.max_batch * s.gen;
     uint64_t *h_seq = reinterpret_cast<uint64_t *>(h_fc + p->d.max_batch);
     memcpy(h_fc, fc, sizeof(double) * nb);
-    for (uint32_t b = 0; b < nb; b++) h_seq[b] = seq ? seq[b] : (uint64_t)b;
+    // sequence ids: copied when given; otherwise a buffer's id is its index and the compaction kernel computes it -- 8 of the
+    // 16 header bytes per buffer that made the 16 .. 128-point steps host-bound (524288 buffers per launch: 4 MB less to write)
+    s.seq_given[s.gen] = seq != nullptr;
+    if (seq) memcpy(h_seq, seq, sizeof(uint64_t) * nb);
   }
 
   ScnFftArgs a;

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void scn_hit_compact_kernel(ScnCompactArgs a) 
     const uint32_t o0 = a.offsets[b], o1 = a.offsets[b + 1u];
     const ScnDevHit first64 = region[lane < a.hit_region ? lane : 0u];
     const double fc = a.center_freq[b];
-    const uint64_t seq = a.seq_id[b];
+    const uint64_t seq = a.seq_id ? a.seq_id[b] : (uint64_t)b;  // (no ids given at submit: a buffer's id is its index, messageQueue.h:86 from zero)
     const uint32_t c = o1 - o0;
     if (c == 0 || o0 >= last || o1 <= a.first) continue;  // no hits, or nothing of this buffer inside the window
     const uint32_t stored = c < a.hit_region ? c : a.hit_region;

@@ -227,7 +227,7 @@ int main() {
   for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
   CHECK(g_violations.empty());
   CHECK(got.size() > 50 && got == g_expected);
-  CHECK(g_maxInFlight == 4);  // kPipe of process.cpp (the default pipeline depth)
+  CHECK(g_maxInFlight >= 2 && g_maxInFlight <= 4);  // never beyond kPipe of process.cpp (the default pipeline depth); how full the ring gets here depends on the producer's pace
   const int fastSubmits = g_submits;
   // WHICH path ran (a refused attach used to fall back to the copying worker silently, and the staged path was
   // covered by timing luck): one zero-copy consumer, every append accounted for, and what was copied into a pooled message is
@@ -249,6 +249,7 @@ int main() {
   fprintf(stderr, "1b: staged workers %u, queued at attach %lu, copied %lu, staged %lu, buffers %lu\n", g_stagedWorkers, (unsigned long)g_queuedAtAttach,
           (unsigned long)g_copiedAppends, (unsigned long)g_stagedAppends, (unsigned long)g_buffers);
   CHECK(g_stagedWorkers == 1 && g_queuedAtAttach == 64 && g_copiedAppends == 64);
+  CHECK(g_maxInFlight == 4);  // a full queue at the start fills the whole ring whatever the producer's pace: the default pipeline depth
   CHECK(g_stagedAppends + g_copiedAppends == g_buffers && g_stagedAppends > 0);
 
   // 2. a slow producer (long buffers), an instant "GPU": the queue runs empty between batches, every batch is reported at once

@@ -7,8 +7,8 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-BENCH_ARGS="--steps 500 --warmup 5 --no-cpu-baseline --no-overlap-leg --no-records-leg --no-hits-only-leg --no-copy-ref $*"   # the contract leg only: overlapped kernels have inflated begin-to-end times
-PMC_ARGS="--steps 50 --warmup 5 --settle 0 --no-cpu-baseline --no-overlap-leg --no-records-leg --no-hits-only-leg --no-copy-ref $*"   # counters serialise the launches: a short run is enough
+BENCH_ARGS="--steps 500 --warmup 5 --no-cpu-baseline --no-overlap-leg --no-records-leg --no-hits-only-leg --no-copy-ref --no-configs-leg $*"   # the contract leg only: overlapped kernels have inflated begin-to-end times
+PMC_ARGS="--steps 50 --warmup 5 --settle 0 --no-cpu-baseline --no-overlap-leg --no-records-leg --no-hits-only-leg --no-copy-ref --no-configs-leg $*"   # counters serialise the launches: a short run is enough
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.log"
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
             "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS" \

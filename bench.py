@@ -541,6 +541,9 @@ def kernel_name(n, kind, hits=True, spectrum=True, dc=False, time_domain=False):
     m = re.search(r"X\(%d, (\d+), (\d+), (\d+), (\d+), (\d+), \d+\)" % n, plans)
     if m:  # a mixed-radix fused kernel (scn_mixed.hip); DC removal is a runtime branch there
         return f"scn_fft_mixed_kernel<GeoMixed<{n}, {m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>, {k}, {h}, {sp}>"
+    m = re.search(r"X\(%d, (\d+), (\d+), (\d+), (\d+), \d+\)" % n, plans)
+    if m:  # ... beyond 10000 points: two virtual threads per thread, one in-place exchange
+        return f"scn_fft_mixed_big_kernel<GeoMixedBig<{n}, {m.group(1)}, {m.group(2)}, {m.group(3)}, {m.group(4)}>, {k}, {h}, {sp}>"
     if n == 65536:
         return f"scn_big_cols_kernel<{k}, 65536, false> + scn_big_rows_kernel<{h}, {sp}> (four-step 256 x 256, scn_big.hip: the work buffer's round trip is not algorithmic traffic)"
     if n == 32768:

@@ -1088,192 +1088,6 @@ __global__ __launch_bounds__(256, 2) void scn_fft8k_kernel(ScnFftArgs args) {
   scn_fft8k_body<KIND, DC, HITS, SPEC>(args);
 }
 
-#ifdef SCN_VAR_PAIR8K
-// ------------------------------------------------------------------------------------
-// EXPERIMENT (scripts/build_variants.py pair8k=SCN_VAR_PAIR8K): 8192 points as a PAIR of 4096-point
-// transforms -- even and odd samples through the 16 x 16 x 16 passes of scn_fft_kernel<16> one after the other, then ONE radix-2
-// level in registers: X[k] = E[k] + W_8192^k O[k], X[k + 4096] = E[k] - W_8192^k O[k], W_8192^(t + 256 r) = W_8192^t W_32^r.
-// 256 threads, 36.9 KiB of LDS: three workgroups per CU at <= 168 registers (the wide kernel: two, LDS-capped), no register
-// prefetch (the first transform's 16 outputs are held instead), eight barriers per buffer.  Integer formats only (a float
-// buffer's 32 raw samples per thread are 64 registers).
-// ------------------------------------------------------------------------------------
-#ifndef SCN_VAR_PAIR8K_WAVES
-#define SCN_VAR_PAIR8K_WAVES 3
-#endif
-template <int KIND, bool DC, bool HITS, bool SPEC>
-__global__ __launch_bounds__(256, SCN_VAR_PAIR8K_WAVES) void scn_fft8k_pair_kernel(ScnFftArgs args) {
-  static_assert(KIND != SCN_K_FLOAT_COMPLEX, "integer formats only");
-  constexpr int AUX_LD = SCN_AUX_LD;
-  constexpr int AUX_ST = SCN_AUX_ST;
-  constexpr uint32_t N = 8192, T = 256, P1 = 272, P2 = 257, EXCH = 16u * P1;
-  typedef RawLoader<KIND> L;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  v2f *lds = reinterpret_cast<v2f *>(smem_raw);
-  v2f *lds_tw2 = lds + EXCH;                              // [16][16]: W_256^(c q) at 16 q + c
-  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T);   // [16] DC-sum scratch
-  int *lds_hits = lds_cnt + 16;                          // [2]
-  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  const uint32_t p2 = t / 16u, c2 = t % 16u;
-
-  cf tw1[16];  // W_4096^(t p) = W_8192^(2 t p): row p - 1, entry 2 t of the plan's table (rows of 512)
-#pragma unroll
-  for (int p = 1; p < 16; p++) tw1[p] = from_v2f(args.tw1_table[(p - 1) * 512 + 2u * t]);
-  float win[32];  // win[2 a + e] = w[512 a + 2 t + e]
-#pragma unroll
-  for (int a = 0; a < 16; a++) {
-    win[2 * a] = args.window[512u * a + 2u * t] * args.scale;
-    win[2 * a + 1] = args.window[512u * a + 2u * t + 1u] * args.scale;
-  }
-  const cf wt = from_v2f(args.twiddle[t]);                       // W_8192^t
-  lds_tw2[t] = args.twiddle[(32u * p2 * c2) & (N - 1)];           // W_256^(c q) = W_8192^(32 c q), entry 16 q + c = t
-  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
-  __syncthreads();
-  v2f *w1 = lds + t, *r1 = lds + p2 * P1 + c2, *w2 = lds + c2 * P2 + p2, *r3 = lds + t;
-  const v2f *tw2 = lds_tw2 + c2;
-  const uint32_t st_voff = t * 4u;
-  uint32_t keepmask = 0;
-  if (HITS) {
-#pragma unroll
-    for (int r = 0; r < 32; r++) {
-      const uint32_t j = t + 256u * r, i = j ^ (N / 2);
-      const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
-      keepmask |= keep ? (1u << r) : 0u;
-    }
-  }
-  uint32_t par = 0, prev = 0xffffffffu;
-  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
-    typename L::raw_t raw[32];
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), L::kBufBytes(N));
-#pragma unroll
-    for (int a = 0; a < 16; a++) L::template load2<AUX_LD>(rc, N, t, 512u * a, raw[2 * a], raw[2 * a + 1]);
-    int dc_re = 0, dc_im = 0;
-    if (DC) {
-      int sr = 0, si = 0;
-#pragma unroll
-      for (int a = 0; a < 32; a++) {
-        int re, im;
-        L::ints(raw[a], re, im);
-        sr += re;
-        si += im;
-      }
-      sr = wave_sum(sr);
-      si = wave_sum(si);
-      if (lane == 0) {
-        lds_cnt[wave] = sr;
-        lds_cnt[8 + wave] = si;
-      }
-      __syncthreads();
-      sr = si = 0;
-#pragma unroll
-      for (uint32_t w = 0; w < 4; w++) {
-        sr += lds_cnt[w];
-        si += lds_cnt[8 + w];
-      }
-      dc_re = (int)((uint32_t)sr / N);
-      dc_im = (int)((uint32_t)si / N);
-    }
-    cf E[16];
-    cf v[16];
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-#pragma unroll
-      for (int a = 0; a < 16; a++) v[a] = L::conv(raw[2 * a + e], dc_re, dc_im, 1.0f) * win[2 * a + e];
-      fft16(v);
-#pragma unroll
-      for (int p = 0; p < 16; p++) {
-        cf y = v[OUT16(p)];
-        if (p) y = cmul(y, tw1[p]);
-        w1[p * P1] = to_v2f(y);
-      }
-      __syncthreads();
-      if (HITS && e == 0) {
-        if (t == 0 && prev != 0xffffffffu) {
-          args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
-          if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
-          lds_hits[par ^ 1] = 0;
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 16]);
-      fft16(v);
-#pragma unroll
-      for (int q = 1; q < 16; q++) v[OUT16(q)] = cmul(v[OUT16(q)], from_v2f(tw2[q * 16]));
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 16; q++) w2[q * 16] = to_v2f(v[OUT16(q)]);
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < 16; c++) v[c] = from_v2f(r3[c * P2]);
-      fft16(v);
-      __syncthreads();  // every pass-3 read done: the exchange area is free for the other half / the next buffer
-      if (e == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) E[r] = v[OUT16(r)];
-      }
-    }
-    // the combining level + K4, laid out like the wide kernel's pass 3: output r of this thread is bin j = t + 256 r
-    v32f pw;
-    float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db) ? 4u * N : 0u);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      cf w = wt;
-      if (r) {
-        const float cr = (float)__builtin_cos(6.283185307179586476925286766559 * r / 32.0);
-        const float sr = (float)__builtin_sin(6.283185307179586476925286766559 * r / 32.0);
-        w = cmul(wt, cf{cr, -sr});
-      }
-      const cf od = cmul(v[OUT16(r)], w);
-      const cf x0 = E[r] + od, x1 = E[r] - od;
-      const float p0 = power_of(x0), p1 = power_of(x1);
-      pw[r] = p0;
-      pw[r + 16] = p1;
-      gmax[r >> 3] = fmaxf(gmax[r >> 3], p0);
-      gmax[2 + (r >> 3)] = fmaxf(gmax[2 + (r >> 3)], p1);
-      if constexpr (SPEC) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p0)), rout, st_voff, 1024u * r, AUX_ST);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(p1)), rout, st_voff, 1024u * (r + 16), AUX_ST);
-      }
-    }
-    const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
-    if constexpr (SPEC) {
-      if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
-#pragma unroll
-            for (int r = 8 * g; r < 8 * g + 8; r++) {
-              const float q = pw[r];
-              if (__ballot(q >= SCN_P_EXACT_FROM)) {
-                const float d = db_exact(q);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 1024u * r, AUX_ST);
-              }
-            }
-          }
-        }
-      }
-    }
-    if (HITS) {
-      if (__ballot(pmax > args.p_lo))
-        scn_record_hits_lanes<32, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t { return (t + 256u * (uint32_t)r) ^ (N / 2); });
-      prev = buf;
-      par ^= 1;
-    }
-  }
-  if (HITS) {
-    __syncthreads();
-    if (t == 0 && prev != 0xffffffffu) {
-      args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
-      if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
-    }
-  }
-}
-struct GeoPair8k {
-  static constexpr uint32_t N = 8192, T = 256;
-  static constexpr uint32_t LDS_BYTES = 16u * 272u * 8u + 256u * 8u + 16u * 4u + 2u * 4u + 8u;
-  static constexpr uint32_t WG_PER_CU = SCN_VAR_PAIR8K_WAVES;
-};
-#endif
 
 // ------------------------------------------------------------------------------------
 // 16384 points as 32 x 16 x 32: 512 threads x 32 points, one workgroup per CU (scn_fft16k2_kernel).
@@ -1873,19 +1687,6 @@ struct Family8k {
     };
   };
 };
-#ifdef SCN_VAR_PAIR8K
-struct FamilyPair8k {
-  typedef GeoPair8k G;
-  static constexpr uint32_t THREADS = 256, SLOTS = 1;
-  template <int KIND>
-  struct K {
-    template <bool DC, bool HITS, bool SPEC>
-    struct T {
-      static constexpr void (*fn)(ScnFftArgs) = scn_fft8k_pair_kernel<KIND, DC, HITS, SPEC>;
-    };
-  };
-};
-#endif
 struct Family16k {
   typedef Geo16k2 G;
   static constexpr uint32_t THREADS = G::T, SLOTS = 1;
@@ -1959,18 +1760,7 @@ hipError_t scn_launch_fft_tu3(uint32_t n, SCN_FFT_LAUNCH_ARGS) {
 hipError_t scn_launch_fft_tu4(uint32_t, SCN_FFT_LAUNCH_ARGS) { return launch_family<NarrowFamily<16>>(SCN_FFT_LAUNCH_PASS); }
 #endif
 #if SCN_IN_TU(5)
-#ifdef SCN_VAR_PAIR8K
-hipError_t scn_launch_fft_tu5(uint32_t, SCN_FFT_LAUNCH_ARGS) {
-  switch (kind) {  // the experiment: the integer formats through the pair-of-4096 kernel (static assignment: the host's queue bookkeeping is unused)
-    case SCN_K_SHORT_COMPLEX: return launch_kind<FamilyPair8k, SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_kind<FamilyPair8k, SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_kind<FamilyPair8k, SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    default: return launch_family<Family8k>(SCN_FFT_LAUNCH_PASS);
-  }
-}
-#else
 hipError_t scn_launch_fft_tu5(uint32_t, SCN_FFT_LAUNCH_ARGS) { return launch_family<Family8k>(SCN_FFT_LAUNCH_PASS); }
-#endif
 #endif
 #if SCN_IN_TU(6)
 hipError_t scn_launch_fft_tu6(uint32_t, SCN_FFT_LAUNCH_ARGS) { return launch_family<Family16k>(SCN_FFT_LAUNCH_PASS); }

@@ -1,5 +1,5 @@
-// scn_mixed.hip -- fused kernels for the sizes N = 2^a 3^b 5^c up to 10000 that are not powers of two (1000, 3000, 5000, 6000,
-// 10000 ...: scn_mixed_plans.h).
+// scn_mixed.hip -- fused kernels for the sizes N = 2^a 3^b 5^c that are not powers of two (1000, 3000, 5000, 6000, 10000, 12000
+// ...: scn_mixed_plans.h; two forms, up to 10000 points and beyond).
 //
 // The reference hands any --count to FFTW (fft.cpp:4-11), which runs these sizes with radix-3 / radix-5 codelets at the speed
 // of their power-of-two neighbours.  Until round 5 they went through Bluestein's algorithm on the staged path of
@@ -42,7 +42,7 @@ struct GeoMixed {
   // samples + a 25-point DFT in flight need ~240 at 10000 points.  Every 5-smooth size above ~10600 has a pass with more than
   // 512 threads (three radices <= 32 with N / R <= 512 for each need N <= 22^3); built with 640 .. 832 threads (168 / 128
   // registers) the 12000 .. 16000-point kernels spilled 40 .. 170 VGPRs, with two virtual threads per thread 80 .. 250
-  // (profiles/r05_experiments.md): those sizes stay on the staged path.
+  // (profiles/r05_experiments.md): those sizes have a form of their own, GeoMixedBig below.
   static_assert(W <= 512, "one workgroup of at most two waves per SIMD per buffer");
   static constexpr uint32_t P1 = T1 + PAD1, P2 = V3 + PAD2;
   static constexpr uint32_t EXCH = (R1 * P1 > R3 * P2) ? R1 * P1 : R3 * P2;  // 8-byte slots
@@ -254,7 +254,210 @@ __global__ __launch_bounds__(G::W) void scn_fft_mixed_kernel(ScnFftArgs args, ui
 }
 
 // ------------------------------------------------------------------------------------
-// host-side launchers.  scanner_amd/build.py compiles this file once per SCN_MIXED_TU value (0 .. 3), side by side, each
+// The sizes beyond 10000 (12000, 12288, 14400, 15000, 16000): scn_fft_mixed_big_kernel.
+//
+// Every factorisation of these sizes into three radices <= 32 has a pass with more than 512 threads (see GeoMixed), so a thread
+// plays TWO virtual threads (tv = t and t + W) of every pass in a workgroup of <= 448 threads -- two waves per SIMD, 256
+// registers.  Three things keep that inside the register file where the straightforward form spilled 80 .. 250 VGPRs:
+//   * the two virtual threads run ONE AFTER THE OTHER in a loop that is not unrolled, so hipcc cannot interleave the two 24- /
+//     25-point DFTs and keep both live;
+//   * nothing of a virtual thread survives a barrier in registers: pass 2 works IN PLACE -- thread (p, c) reads L1(p, R3 b + c),
+//     b < R2, and writes its outputs back to the very slots it read, L1(p, R3 q + c); no other thread touches them in that pass,
+//     so there is no barrier between its reads and its writes -- and pass 3 then reads L1(p, R3 q + c), c < R3, as thread
+//     kl = p + R1 q (scripts/mixed_plan.py emulates exactly this against numpy.fft).  One exchange area, three barriers per
+//     buffer; hits are recorded inside pass 3's loop;
+//   * no register-resident constants and no prefetch: pass-1 twiddles and window taps are read per buffer from their
+//     (L2-resident) tables, the samples when they are needed.
+// One workgroup per CU (94 .. 125 KiB of LDS): these kernels trade speed for fitting at all -- against Bluestein's three
+// double-precision transforms through HBM.
+// ------------------------------------------------------------------------------------
+namespace {
+template <uint32_t N_, uint32_t R1_, uint32_t R2_, uint32_t R3_, uint32_t PAD1>
+struct GeoMixedBig {
+  static constexpr uint32_t N = N_, R1 = R1_, R2 = R2_, R3 = R3_;
+  static_assert(R1 * R2 * R3 == N && R1 <= R2 && R1 <= R3 && R2 <= 32 && R3 <= 32, "three radices, the smallest first");
+  static constexpr uint32_t T1 = R2 * R3, V2 = R1 * R3, V3 = R1 * R2;
+  static constexpr uint32_t W = ((T1 + 1u) / 2u + 63u) / 64u * 64u;  // two virtual threads per thread
+  static_assert(T1 > 512 && W <= 512 && 2u * W >= T1, "the sizes one virtual thread per thread cannot carry");
+  static constexpr uint32_t P1 = T1 + PAD1;
+  static constexpr uint32_t EXCH = R1 * P1;
+  static constexpr uint32_t LDS_BYTES = EXCH * 8u + T1 * 8u + 32u * 4u + 2u * 4u + 8u;
+  static constexpr int NB = R3 <= 16 ? 16 : 32;
+};
+}  // namespace
+
+template <class G, int KIND, bool HITS, bool SPEC>
+__global__ __launch_bounds__(G::W) void scn_fft_mixed_big_kernel(ScnFftArgs args, uint32_t correct_dc) {
+  static_assert(HITS || SPEC, "a kernel that reports nothing");
+  constexpr int AUX_LD = SCN_AUX_LD;
+  constexpr int AUX_ST = SCN_AUX_ST;
+  constexpr uint32_t N = G::N, R1 = G::R1, R2 = G::R2, R3 = G::R3, T1 = G::T1, V2 = G::V2, V3 = G::V3, P1 = G::P1, W = G::W;
+  constexpr int NB = G::NB;
+  constexpr uint32_t HALF = N / 2u;
+  typedef RawLoader<KIND> L;
+  typedef typename PowVec<NB>::type pow_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  v2f *lds = reinterpret_cast<v2f *>(smem_raw);
+  v2f *lds_tw2 = lds + G::EXCH;                           // [R2][R3]: W_(R2 R3)^(c q) at q R3 + c
+  int *lds_cnt = reinterpret_cast<int *>(lds_tw2 + T1);  // [32] DC-sum scratch
+  int *lds_hits = lds_cnt + 32;                          // [2]
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+
+#pragma nounroll
+  for (uint32_t h = 0; h < 2; h++) {  // entry q R3 + c = tv: W_(R2 R3)^(c q) = W_N^(R1 c q)
+    const uint32_t tv = t + h * W;
+    if (tv < T1) lds_tw2[tv] = args.twiddle[(R1 * (tv / R3) * (tv % R3)) % N];
+  }
+  if (t == 0) lds_hits[0] = lds_hits[1] = 0;
+  __syncthreads();
+  uint32_t par = 0, prev = 0xffffffffu;
+
+  for (uint32_t buf = blockIdx.x; buf < args.n_buffers; buf += gridDim.x) {
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(reinterpret_cast<const char *>(args.raw) + (size_t)buf * L::kBufBytes(N), L::kBufBytes(N));
+    int dc_re = 0, dc_im = 0;
+    if (KIND != SCN_K_FLOAT_COMPLEX && correct_dc) {  // a pass of its own over the raw samples: the integer sums (utility.cpp:70-79)
+      int sr = 0, si = 0;
+#pragma nounroll
+      for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t tv = t + h * W, t_ld = tv < T1 ? tv : 0x10000000u;
+#pragma unroll
+        for (uint32_t a = 0; a < R1; a++) {
+          int re, im;
+          L::ints(L::template load<AUX_LD>(rc, N, t_ld, T1 * a), re, im);
+          sr += re;
+          si += im;
+        }
+      }
+      sr = wave_sum(sr);
+      si = wave_sum(si);
+      if (lane == 0) {
+        lds_cnt[wave] = sr;
+        lds_cnt[16 + wave] = si;
+      }
+      __syncthreads();
+      sr = si = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < W / 64u; w++) {
+        sr += lds_cnt[w];
+        si += lds_cnt[16 + w];
+      }
+      dc_re = (int)((uint32_t)sr / N);  // int32 /= uint32, utility.cpp:77-78
+      dc_im = (int)((uint32_t)si / N);
+    }
+    // ---- pass 1: DFT over a of x[T1 a + tv] w[..], twiddle W_N^(tv p), to row p ----
+#pragma nounroll
+    for (uint32_t h = 0; h < 2; h++) {
+      const uint32_t tv = t + h * W;
+      const bool on = tv < T1;
+      const uint32_t t_ld = on ? tv : 0x10000000u, tt = on ? tv : 0u;
+      cf v[R1];
+#pragma unroll
+      for (uint32_t a = 0; a < R1; a++) v[a] = L::conv(L::template load<AUX_LD>(rc, N, t_ld, T1 * a), dc_re, dc_im, 1.0f) * (args.window[T1 * a + tt] * args.scale);
+      scn_dft<(int)R1>(v);
+      if (on) {
+#pragma unroll
+        for (uint32_t p = 0; p < R1; p++) lds[p * P1 + tv] = to_v2f(p ? cmul(v[p], from_v2f(args.tw1_table[(p - 1) * T1 + tv])) : v[p]);
+      }
+    }
+    __syncthreads();  // barrier 1
+    if (HITS) {
+      if (t == 0 && prev != 0xffffffffu) {  // every wave is past the barrier: the previous buffer's recorders are done
+        args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+        lds_hits[par ^ 1] = 0;
+      }
+    }
+    // ---- pass 2, in place: thread (p, c): DFT over b, twiddle W_(R2 R3)^(c q), back to the slots it read ----
+#pragma nounroll
+    for (uint32_t h = 0; h < 2; h++) {
+      const uint32_t tv = t + h * W;
+      if (tv < V2) {
+        const uint32_t p2 = tv / R3, c2 = tv % R3;
+        v2f *row = lds + p2 * P1 + c2;
+        cf u[R2];
+#pragma unroll
+        for (uint32_t b = 0; b < R2; b++) u[b] = from_v2f(row[R3 * b]);
+        scn_dft<(int)R2>(u);
+#pragma unroll
+        for (uint32_t q = 0; q < R2; q++) row[R3 * q] = to_v2f(q ? cmul(u[q], from_v2f(lds_tw2[q * R3 + c2])) : u[q]);
+      }
+    }
+    __syncthreads();  // barrier 2
+    // ---- pass 3: thread kl = p + R1 q: DFT over c of L1(p, R3 q + c) -> X[kl + R1 R2 r]; K4, K5 ----
+    __amdgpu_buffer_rsrc_t rout = make_rsrc(args.power_db + (size_t)buf * N, (SPEC && args.power_db) ? 4u * N : 0u);
+#pragma nounroll
+    for (uint32_t h = 0; h < 2; h++) {
+      const uint32_t tv = t + h * W;
+      const bool on = tv < V3;
+      const uint32_t st_voff = on ? tv * 4u : 0x80000000u;
+      pow_t pw;
+      float gmax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int o = 0; o < NB; o++) pw[o] = 0.0f;
+      uint32_t keepmask = 0;
+      if (on) {
+        const v2f *col = lds + (tv % R1) * P1 + R3 * (tv / R1);
+        cf z[R3];
+#pragma unroll
+        for (uint32_t c = 0; c < R3; c++) z[c] = from_v2f(col[c]);
+        scn_dft<(int)R3>(z);
+#pragma unroll
+        for (uint32_t r = 0; r < R3; r++) {
+          const float q = power_of(z[r]);
+          pw[r] = q;
+          gmax[r / (NB / 4)] = fmaxf(gmax[r / (NB / 4)], q);
+          if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 4u * V3 * r, AUX_ST);
+          if constexpr (HITS) {  // K5 mask of bin j = tv + V3 r (process.cpp:46-52)
+            const uint32_t j = tv + V3 * r, i = j >= HALF ? j - HALF : j + (N - HALF);
+            const bool keep = !(j < args.dc_ignore || (N - j) < args.dc_ignore) && !(i < args.i_lo || i > args.i_hi);
+            keepmask |= keep ? (1u << r) : 0u;
+          }
+        }
+      }
+      const float pmax = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
+      if constexpr (SPEC) {
+        if (__ballot(pmax >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            if (__ballot(gmax[g] >= SCN_P_EXACT_FROM)) {
+#pragma unroll
+              for (int r = g * (NB / 4); r < (g + 1) * (NB / 4); r++) {
+                if (r < (int)R3) {
+                  const float q = pw[r];
+                  if (__ballot(q >= SCN_P_EXACT_FROM)) {
+                    const float d = db_exact(q);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d), rout, q >= SCN_P_EXACT_FROM ? st_voff : 0x80000000u, 4u * V3 * (uint32_t)r, AUX_ST);
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      if constexpr (HITS) {
+        if (__ballot(pmax > args.p_lo))
+          scn_record_hits_lanes<NB, false, true>(pw, gmax, keepmask, args, &lds_hits[par], buf, lane, [&](int r) -> uint32_t {
+            const uint32_t j = tv + V3 * (uint32_t)r;
+            return j >= HALF ? j - HALF : j + (N - HALF);
+          });
+      }
+    }
+    __syncthreads();  // barrier 3: exchange area free again, this buffer's recorders done
+    if (HITS) {
+      prev = buf;
+      par ^= 1;
+    }
+  }
+  if (HITS) {
+    if (t == 0 && prev != 0xffffffffu) {
+      args.per_buffer_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+      if (args.host_hits) args.host_hits[prev] = (uint32_t)lds_hits[par ^ 1];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// host-side launchers.  scanner_amd/build.py compiles this file once per SCN_MIXED_TU value (0 .. 5), side by side, each
 // translation unit instantiating the sizes whose row in scn_mixed_plans.h has that unit number; without SCN_MIXED_TU one unit
 // holds everything.
 // ------------------------------------------------------------------------------------
@@ -264,11 +467,13 @@ __global__ __launch_bounds__(G::W) void scn_fft_mixed_kernel(ScnFftArgs args, ui
 #define SCN_MIXED_IN_TU(x) (SCN_MIXED_TU == -1 || SCN_MIXED_TU == (x))
 
 namespace {
-template <class G, int KIND>
+template <class G, int KIND, bool BIG>
 hipError_t launch_mixed_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec, int num_cus, hipStream_t s, hipEvent_t stop) {
-  void (*k)(ScnFftArgs, uint32_t) = !hits ? scn_fft_mixed_kernel<G, KIND, false, true>
-                                    : spec ? scn_fft_mixed_kernel<G, KIND, true, true>
-                                           : scn_fft_mixed_kernel<G, KIND, true, false>;
+  void (*k)(ScnFftArgs, uint32_t);
+  if constexpr (BIG)
+    k = !hits ? scn_fft_mixed_big_kernel<G, KIND, false, true> : spec ? scn_fft_mixed_big_kernel<G, KIND, true, true> : scn_fft_mixed_big_kernel<G, KIND, true, false>;
+  else
+    k = !hits ? scn_fft_mixed_kernel<G, KIND, false, true> : spec ? scn_fft_mixed_kernel<G, KIND, true, true> : scn_fft_mixed_kernel<G, KIND, true, false>;
   if (G::LDS_BYTES > 65536u) {  // per function and per device: simply set on every launch (see launch_kind, scn_kernels.hip)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -287,13 +492,13 @@ hipError_t launch_mixed_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec,
   return hipGetLastError();
 }
 
-template <class G>
+template <class G, bool BIG = false>
 hipError_t launch_mixed(int kind, bool dc, bool hits, bool spec, const ScnFftArgs &args, int num_cus, hipStream_t stream, hipEvent_t stop) {
   switch (kind) {
-    case SCN_K_FLOAT_COMPLEX: return launch_mixed_kind<G, SCN_K_FLOAT_COMPLEX>(args, false, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT_COMPLEX: return launch_mixed_kind<G, SCN_K_SHORT_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_SHORT: return launch_mixed_kind<G, SCN_K_SHORT>(args, dc, hits, spec, num_cus, stream, stop);
-    case SCN_K_BYTE_COMPLEX: return launch_mixed_kind<G, SCN_K_BYTE_COMPLEX>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_FLOAT_COMPLEX: return launch_mixed_kind<G, SCN_K_FLOAT_COMPLEX, BIG>(args, false, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT_COMPLEX: return launch_mixed_kind<G, SCN_K_SHORT_COMPLEX, BIG>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_SHORT: return launch_mixed_kind<G, SCN_K_SHORT, BIG>(args, dc, hits, spec, num_cus, stream, stop);
+    case SCN_K_BYTE_COMPLEX: return launch_mixed_kind<G, SCN_K_BYTE_COMPLEX, BIG>(args, dc, hits, spec, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }
@@ -304,6 +509,8 @@ hipError_t scn_launch_mixed_tu0(uint32_t n, SCN_MIXED_ARGS);
 hipError_t scn_launch_mixed_tu1(uint32_t n, SCN_MIXED_ARGS);
 hipError_t scn_launch_mixed_tu2(uint32_t n, SCN_MIXED_ARGS);
 hipError_t scn_launch_mixed_tu3(uint32_t n, SCN_MIXED_ARGS);
+hipError_t scn_launch_mixed_tu4(uint32_t n, SCN_MIXED_ARGS);
+hipError_t scn_launch_mixed_tu5(uint32_t n, SCN_MIXED_ARGS);
 
 // (`if constexpr` on the template parameter: a discarded branch instantiates nothing -- with a plain `if` every translation unit
 //  would compile every size's kernels)
@@ -311,10 +518,15 @@ hipError_t scn_launch_mixed_tu3(uint32_t n, SCN_MIXED_ARGS);
   if constexpr (UNIT == TU) {                             \
     if (n == N) return launch_mixed<GeoMixed<N, R1, R2, R3, PAD1, PAD2>>(kind, dc, hits, spec, args, num_cus, stream, stop); \
   }
+#define SCN_MIXED_BIG_CASE(N, R1, R2, R3, PAD1, UNIT)     \
+  if constexpr (UNIT == TU) {                             \
+    if (n == N) return launch_mixed<GeoMixedBig<N, R1, R2, R3, PAD1>, true>(kind, dc, hits, spec, args, num_cus, stream, stop); \
+  }
 namespace {
 template <int TU>
 hipError_t launch_mixed_unit(uint32_t n, SCN_MIXED_ARGS) {
   SCN_MIXED_PLANS(SCN_MIXED_CASE)
+  SCN_MIXED_BIG_PLANS(SCN_MIXED_BIG_CASE)
   return hipErrorInvalidValue;
 }
 }  // namespace
@@ -330,6 +542,12 @@ hipError_t scn_launch_mixed_tu2(uint32_t n, SCN_MIXED_ARGS) { return launch_mixe
 #if SCN_MIXED_IN_TU(3)
 hipError_t scn_launch_mixed_tu3(uint32_t n, SCN_MIXED_ARGS) { return launch_mixed_unit<3>(n, kind, dc, hits, spec, args, num_cus, stream, stop); }
 #endif
+#if SCN_MIXED_IN_TU(4)
+hipError_t scn_launch_mixed_tu4(uint32_t n, SCN_MIXED_ARGS) { return launch_mixed_unit<4>(n, kind, dc, hits, spec, args, num_cus, stream, stop); }
+#endif
+#if SCN_MIXED_IN_TU(5)
+hipError_t scn_launch_mixed_tu5(uint32_t n, SCN_MIXED_ARGS) { return launch_mixed_unit<5>(n, kind, dc, hits, spec, args, num_cus, stream, stop); }
+#endif
 
 #if SCN_MIXED_IN_TU(0)
 // the plan of size n, or false: its smallest radix R1 (the tw1 table has R1 - 1 rows) and the pass-1 thread count T1 (its row length)
@@ -339,8 +557,10 @@ hipError_t scn_launch_mixed_tu3(uint32_t n, SCN_MIXED_ARGS) { return launch_mixe
     if (threads) *threads = R2 * R3;                       \
     return true;                                           \
   }
+#define SCN_MIXED_BIG_LOOKUP(N, R1, R2, R3, PAD1, UNIT) SCN_MIXED_LOOKUP(N, R1, R2, R3, PAD1, 0, UNIT)
 bool scn_mixed_layout(uint32_t n, uint32_t *rows, uint32_t *threads) {
   SCN_MIXED_PLANS(SCN_MIXED_LOOKUP)
+  SCN_MIXED_BIG_PLANS(SCN_MIXED_BIG_LOOKUP)
   return false;
 }
 bool scn_mixed_size_supported(uint32_t n) { return scn_mixed_layout(n, nullptr, nullptr); }
@@ -352,12 +572,16 @@ hipError_t scn_launch_mixed(uint32_t n, int kind, bool dc, bool hits, bool spec,
   if (!hits && !spec) return hipErrorInvalidValue;
   if (args.n_buffers == 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
   int unit = -1;
+#define SCN_MIXED_BIG_UNIT_OF(N, R1, R2, R3, PAD1, UNIT) SCN_MIXED_UNIT_OF(N, R1, R2, R3, PAD1, 0, UNIT)
   SCN_MIXED_PLANS(SCN_MIXED_UNIT_OF)
+  SCN_MIXED_BIG_PLANS(SCN_MIXED_BIG_UNIT_OF)
   switch (unit) {
     case 0: return scn_launch_mixed_tu0(n, kind, dc, hits, spec, args, num_cus, stream, stop);
     case 1: return scn_launch_mixed_tu1(n, kind, dc, hits, spec, args, num_cus, stream, stop);
     case 2: return scn_launch_mixed_tu2(n, kind, dc, hits, spec, args, num_cus, stream, stop);
     case 3: return scn_launch_mixed_tu3(n, kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 4: return scn_launch_mixed_tu4(n, kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 5: return scn_launch_mixed_tu5(n, kind, dc, hits, spec, args, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }

@@ -70,7 +70,7 @@ def run(budget, seed, plans=None):
     while time.time() < t_end and (plans is None or cases < plans):
         # 16 ... 512: several buffers per workgroup; 65536, 32768: the four-step pairs; 1000, 6000: the mixed-radix fused kernels; 1023: the staged path (Bluestein)
         sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else \
-            [1024, 2048, 4096, 8192, 16384, 16384, 256, 512, 65536, 32768, 1000, 6000, 1023, 16, 32, 64, 128]
+            [1024, 2048, 4096, 8192, 16384, 16384, 256, 512, 65536, 32768, 1000, 6000, 12000, 1023, 16, 32, 64, 128]
         n = int(rng.choice(sizes))
         kind = int(rng.choice(kinds))
         enob = 8 if kind == capi.KIND_BYTE_COMPLEX else int(rng.choice([12, 12, 14, 16, 10]))
@@ -78,7 +78,7 @@ def run(budget, seed, plans=None):
         thr = float(rng.choice([6.0, 9.5, 12.0, 20.0, -5.0]))
         out_flags = int(rng.choice([3, 3, 1, 2]))
         flags = out_flags | (capi.PLAN_OVERLAP_SLOTS if rng.integers(0, 2) else 0)
-        max_nb = int(rng.choice([3, 40, 150])) if n == 1023 else int(rng.choice([3, 64, 700, 2600])) if n == 1000 else int(rng.choice([3, 64, 400, 900])) if n == 6000 else int(rng.choice([3, 64, 700, 2600, 5000])) if n <= 512 else int(rng.choice([3, 64, 700, 1300, 2600])) if n <= 4096 else int(rng.choice([3, 64, 600, 1100])) if n == 8192 else int(rng.choice([3, 64, 300, 520])) if n == 16384 else int(rng.choice([3, 40, 130])) if n == 32768 else int(rng.choice([3, 20, 70])) if n == 65536 else int(rng.choice([3, 64, 700, 2600]))
+        max_nb = int(rng.choice([3, 40, 150])) if n == 1023 else int(rng.choice([3, 64, 700, 2600])) if n == 1000 else int(rng.choice([3, 64, 400, 900])) if n in (6000, 12000) else int(rng.choice([3, 64, 700, 2600, 5000])) if n <= 512 else int(rng.choice([3, 64, 700, 1300, 2600])) if n <= 4096 else int(rng.choice([3, 64, 600, 1100])) if n == 8192 else int(rng.choice([3, 64, 300, 520])) if n == 16384 else int(rng.choice([3, 40, 130])) if n == 32768 else int(rng.choice([3, 20, 70])) if n == 65536 else int(rng.choice([3, 64, 700, 2600]))
         if rng.random() < 0.15:   # time-domain mode (process.cpp:203-237): a few small launches against the oracle
             time_domain_case(rng, n, kind, enob, dc)
             cases += 1

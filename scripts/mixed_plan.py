@@ -36,6 +36,47 @@ CHOSEN = {
 }
 
 
+# The sizes beyond 10000: two virtual threads per thread and ONE in-place exchange (GeoMixedBig in scn_mixed.hip): pass 2 writes its
+# outputs back to the slots it read, pass 3 reads L1(p, R3 q + c).  N: (R1, R2, R3, pad1, extra LDS cycles per buffer)
+BIG_CHOSEN = {12000: (20, 24, 25, 1, 450), 12288: (16, 24, 32, 1, 0), 14400: (24, 24, 25, 1, 300), 15000: (24, 25, 25, 8, 300), 16000: (20, 25, 32, 1, 576)}
+
+
+def big_cost(r1, r2, r3, pad1):
+    t1, p1, v2, v3 = r2 * r3, r2 * r3 + pad1, r1 * r3, r1 * r2
+    w = -(-(-(-t1 // 2)) // 64) * 64
+    cost = 0
+    for h in range(2):
+        tvs = [t + h * w for t in range(w)]
+        for b in range(r2):  # pass-2 reads and its in-place writes
+            cost += 2 * conflicts([None if tv >= v2 else (tv // r3) * p1 + r3 * b + tv % r3 for tv in tvs])
+        for c in range(r3):  # pass-3 reads
+            cost += conflicts([None if tv >= v3 else (tv % r1) * p1 + r3 * (tv // r1) + c for tv in tvs])
+    return cost, w
+
+
+def emulate_big(n, r1, r2, r3, seed=0):
+    """the in-place form: the same three DFTs, exchange 2 written back to L1's slots; returns max |X - fft(x)| / max |fft(x)|"""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    t1 = r2 * r3
+    W = lambda m, e: np.exp(-2j * np.pi * (np.asarray(e) % m) / m)  # noqa: E731
+    l1 = np.zeros((r1, t1), complex)
+    a, p = np.arange(r1), np.arange(r1)
+    for tau in range(t1):
+        l1[:, tau] = (W(r1, np.outer(p, a)) @ x[t1 * a + tau]) * W(n, tau * p)
+    b, q = np.arange(r2), np.arange(r2)
+    for pp in range(r1):
+        for c in range(r3):
+            l1[pp, r3 * q + c] = (W(r2, np.outer(q, b)) @ l1[pp, r3 * b + c]) * W(r2 * r3, c * q)   # in place: slots R3 q + c
+    X = np.zeros(n, complex)
+    cc, r = np.arange(r3), np.arange(r3)
+    for kl in range(r1 * r2):
+        pp, qq = kl % r1, kl // r1
+        X[kl + r1 * r2 * r] = W(r3, np.outer(r, cc)) @ l1[pp, r3 * qq + cc]
+    ref = np.fft.fft(x)
+    return np.abs(X - ref).max() / np.abs(ref).max()
+
+
 def factorizations(n):
     out = []
     for r1 in range(2, RMAX + 1):
@@ -140,6 +181,15 @@ def main():
         rows.append((n, r1, r2, r3, pad1, pad2))
         print(f"{n:6d} = {r1:2d} x {r2:2d} x {r3:2d}   threads {threads:4d} (pass 1: {t1}, 2: {r1 * r3}, 3: {r1 * r2})  P1 {t1 + pad1:4d} P2 {r1 * r2 + pad2:4d}  "
               f"LDS {exch * 8 / 1024:6.1f} KiB  extra LDS cycles per buffer {cost:3d}" + ("" if err is None else f"  emulated vs numpy.fft {err:.1e}"))
+    big_rows = []
+    for n, (r1, r2, r3, pad1, cost) in sorted(BIG_CHOSEN.items()):
+        c, w = big_cost(r1, r2, r3, pad1)
+        assert r1 * r2 * r3 == n and r1 <= min(r2, r3) and c == cost, (n, c)
+        err = emulate_big(n, r1, r2, r3)
+        assert err < 1e-12, (n, err)
+        big_rows.append((n, r1, r2, r3, pad1))
+        print(f"{n:6d} = {r1:2d} x {r2:2d} x {r3:2d}   threads {w:4d} x 2 virtual (pass 1: {r2 * r3}, 2: {r1 * r3}, 3: {r1 * r2})  P1 {r2 * r3 + pad1:4d} (in place)  "
+              f"LDS {r1 * (r2 * r3 + pad1) * 8 / 1024:6.1f} KiB  extra LDS cycles per buffer {cost:3d}  emulated vs numpy.fft {err:.1e}")
     if "--write" in sys.argv:
         with open(os.path.join(ROOT, "scanner_amd", "csrc", "scn_mixed_plans.h"), "w") as f:
             f.write("// scn_mixed_plans.h -- GENERATED by scripts/mixed_plan.py --write: the sizes of the mixed-radix fused kernels (scn_mixed.hip),\n"
@@ -147,6 +197,9 @@ def main():
                     "// that instantiates the size (build.py compiles four side by side).  X(N, R1, R2, R3, PAD1, PAD2, UNIT)\n"
                     "#define SCN_MIXED_PLANS(X) \\\n")
             f.write(" \\\n".join(f"  X({n}, {r1}, {r2}, {r3}, {p1}, {p2}, {k % 4})" for k, (n, r1, r2, r3, p1, p2) in enumerate(rows)) + "\n")
+            f.write("// the sizes beyond 10000 (GeoMixedBig: two virtual threads per thread, one in-place exchange).  X(N, R1, R2, R3, PAD1, UNIT)\n"
+                    "#define SCN_MIXED_BIG_PLANS(X) \\\n")
+            f.write(" \\\n".join(f"  X({n}, {r1}, {r2}, {r3}, {p1}, {4 + k % 2})" for k, (n, r1, r2, r3, p1) in enumerate(big_rows)) + "\n")
         print("wrote scanner_amd/csrc/scn_mixed_plans.h")
 
 

@@ -42,7 +42,10 @@ run --n 8192 --batch 4096 --kind int16 --plan-mode hits    # what ProcessSamples
 run --n 8192 --batch 4096 --kind int8 --plan-mode hits
 run --n 8192 --batch 4096 --kind int16 --time-domain       # the CLI's default mode (scan.cpp:87)
 run --n 1023 --batch 4096 --steps 20 --warmup 3      # Bluestein (a size without a fused kernel)
-run --n 12000 --batch 2796 --steps 20 --warmup 3     # Bluestein: 5-smooth, but beyond the mixed-radix kernels' 10000
+run --n 12000 --batch 2796                           # beyond 10000: two virtual threads per thread, one in-place exchange
+run --n 12000 --batch 2796 --kind int16
+run --n 16000 --batch 2097
+run --n 11000 --batch 3050 --steps 20 --warmup 3     # Bluestein: not 5-smooth
 run --welch --welch-psd 32 --steps 100 --warmup 10
 run --welch --welch-psd 8 --welch-pinned --steps 20 --warmup 3
 python3 - <<PY

@@ -80,14 +80,14 @@ def test_loads_and_reports_errors(built_lib):
 
 def test_size_paths(built_lib):
     """scn_size_path needs no device: every power of two from 16 to 16384 has a fused kernel, and so have the 5-smooth sizes of
-    scn_mixed_plans.h (1000 ... 10000); 32768 / 65536 the four-step pair, the other sizes from 17 to 65535 Bluestein, nothing
+    scn_mixed_plans.h (1000 ... 16000); 32768 / 65536 the four-step pair, the other sizes from 17 to 65535 Bluestein, nothing
     else is planned (the GPU suite walks the fused list)."""
     for k in range(4, 15):
         assert capi.size_path(1 << k) == capi.PATH_FUSED, 1 << k
-    for n in (1000, 3000, 5000, 6000, 10000):
+    for n in (1000, 3000, 5000, 6000, 10000, 12000, 16000):
         assert capi.size_path(n) == capi.PATH_FUSED, n
     assert capi.size_path(32768) == capi.size_path(65536) == capi.PATH_FOUR_STEP
-    for n in (17, 100, 1001, 1023, 4097, 12000, 65535):
+    for n in (17, 100, 1001, 1023, 4097, 11000, 65535):
         assert capi.size_path(n) == capi.PATH_BLUESTEIN, n
     for n in (0, 1, 8, 15, 65537, 1 << 17):
         assert capi.size_path(n) == capi.PATH_UNSUPPORTED, n

@@ -34,8 +34,9 @@ NAMES = {capi.KIND_FLOAT_COMPLEX: "cfloat", capi.KIND_SHORT_COMPLEX: "int16", ca
 def test_the_fused_sizes_are_the_documented_ones():
     assert FUSED_SIZES == [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
     assert capi.size_path(32768) == capi.size_path(65536) == capi.PATH_FOUR_STEP
-    assert MIXED_SIZES == [1000, 1200, 1500, 2000, 2400, 2500, 3000, 3600, 4000, 4800, 5000, 6000, 7200, 8000, 9000, 9600, 10000]
-    assert capi.size_path(1023) == capi.size_path(17) == capi.size_path(12000) == capi.size_path(65535) == capi.PATH_BLUESTEIN
+    assert MIXED_SIZES == [1000, 1200, 1500, 2000, 2400, 2500, 3000, 3600, 4000, 4800, 5000, 6000, 7200, 8000, 9000, 9600, 10000,
+                           12000, 12288, 14400, 15000, 16000]   # (from 12000 up: the two-virtual-thread, in-place form)
+    assert capi.size_path(1023) == capi.size_path(17) == capi.size_path(11000) == capi.size_path(65535) == capi.PATH_BLUESTEIN
     assert capi.size_path(8) == capi.size_path(65537) == capi.PATH_UNSUPPORTED
 
 
@@ -59,7 +60,7 @@ def _drop_guard_band(h, near, seq0, n):
 # the mixed-radix sizes: every kernel of a size is (wire format) x (output mode) -- DC removal is a runtime branch there --, so four
 # formats per size reach all twelve (DC on for two of them); two sizes walk all seven combinations like the powers of two
 MIXED_FORMATS = [(capi.KIND_FLOAT_COMPLEX, 12, False), (capi.KIND_SHORT_COMPLEX, 12, True), (capi.KIND_SHORT, 14, False), (capi.KIND_BYTE_COMPLEX, 8, True)]
-CASES = [(n, *f) for n in FUSED_SIZES for f in FORMATS] + [(n, *f) for n in MIXED_SIZES for f in (FORMATS if n in (1000, 6000) else MIXED_FORMATS)]
+CASES = [(n, *f) for n in FUSED_SIZES for f in FORMATS] + [(n, *f) for n in MIXED_SIZES for f in (FORMATS if n in (1000, 6000, 12000) else MIXED_FORMATS)]
 
 
 @pytest.mark.parametrize("n,kind,enob,dc", CASES, ids=[f"{n}-{NAMES[k]}{'-dc' if dc else ''}" for n, k, _, dc in CASES])

@@ -25,10 +25,11 @@ def test_plans_verify_and_the_header_is_the_generators_output(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]          # (asserts inside: every size's three passes == numpy.fft to 1e-12, pitch costs as recorded)
     rows = [l for l in out.stdout.splitlines() if " = " in l and "threads" in l]
     header = open(os.path.join(ROOT, "scanner_amd", "csrc", "scn_mixed_plans.h")).read()
-    assert len(rows) == header.count("\n  X(") == 17
+    assert len(rows) == header.count("\n  X(") == 22
     for l in rows:
         n, r1, r2, r3 = (int(v) for v in l.replace("=", " ").replace("x", " ").split()[:4])
-        assert f"  X({n}, {r1}, {r2}, {r3}, " in header and r1 * r2 * r3 == n and r2 * r3 <= 512 and "emulated vs numpy.fft" in l
+        assert f"  X({n}, {r1}, {r2}, {r3}, " in header and r1 * r2 * r3 == n and "emulated vs numpy.fft" in l
+        assert (r2 * r3 <= 512) == (n <= 10000)      # beyond 10000: the two-virtual-thread form (SCN_MIXED_BIG_PLANS)
 
 
 def test_oracle_factored_dft_is_the_dft_sum(oracle_mod):

@@ -25,8 +25,17 @@
 #include "scn_device.h"
 
 // tunables, each measured (scripts in git history: welch_variants.sh; profiles/r02_experiments.md, r03_experiments.md section 5)
-constexpr int SCN_WELCH_AUX_IN = 0;     // cache policy of the input stream loads (each sample is read by two overlapping segments)
-constexpr int SCN_WELCH_PF_CUT = 8;     // how many of the next segment's 16 loads the column kernel issues before pass 1 (the rest after the barrier)
+#ifndef SCN_WELCH_AUX_IN_POLICY
+#define SCN_WELCH_AUX_IN_POLICY 2
+#endif
+// cache policy of the input stream loads: non-temporal since round 5 -- with the overlapping half of a segment kept in registers
+// (SCN_WELCH_REUSE) a sample is fetched once, and nt then pays like everywhere else: 32 PSDs per step, one box, three rounds:
+// 136.7 .. 139.2 us (round 4's form) / 134.8 .. 136.4 (reuse, default policy) / 126.1 .. 127.0 (reuse + nt)
+constexpr int SCN_WELCH_AUX_IN = SCN_WELCH_AUX_IN_POLICY;
+constexpr int SCN_WELCH_PF_CUT = 4;     // how many of the next segment's 8 NEW loads the column kernel issues before pass 1 (the rest after the barrier)
+#ifndef SCN_WELCH_REUSE
+#define SCN_WELCH_REUSE 1               // 0: round 4's form (segments dealt round-robin, every segment loaded whole): the A/B baseline
+#endif
 #define SCN_WELCH_ROWS_WPS 3            // waves per SIMD the row kernel is compiled for
 constexpr int SCN_WELCH_AUX_WK_ST = 0;  // cache policy of the work-buffer stores (columns) ...
 constexpr int SCN_WELCH_AUX_WK_LD = 2;  // ... and loads (rows): read once, non-temporal (measured 152 -> 140 us per 32-PSD step; the store
@@ -38,8 +47,11 @@ constexpr uint32_t WP = 272;  // LDS row pitch (slots): 16 rows of 256 + 16, as 
 }  // namespace
 
 // ---- kernel A: columns -------------------------------------------------------------------
-// grid = 16 column tiles x G workgroups; workgroup (j, g) owns tile j for segments g, g+G, ...
-// so everything that depends on (n1, n2, k1) but not on the segment stays in registers.
+// grid = 16 column tiles x G workgroups; workgroup (j, g) owns tile j for a CONTIGUOUS range of segments, so everything that
+// depends on (n1, n2, k1) but not on the segment stays in registers -- and so does half of the input: with a hop of N/2 = 128
+// rows of 256, segment s + 1's rows 0 .. 127 are segment s's rows 128 .. 255, which the same thread holds (n1 = 16 a + hi:
+// a' = a - 8).  Only the new half is loaded (round 5; until then the segments were dealt round-robin and every sample was
+// fetched by both segments that contain it: 2.86e8 B of input reads per 32-PSD step where 1.43e8 are new).
 __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
@@ -74,21 +86,37 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
     return make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)(ok ? seg : 0u) * args.hop * 8u, ok ? WN * 8u : 0u);
   };
   v2f raw[16];
+#if SCN_WELCH_REUSE
+  const uint32_t per = (args.n_segments + G - 1u) / G, seg_lo = g * per, seg_hi = seg_lo + per < args.n_segments ? seg_lo + per : args.n_segments;
+  const uint32_t seg_step = 1u;
+#else
+  const uint32_t seg_lo = g, seg_hi = args.n_segments, seg_step = G;
+#endif
   {
-    const __amdgpu_buffer_rsrc_t r0 = in_rsrc(g);
+    const __amdgpu_buffer_rsrc_t r0 = in_rsrc(seg_lo < seg_hi ? seg_lo : args.n_segments);
 #pragma unroll
     for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
   }
-  for (uint32_t seg = g; seg < args.n_segments; seg += G) {
+  for (uint32_t seg = seg_lo; seg < seg_hi; seg += seg_step) {
     __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)seg * WN * 8u + j * 2048u, WN * 8u - j * 2048u);
     cf v[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) v[a] = from_v2f(raw[a]) * win[a];
     // the next segment's loads go out in two groups, one per barrier-separated phase (a burst of 16 stalls the wave at
     // issue when the memory pipeline is backed up: profiles/r01_floors.md)
+#if SCN_WELCH_REUSE
+    const __amdgpu_buffer_rsrc_t rn = in_rsrc(seg + 1u < seg_hi ? seg + 1u : args.n_segments);
+#pragma unroll
+    for (int a = 0; a < 8; a++) raw[a] = raw[a + 8];  // the upper half of this segment is the lower half of the next
+#pragma unroll
+    for (int a = 8; a < 8 + SCN_WELCH_PF_CUT; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
+    constexpr int REST_LO = 8 + SCN_WELCH_PF_CUT;
+#else
     const __amdgpu_buffer_rsrc_t rn = in_rsrc(seg + G);
 #pragma unroll
-    for (int a = 0; a < SCN_WELCH_PF_CUT; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
+    for (int a = 0; a < 8; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
+    constexpr int REST_LO = 8;
+#endif
     fft16(v);
 #pragma unroll
     for (int p = 0; p < 16; p++) {
@@ -100,7 +128,7 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
 #pragma unroll
     for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 16]);
 #pragma unroll
-    for (int a = SCN_WELCH_PF_CUT; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
+    for (int a = REST_LO; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
     fft16(v);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
@@ -212,6 +240,7 @@ __global__ __launch_bounds__(256) void scn_welch_combine_kernel(ScnWelchArgs arg
 
 hipError_t scn_launch_welch(const ScnWelchArgs &a, int num_cus, hipStream_t s) {
   if (a.n_segments == 0) return hipSuccess;
+  if (a.hop != WN / 2u) return hipErrorInvalidValue;  // (the column kernel's in-register overlap is the 50 % one)
   const size_t lds = 16 * WP * sizeof(v2f);
   // kernel A: 16 tiles x G groups, G so that the grid is one resident wave of workgroups
   uint32_t G = (uint32_t)(num_cus * 3) / 16u;

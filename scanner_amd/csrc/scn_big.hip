@@ -22,7 +22,14 @@
 
 #include "scn_device.h"
 
+#ifndef SCN_BIG_AUX_IN_POLICY
+#define SCN_BIG_AUX_IN_POLICY 2
+#endif
 namespace {
+// cache policy of the column kernel's sample loads: non-temporal (every sample is read once) -- until round 5 they were the one
+// streaming access of the library left at the default policy.  One box, two rounds, us per step default -> nt: 65536-pt cfloat
+// 195.0 -> 160.7 / 162.1, int16 193.6 / 189.2 -> 168.8 / 168.6, 32768-pt cfloat 191.5 / 195.3 -> 172.8 / 177.6 (profiles/r05_bignt_ab.txt)
+constexpr int BIG_AUX_IN = SCN_BIG_AUX_IN_POLICY;
 constexpr uint32_t BN = 65536;
 constexpr uint32_t BP = 272;  // LDS row pitch (slots): 16 rows of 256 + 16, as in scn_welch.hip
 
@@ -33,7 +40,7 @@ struct BigRaw<SCN_K_FLOAT_COMPLEX> {
   static constexpr uint32_t kBytes = 8;
   typedef v2f raw_t;
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t s, uint32_t a, uint32_t n) {  // sample s + (n / 16) a
-    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, s * 8u, a * (n / 2u), 0));
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, s * 8u, a * (n / 2u), BIG_AUX_IN));
   }
   static __device__ __forceinline__ cf conv(raw_t r, int, int) { return from_v2f(r); }
   static __device__ __forceinline__ void ints(raw_t, int &re, int &im) { re = im = 0; }  // (no DC removal for float samples)
@@ -43,7 +50,7 @@ struct BigRaw<SCN_K_SHORT_COMPLEX> {
   static constexpr uint32_t kBytes = 4;
   typedef int raw_t;
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t s, uint32_t a, uint32_t n) {
-    return __builtin_amdgcn_raw_buffer_load_b32(r, s * 4u, a * (n / 4u), 0);
+    return __builtin_amdgcn_raw_buffer_load_b32(r, s * 4u, a * (n / 4u), BIG_AUX_IN);
   }
   // float(source) * onebymax with the scale folded into the window tap (utility.cpp:81-82; onebymax is +-2^-k: exact)
   // (source - dc in int arithmetic with wrap-around, as the oracle's conv1)
@@ -59,8 +66,8 @@ struct BigRaw<SCN_K_SHORT> {  // planar: I[n] then Q[n]
   static constexpr uint32_t kBytes = 4;
   typedef int raw_t;
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t s, uint32_t a, uint32_t n) {
-    const int re = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, a * (n / 8u), 0);
-    const int im = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, n * 2u + a * (n / 8u), 0);
+    const int re = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, a * (n / 8u), BIG_AUX_IN);
+    const int im = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, n * 2u + a * (n / 8u), BIG_AUX_IN);
     return (re & 0xffff) | (im << 16);
   }
   static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) { BigRaw<SCN_K_SHORT_COMPLEX>::ints(r, re, im); }
@@ -71,7 +78,7 @@ struct BigRaw<SCN_K_BYTE_COMPLEX> {
   static constexpr uint32_t kBytes = 2;
   typedef int raw_t;
   static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t s, uint32_t a, uint32_t n) {
-    return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, a * (n / 8u), 0);
+    return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, a * (n / 8u), BIG_AUX_IN);
   }
   static __device__ __forceinline__ void ints(raw_t r, int &re, int &im) { re = (int)(signed char)(r & 0xff); im = (int)(signed char)((r >> 8) & 0xff); }
   static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im) {

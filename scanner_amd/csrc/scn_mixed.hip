@@ -268,6 +268,11 @@ __global__ __launch_bounds__(G::W) void scn_fft_mixed_kernel(ScnFftArgs args, ui
 //     buffer; hits are recorded inside pass 3's loop;
 //   * no register-resident constants and no prefetch: pass-1 twiddles and window taps are read per buffer from their
 //     (L2-resident) tables, the samples when they are needed.
+// PASS 3 RUNS IN DOUBLE, and the smallest radix goes last so that it fits (a 16 .. 24-point DFT in double: 64 .. 96 registers of data):
+// all in float, these sizes put the parity metric's tail ON the bar -- a strong tone's partial sums are rounded in the last pass and
+// the error lands on the other bins of its column, as at 16384 points (scn_kernels.hip) -- : 1024 strong-tone buffers per format
+// read up to 9.8e-6 (16000 points) and 9.1e-6 (14400), a ten-minute fuzz on these sizes found two spectra over 1e-5 (1.3e-5 at 12288
+// points, 1.1e-5 at 16000); the sizes up to 10000 stay within 6e-6 (profiles/r05_experiments.md section 4).
 // One workgroup per CU (94 .. 125 KiB of LDS): these kernels trade speed for fitting at all -- against Bluestein's three
 // double-precision transforms through HBM.
 // ------------------------------------------------------------------------------------
@@ -275,10 +280,11 @@ namespace {
 template <uint32_t N_, uint32_t R1_, uint32_t R2_, uint32_t R3_, uint32_t PAD1>
 struct GeoMixedBig {
   static constexpr uint32_t N = N_, R1 = R1_, R2 = R2_, R3 = R3_;
-  static_assert(R1 * R2 * R3 == N && R1 <= R2 && R1 <= R3 && R2 <= 32 && R3 <= 32, "three radices, the smallest first");
+  static_assert(R1 * R2 * R3 == N && R3 <= R1 && R3 <= R2 && R1 <= 32 && R2 <= 32, "three radices, the smallest LAST (pass 3 runs in double)");
   static constexpr uint32_t T1 = R2 * R3, V2 = R1 * R3, V3 = R1 * R2;
-  static constexpr uint32_t W = ((T1 + 1u) / 2u + 63u) / 64u * 64u;  // two virtual threads per thread
-  static_assert(T1 > 512 && W <= 512 && 2u * W >= T1, "the sizes one virtual thread per thread cannot carry");
+  static constexpr uint32_t VMAX = T1 > V2 ? (T1 > V3 ? T1 : V3) : (V2 > V3 ? V2 : V3);
+  static constexpr uint32_t W = ((VMAX + 1u) / 2u + 63u) / 64u * 64u;  // two virtual threads per thread
+  static_assert(VMAX > 512 && W <= 512, "the sizes one virtual thread per thread cannot carry");
   static constexpr uint32_t P1 = T1 + PAD1;
   static constexpr uint32_t EXCH = R1 * P1;
   static constexpr uint32_t LDS_BYTES = EXCH * 8u + T1 * 8u + 32u * 4u + 2u * 4u + 8u;
@@ -397,13 +403,13 @@ __global__ __launch_bounds__(G::W) void scn_fft_mixed_big_kernel(ScnFftArgs args
       uint32_t keepmask = 0;
       if (on) {
         const v2f *col = lds + (tv % R1) * P1 + R3 * (tv / R1);
-        cf z[R3];
+        cd z[R3];  // in double: see the header of this kernel
 #pragma unroll
-        for (uint32_t c = 0; c < R3; c++) z[c] = from_v2f(col[c]);
+        for (uint32_t c = 0; c < R3; c++) z[c] = to_cd(col[c]);
         scn_dft<(int)R3>(z);
 #pragma unroll
         for (uint32_t r = 0; r < R3; r++) {
-          const float q = power_of(z[r]);
+          const float q = (float)__builtin_fma(z[r].y, z[r].y, z[r].x * z[r].x);
           pw[r] = q;
           gmax[r / (NB / 4)] = fmaxf(gmax[r / (NB / 4)], q);
           if constexpr (SPEC) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, db_fast(q)), rout, st_voff, 4u * V3 * r, AUX_ST);
@@ -480,10 +486,15 @@ hipError_t launch_mixed_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec,
   }
   // one resident wave of persistent workgroups: what fits a CU by registers, LDS and waves (asked of the runtime: the register
   // count of these kernels is the compiler's choice)
-  int per_cu = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, (int)G::W, G::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  if (per_cu < 1) per_cu = 1;
+  // (asked once per kernel: one static per instantiation and output mode; the GPUs of a node are alike)
+  static int per_cu_of_mode[3] = {0, 0, 0};
+  int &per_cu = per_cu_of_mode[!hits ? 0 : spec ? 1 : 2];
+  if (per_cu < 1) {
+    int q = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k, (int)G::W, G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    per_cu = q < 1 ? 1 : q;
+  }
   int grid = num_cus * per_cu;
   if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;
   const uint32_t cdc = dc ? 1u : 0u;

@@ -3,6 +3,9 @@
 // the same kind of codelets.  Plain arithmetic on a complex type with members x, y -- no device builtins -- so that the same
 // header compiles for the host: tests/cpp/test_mixed_dft.cpp holds every length against the DFT sum in double on the CPU.
 //
+// The complex type decides the precision: members of type float (cf) or double (cd: the last pass of the sizes beyond 10000, where a
+// strong tone's float partial sums put the parity metric's tail on the bar -- scn_mixed.hip); the constants follow it.
+//
 // scn_dft<R>(v): in place, natural order in and out.  R in {2, 3, 4, 5} are straight-line butterflies; any other length is one
 // Cooley-Tukey step R = A B (A = 4 where that divides, else the smallest prime factor), n = B a + b, k = p + A q:
 //   y[p][b] = W_R^(b p) * sum_a v[B a + b] W_A^(a p);   X[p + A q] = sum_b y[p][b] W_B^(b q)
@@ -14,6 +17,11 @@
 #else
 #define SCN_DFT_FN inline
 #endif
+
+template <class C>
+struct ScnDftReal {
+  typedef decltype(C{}.x) type;
+};
 
 template <int R>
 struct ScnDftSplit {
@@ -30,13 +38,14 @@ SCN_DFT_FN C scn_dft_twiddle(C v, int e) {
   if (4 * e == R) return C{v.y, -v.x};       // -i
   if (2 * e == R) return C{-v.x, -v.y};      // -1
   if (4 * e == 3 * R) return C{-v.y, v.x};   // +i
-  const float h = 0.70710678118654752440f;
+  typedef typename ScnDftReal<C>::type real_t;
+  const real_t h = (real_t)0.70710678118654752440;
   if (8 * e == R) return C{(v.x + v.y) * h, (v.y - v.x) * h};        // (1 - i) / sqrt 2
   if (8 * e == 3 * R) return C{(v.y - v.x) * h, -(v.x + v.y) * h};   // (-1 - i) / sqrt 2
   if (8 * e == 5 * R) return C{-(v.x + v.y) * h, (v.x - v.y) * h};   // (-1 + i) / sqrt 2
   if (8 * e == 7 * R) return C{(v.x - v.y) * h, (v.x + v.y) * h};    // (1 + i) / sqrt 2
-  const float wr = (float)__builtin_cos(6.283185307179586476925286766559 * e / R);
-  const float wi = -(float)__builtin_sin(6.283185307179586476925286766559 * e / R);
+  const real_t wr = (real_t)__builtin_cos(6.283185307179586476925286766559 * e / R);
+  const real_t wi = -(real_t)__builtin_sin(6.283185307179586476925286766559 * e / R);
   return C{v.x * wr - v.y * wi, v.x * wi + v.y * wr};
 }
 
@@ -81,9 +90,10 @@ struct ScnDft<2, C> {
 template <class C>
 struct ScnDft<3, C> {
   static SCN_DFT_FN void run(C (&v)[3]) {
-    const float S = 0.86602540378443864676f;  // sin(2 pi / 3)
+    typedef typename ScnDftReal<C>::type real_t;
+    const real_t S = (real_t)0.86602540378443864676, HALF = (real_t)0.5;  // sin(2 pi / 3)
     const C s{v[1].x + v[2].x, v[1].y + v[2].y}, d{v[1].x - v[2].x, v[1].y - v[2].y};
-    const C m{v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y};
+    const C m{v[0].x - HALF * s.x, v[0].y - HALF * s.y};
     const C u{S * d.y, -S * d.x};  // -i S d
     v[0] = C{v[0].x + s.x, v[0].y + s.y};
     v[1] = C{m.x + u.x, m.y + u.y};
@@ -104,8 +114,9 @@ struct ScnDft<4, C> {
 template <class C>
 struct ScnDft<5, C> {
   static SCN_DFT_FN void run(C (&v)[5]) {
-    const float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;  // cos(2 pi / 5), cos(4 pi / 5)
-    const float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;   // sin(2 pi / 5), sin(4 pi / 5)
+    typedef typename ScnDftReal<C>::type real_t;
+    const real_t C1 = (real_t)0.30901699437494742410, C2 = (real_t)-0.80901699437494742410;  // cos(2 pi / 5), cos(4 pi / 5)
+    const real_t S1 = (real_t)0.95105651629515357212, S2 = (real_t)0.58778525229247312917;   // sin(2 pi / 5), sin(4 pi / 5)
     const C t1{v[1].x + v[4].x, v[1].y + v[4].y}, t2{v[2].x + v[3].x, v[2].y + v[3].y};
     const C t3{v[1].x - v[4].x, v[1].y - v[4].y}, t4{v[2].x - v[3].x, v[2].y - v[3].y};
     const C m1{v[0].x + C1 * t1.x + C2 * t2.x, v[0].y + C1 * t1.y + C2 * t2.y};

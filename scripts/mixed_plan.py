@@ -37,13 +37,15 @@ CHOSEN = {
 
 
 # The sizes beyond 10000: two virtual threads per thread and ONE in-place exchange (GeoMixedBig in scn_mixed.hip): pass 2 writes its
-# outputs back to the slots it read, pass 3 reads L1(p, R3 q + c).  N: (R1, R2, R3, pad1, extra LDS cycles per buffer)
-BIG_CHOSEN = {12000: (20, 24, 25, 1, 450), 12288: (16, 24, 32, 1, 0), 14400: (24, 24, 25, 1, 300), 15000: (24, 25, 25, 8, 300), 16000: (20, 25, 32, 1, 576)}
+# outputs back to the slots it read, pass 3 reads L1(p, R3 q + c).  The SMALLEST radix goes last: pass 3 runs in double there (the
+# accuracy tail of these sizes, profiles/r05_experiments.md section 4) and a 16 .. 24-point double DFT fits the registers where a
+# 25- or 32-point one does not.  N: (R1, R2, R3, pad1, extra LDS cycles per buffer)
+BIG_CHOSEN = {12000: (24, 25, 20, 1, 1140), 12288: (32, 24, 16, 1, 0), 14400: (24, 25, 24, 1, 600), 15000: (25, 25, 24, 1, 1152), 16000: (32, 25, 20, 1, 1200)}
 
 
 def big_cost(r1, r2, r3, pad1):
     t1, p1, v2, v3 = r2 * r3, r2 * r3 + pad1, r1 * r3, r1 * r2
-    w = -(-(-(-t1 // 2)) // 64) * 64
+    w = -(-(-(-max(t1, v2, v3) // 2)) // 64) * 64
     cost = 0
     for h in range(2):
         tvs = [t + h * w for t in range(w)]
@@ -184,7 +186,7 @@ def main():
     big_rows = []
     for n, (r1, r2, r3, pad1, cost) in sorted(BIG_CHOSEN.items()):
         c, w = big_cost(r1, r2, r3, pad1)
-        assert r1 * r2 * r3 == n and r1 <= min(r2, r3) and c == cost, (n, c)
+        assert r1 * r2 * r3 == n and r3 <= min(r1, r2) and c == cost, (n, c)
         err = emulate_big(n, r1, r2, r3)
         assert err < 1e-12, (n, err)
         big_rows.append((n, r1, r2, r3, pad1))

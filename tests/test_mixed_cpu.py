@@ -16,8 +16,10 @@ def test_in_register_dfts_against_the_dft_sum(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tests", "cpp", "test_mixed_dft.cpp")])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "mixed dft tests ok" in out.stdout, out.stdout[-2000:]
-    for r in (10, 12, 15, 16, 18, 20, 24, 25):   # every radix scn_mixed_plans.h uses
+    for r in (10, 12, 15, 16, 18, 20, 24, 25, 32):   # every radix scn_mixed_plans.h uses
         assert f"dft<{r:2d}>" in out.stdout
+    for r in (16, 20, 24):                            # ... and the last-pass radices of the sizes beyond 10000, in double
+        assert f"dft<{r:2d}> in double" in out.stdout
 
 
 def test_plans_verify_and_the_header_is_the_generators_output(tmp_path):
@@ -29,7 +31,10 @@ def test_plans_verify_and_the_header_is_the_generators_output(tmp_path):
     for l in rows:
         n, r1, r2, r3 = (int(v) for v in l.replace("=", " ").replace("x", " ").split()[:4])
         assert f"  X({n}, {r1}, {r2}, {r3}, " in header and r1 * r2 * r3 == n and "emulated vs numpy.fft" in l
-        assert (r2 * r3 <= 512) == (n <= 10000)      # beyond 10000: the two-virtual-thread form (SCN_MIXED_BIG_PLANS)
+        if n <= 10000:
+            assert r1 <= min(r2, r3) and r2 * r3 <= 512      # one virtual thread per thread, the smallest radix first
+        else:
+            assert r3 <= min(r1, r2) and "x 2 virtual" in l  # SCN_MIXED_BIG_PLANS: the smallest radix last (pass 3 in double)
 
 
 def test_oracle_factored_dft_is_the_dft_sum(oracle_mod):

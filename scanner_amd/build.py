@@ -15,7 +15,7 @@ SOURCES = ["scn_kernels.hip", "scn_mixed.hip", "scn_generic.hip", "scn_big.hip",
 HEADERS = ["scn_kernels.h", "scn_device.h", "scn_mixed_dft.h", "scn_mixed_plans.h", "scn_gather_protocol.h", os.path.join("..", "..", "include", "scanner_hip.h")]
 ARCH = "gfx950"
 # files compiled once per value of a macro, side by side, each translation unit instantiating one group of sizes
-SPLIT = {"scn_kernels.hip": ("SCN_TU", 8), "scn_mixed.hip": ("SCN_MIXED_TU", 6)}
+SPLIT = {"scn_kernels.hip": ("SCN_TU", 8), "scn_mixed.hip": ("SCN_MIXED_TU", 8)}
 
 
 def hipcc():

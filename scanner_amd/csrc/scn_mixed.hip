@@ -463,7 +463,7 @@ __global__ __launch_bounds__(G::W) void scn_fft_mixed_big_kernel(ScnFftArgs args
 }
 
 // ------------------------------------------------------------------------------------
-// host-side launchers.  scanner_amd/build.py compiles this file once per SCN_MIXED_TU value (0 .. 5), side by side, each
+// host-side launchers.  scanner_amd/build.py compiles this file once per SCN_MIXED_TU value (0 .. 7), side by side, each
 // translation unit instantiating the sizes whose row in scn_mixed_plans.h has that unit number; without SCN_MIXED_TU one unit
 // holds everything.
 // ------------------------------------------------------------------------------------
@@ -522,6 +522,8 @@ hipError_t scn_launch_mixed_tu2(uint32_t n, SCN_MIXED_ARGS);
 hipError_t scn_launch_mixed_tu3(uint32_t n, SCN_MIXED_ARGS);
 hipError_t scn_launch_mixed_tu4(uint32_t n, SCN_MIXED_ARGS);
 hipError_t scn_launch_mixed_tu5(uint32_t n, SCN_MIXED_ARGS);
+hipError_t scn_launch_mixed_tu6(uint32_t n, SCN_MIXED_ARGS);
+hipError_t scn_launch_mixed_tu7(uint32_t n, SCN_MIXED_ARGS);
 
 // (`if constexpr` on the template parameter: a discarded branch instantiates nothing -- with a plain `if` every translation unit
 //  would compile every size's kernels)
@@ -559,6 +561,12 @@ hipError_t scn_launch_mixed_tu4(uint32_t n, SCN_MIXED_ARGS) { return launch_mixe
 #if SCN_MIXED_IN_TU(5)
 hipError_t scn_launch_mixed_tu5(uint32_t n, SCN_MIXED_ARGS) { return launch_mixed_unit<5>(n, kind, dc, hits, spec, args, num_cus, stream, stop); }
 #endif
+#if SCN_MIXED_IN_TU(6)
+hipError_t scn_launch_mixed_tu6(uint32_t n, SCN_MIXED_ARGS) { return launch_mixed_unit<6>(n, kind, dc, hits, spec, args, num_cus, stream, stop); }
+#endif
+#if SCN_MIXED_IN_TU(7)
+hipError_t scn_launch_mixed_tu7(uint32_t n, SCN_MIXED_ARGS) { return launch_mixed_unit<7>(n, kind, dc, hits, spec, args, num_cus, stream, stop); }
+#endif
 
 #if SCN_MIXED_IN_TU(0)
 // the plan of size n, or false: its smallest radix R1 (the tw1 table has R1 - 1 rows) and the pass-1 thread count T1 (its row length)
@@ -593,6 +601,8 @@ hipError_t scn_launch_mixed(uint32_t n, int kind, bool dc, bool hits, bool spec,
     case 3: return scn_launch_mixed_tu3(n, kind, dc, hits, spec, args, num_cus, stream, stop);
     case 4: return scn_launch_mixed_tu4(n, kind, dc, hits, spec, args, num_cus, stream, stop);
     case 5: return scn_launch_mixed_tu5(n, kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 6: return scn_launch_mixed_tu6(n, kind, dc, hits, spec, args, num_cus, stream, stop);
+    case 7: return scn_launch_mixed_tu7(n, kind, dc, hits, spec, args, num_cus, stream, stop);
     default: return hipErrorInvalidValue;
   }
 }

@@ -21,8 +21,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the sizes VERDICT r4 (next 7) names first, and round decimal / 3-smooth sizes between them
+# -- and the families a radix-2 user reaches for next: 3 * 2^k, 5 * 2^k, 15 * 2^k --
 # (up to 10000: beyond ~10600 every factorisation has a pass of more than 512 threads, see GeoMixed in scn_mixed.hip)
-SIZES = [1000, 1200, 1500, 2000, 2400, 2500, 3000, 3600, 4000, 4800, 5000, 6000, 7200, 8000, 9000, 9600, 10000]
+SIZES = [1000, 1200, 1280, 1500, 1536, 1920, 2000, 2400, 2500, 2560, 3000, 3072, 3600, 3840, 4000, 4800, 5000, 5120, 6000, 6144, 7200, 7680,
+         8000, 9000, 9600, 10000]
 RMAX = 32
 # what `--search` found (the pad search is a brute force over 256 pitch pairs per factorisation: minutes in Python), kept here so
 # that --write and the verification are instant; N: (R1, R2, R3, pad1, pad2, extra LDS cycles per buffer)
@@ -33,6 +35,8 @@ CHOSEN = {
     7200: (18, 20, 20, 4, 1, 260), 8000: (20, 20, 20, 4, 1, 300), 9000: (18, 20, 25, 5, 1, 0), 9600: (20, 20, 24, 8, 1, 200),
     10000: (20, 20, 25, 5, 9, 0), 12000: (20, 24, 25, 1, 9, 0), 12288: (16, 24, 32, 0, 1, 0), 14400: (24, 24, 25, 1, 9, 0),
     15000: (24, 25, 25, 8, 1, 0), 16000: (20, 25, 32, 0, 1, 0),
+    1280: (8, 10, 16, 0, 1, 0), 1536: (8, 12, 16, 0, 1, 0), 1920: (10, 12, 16, 0, 1, 0), 2560: (10, 16, 16, 0, 1, 0), 3072: (12, 16, 16, 0, 1, 0),
+    3840: (15, 16, 16, 0, 1, 0), 5120: (16, 20, 16, 0, 1, 0), 6144: (16, 24, 16, 0, 1, 0), 7680: (16, 20, 24, 8, 1, 160),
 }
 
 
@@ -40,7 +44,8 @@ CHOSEN = {
 # outputs back to the slots it read, pass 3 reads L1(p, R3 q + c).  The SMALLEST radix goes last: pass 3 runs in double there (the
 # accuracy tail of these sizes, profiles/r05_experiments.md section 4) and a 16 .. 24-point double DFT fits the registers where a
 # 25- or 32-point one does not.  N: (R1, R2, R3, pad1, extra LDS cycles per buffer)
-BIG_CHOSEN = {12000: (24, 25, 20, 1, 1140), 12288: (32, 24, 16, 1, 0), 14400: (24, 25, 24, 1, 600), 15000: (25, 25, 24, 1, 1152), 16000: (32, 25, 20, 1, 1200)}
+BIG_CHOSEN = {12000: (24, 25, 20, 1, 1140), 12288: (32, 24, 16, 1, 0), 14400: (24, 25, 24, 1, 600), 15000: (25, 25, 24, 1, 1152), 16000: (32, 25, 20, 1, 1200),
+              10240: (32, 20, 16, 1, 0), 12800: (32, 20, 20, 1, 960), 15360: (32, 24, 20, 1, 1152)}
 
 
 def big_cost(r1, r2, r3, pad1):
@@ -110,16 +115,22 @@ def conflicts(slots):
     return extra
 
 
+def conflicts_np(slots, active):
+    """conflicts() for many wave instructions at once: slots [instructions, lanes] (lanes a multiple of 16), active [lanes]"""
+    res = np.where(active[None, :], slots % 16, -1).reshape(slots.shape[0], -1, 16)
+    worst = np.zeros(res.shape[:2], int)
+    for r in range(16):
+        worst = np.maximum(worst, (res == r).sum(axis=2))
+    return int(np.maximum(worst - 1, 0).sum())
+
+
 def pitch_cost(r1, r2, r3, pad1, pad2):
     t1, p1, p2 = r2 * r3, r2 * r3 + pad1, r1 * r2 + pad2
     threads = -(-t1 // 64) * 64
-    cost = 0
-    v2 = [(t // r3, t % r3) if t < r1 * r3 else None for t in range(threads)]
-    for b in range(r2):  # pass-2 reads
-        cost += conflicts([None if v is None else v[0] * p1 + r3 * b + v[1] for v in v2])
-    for q in range(r2):  # pass-2 writes
-        cost += conflicts([None if v is None else v[1] * p2 + v[0] + r1 * q for v in v2])
-    return cost
+    t = np.arange(threads)
+    active, p, c = t < r1 * r3, t // r3, t % r3
+    k = np.arange(r2)[:, None]
+    return conflicts_np(p[None, :] * p1 + r3 * k + c[None, :], active) + conflicts_np(c[None, :] * p2 + p[None, :] + r1 * k, active)  # pass-2 reads, pass-2 writes
 
 
 def choose(n):
@@ -174,7 +185,7 @@ def main():
         plan = choose(n) if "--search" in sys.argv else CHOSEN[n]
         assert plan, n
         r1, r2, r3, pad1, pad2, cost = plan
-        assert r1 * r2 * r3 == n and r1 <= min(r2, r3) and max(r2, r3) <= RMAX and cost == pitch_cost(r1, r2, r3, pad1, pad2)
+        assert r1 * r2 * r3 == n and r1 <= min(r2, r3) and max(r2, r3) <= RMAX and r2 * r3 <= 512 and cost == pitch_cost(r1, r2, r3, pad1, pad2)
         err = emulate(n, r1, r2, r3) if n <= 3000 or "--all" in sys.argv else None
         assert err is None or err < 1e-12, (n, err)
         t1 = r2 * r3
@@ -196,12 +207,12 @@ def main():
         with open(os.path.join(ROOT, "scanner_amd", "csrc", "scn_mixed_plans.h"), "w") as f:
             f.write("// scn_mixed_plans.h -- GENERATED by scripts/mixed_plan.py --write: the sizes of the mixed-radix fused kernels (scn_mixed.hip),\n"
                     "// their three radices (R1 the smallest), the pads of the two LDS row pitches and the translation unit of scn_mixed.hip\n"
-                    "// that instantiates the size (build.py compiles four side by side).  X(N, R1, R2, R3, PAD1, PAD2, UNIT)\n"
+                    "// that instantiates the size (build.py compiles eight side by side).  X(N, R1, R2, R3, PAD1, PAD2, UNIT)\n"
                     "#define SCN_MIXED_PLANS(X) \\\n")
-            f.write(" \\\n".join(f"  X({n}, {r1}, {r2}, {r3}, {p1}, {p2}, {k % 4})" for k, (n, r1, r2, r3, p1, p2) in enumerate(rows)) + "\n")
+            f.write(" \\\n".join(f"  X({n}, {r1}, {r2}, {r3}, {p1}, {p2}, {k % 6})" for k, (n, r1, r2, r3, p1, p2) in enumerate(rows)) + "\n")
             f.write("// the sizes beyond 10000 (GeoMixedBig: two virtual threads per thread, one in-place exchange).  X(N, R1, R2, R3, PAD1, UNIT)\n"
                     "#define SCN_MIXED_BIG_PLANS(X) \\\n")
-            f.write(" \\\n".join(f"  X({n}, {r1}, {r2}, {r3}, {p1}, {4 + k % 2})" for k, (n, r1, r2, r3, p1) in enumerate(big_rows)) + "\n")
+            f.write(" \\\n".join(f"  X({n}, {r1}, {r2}, {r3}, {p1}, {6 + k % 2})" for k, (n, r1, r2, r3, p1) in enumerate(sorted(big_rows, key=lambda r: -r[0]))) + "\n")
         print("wrote scanner_amd/csrc/scn_mixed_plans.h")
 
 

@@ -84,7 +84,7 @@ def test_size_paths(built_lib):
     else is planned (the GPU suite walks the fused list)."""
     for k in range(4, 15):
         assert capi.size_path(1 << k) == capi.PATH_FUSED, 1 << k
-    for n in (1000, 3000, 5000, 6000, 10000, 12000, 16000):
+    for n in (1000, 1536, 3000, 5000, 6000, 10000, 10240, 12000, 15360, 16000):
         assert capi.size_path(n) == capi.PATH_FUSED, n
     assert capi.size_path(32768) == capi.size_path(65536) == capi.PATH_FOUR_STEP
     for n in (17, 100, 1001, 1023, 4097, 11000, 65535):

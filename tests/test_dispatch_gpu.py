@@ -34,8 +34,9 @@ NAMES = {capi.KIND_FLOAT_COMPLEX: "cfloat", capi.KIND_SHORT_COMPLEX: "int16", ca
 def test_the_fused_sizes_are_the_documented_ones():
     assert FUSED_SIZES == [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
     assert capi.size_path(32768) == capi.size_path(65536) == capi.PATH_FOUR_STEP
-    assert MIXED_SIZES == [1000, 1200, 1500, 2000, 2400, 2500, 3000, 3600, 4000, 4800, 5000, 6000, 7200, 8000, 9000, 9600, 10000,
-                           12000, 12288, 14400, 15000, 16000]   # (from 12000 up: the two-virtual-thread, in-place form)
+    assert MIXED_SIZES == [1000, 1200, 1280, 1500, 1536, 1920, 2000, 2400, 2500, 2560, 3000, 3072, 3600, 3840, 4000, 4800, 5000, 5120, 6000,
+                           6144, 7200, 7680, 8000, 9000, 9600, 10000,
+                           10240, 12000, 12288, 12800, 14400, 15000, 15360, 16000]   # (from 10240 up: the two-virtual-thread, in-place form)
     assert capi.size_path(1023) == capi.size_path(17) == capi.size_path(11000) == capi.size_path(65535) == capi.PATH_BLUESTEIN
     assert capi.size_path(8) == capi.size_path(65537) == capi.PATH_UNSUPPORTED
 

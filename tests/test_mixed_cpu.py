@@ -16,7 +16,7 @@ def test_in_register_dfts_against_the_dft_sum(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tests", "cpp", "test_mixed_dft.cpp")])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "mixed dft tests ok" in out.stdout, out.stdout[-2000:]
-    for r in (10, 12, 15, 16, 18, 20, 24, 25, 32):   # every radix scn_mixed_plans.h uses
+    for r in (8, 10, 12, 15, 16, 18, 20, 24, 25, 32):   # every radix scn_mixed_plans.h uses
         assert f"dft<{r:2d}>" in out.stdout
     for r in (16, 20, 24):                            # ... and the last-pass radices of the sizes beyond 10000, in double
         assert f"dft<{r:2d}> in double" in out.stdout
@@ -27,7 +27,7 @@ def test_plans_verify_and_the_header_is_the_generators_output(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]          # (asserts inside: every size's three passes == numpy.fft to 1e-12, pitch costs as recorded)
     rows = [l for l in out.stdout.splitlines() if " = " in l and "threads" in l]
     header = open(os.path.join(ROOT, "scanner_amd", "csrc", "scn_mixed_plans.h")).read()
-    assert len(rows) == header.count("\n  X(") == 22
+    assert len(rows) == header.count("\n  X(") == 34
     for l in rows:
         n, r1, r2, r3 = (int(v) for v in l.replace("=", " ").replace("x", " ").split()[:4])
         assert f"  X({n}, {r1}, {r2}, {r3}, " in header and r1 * r2 * r3 == n and "emulated vs numpy.fft" in l

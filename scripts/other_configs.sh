@@ -38,6 +38,11 @@ run --n 5000 --batch 6710
 run --n 6000 --batch 5592
 run --n 6000 --batch 5592 --kind int16
 run --n 10000 --batch 3355
+run --n 1536 --batch 21845                          # the 3 * 2^k / 5 * 2^k / 15 * 2^k families
+run --n 3072 --batch 10922
+run --n 5120 --batch 6553
+run --n 7680 --batch 4369
+run --n 10240 --batch 3276                          # (from 10240 up: two virtual threads per thread, pass 3 in double)
 run --n 8192 --batch 4096 --kind int16 --plan-mode hits    # what ProcessSamples::ThreadWorker's plans run at the reference's defaults
 run --n 8192 --batch 4096 --kind int8 --plan-mode hits
 run --n 8192 --batch 4096 --kind int16 --time-domain       # the CLI's default mode (scan.cpp:87)

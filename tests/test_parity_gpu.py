@@ -735,6 +735,27 @@ def test_every_evaluated_bin_hits_and_trigger(torch_cuda, oracle_mod):
     assert np.array_equal(h["power_db"], p[b, j])
 
 
+@pytest.mark.parametrize("use_bw,dc_bins", [(0.5, 8), (1.0, 0), (0.9, 1), (0.75, 4)])
+@pytest.mark.parametrize("n", [64, 256, 1024, 4096, 8192, 16384, 3000, 12000, 32768, 1023])
+def test_mask_parameters_across_kernel_families(torch_cuda, oracle_mod, n, use_bw, dc_bins):
+    """process.cpp:46-52 with other parameters than the CLI's defaults (useBandWidth 0.75, dcIgnoreWindow 4): every kernel family
+    builds its keep mask from the plan's dc_ignore_bins / i_lo / i_hi -- tiny, small, narrow, 8192, 16384, both mixed-radix forms,
+    the four-step pair, Bluestein.  With a threshold under every bin the hit list IS the mask: (seq_id, i, freq_hz) bit for bit,
+    and exactly mask.sum() records per buffer (use_bandwidth 1.0: U = N/2, every i kept; dc_ignore 0: no DC window)."""
+    nb = 4 if n >= 8192 else 9
+    x = synth.cfloat_batch(n, nb, seed=11 + n, sigma=0.1)
+    fc = 1.2e9 + 6e6 * np.arange(nb)
+    o = oracle_mod.Oracle(n, FS, -200.0, use_bandwidth=use_bw, dc_ignore_bins=dc_bins)
+    _, h_ref, t_ref = o.run(x, fc, None, threads=4)
+    m = tol.evaluated_mask(n, use_bw, dc_bins)
+    assert len(h_ref) == nb * int(m.sum()) > 0
+    with Plan(n, FS, -200.0, max_batch=nb, max_hits=nb * n, use_bandwidth=use_bw, dc_ignore_bins=dc_bins, flags=capi.OUT_HITS) as plan:
+        plan.submit_device(0, _to_dev(torch_cuda, x), nb, fc)
+        _, h, t = plan.collect(0, hit_cap=nb * n)
+    _assert_hits_equal(h, h_ref)
+    assert np.array_equal(t, t_ref)
+
+
 def test_trigger_threshold_edge(torch_cuda, oracle_mod):
     """trigger = hits > 1047, strictly (process.cpp:62): build spectra with exactly 1047 / 1048 hits."""
     n = 4096

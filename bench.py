@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--dc", action="store_true", help="integer formats: remove the integer mean first (utility.cpp:70-79, correctDC)")
     ap.add_argument("--time-domain", action="store_true",
                     help="the reference CLI's default mode (scan.cpp:87, process.cpp:203-237): per-buffer max / min dB, no FFT")
+    ap.add_argument("--per-buffer-centres", action="store_true",
+                    help="send the centre frequencies with every submit (scn_submit_device) instead of naming a run of the plan's "
+                         "GPU-resident frequency table (scn_plan_set_table + scn_submit_device_indexed)")
     ap.add_argument("--no-configs-leg", action="store_true",
                     help="skip the short legs for BASELINE configs C3, the C4 per-GPU share and C5 that ride on the default C2 line (`configs`)")
     ap.add_argument("--threshold", type=float, default=None,
@@ -269,7 +272,8 @@ def quick_leg(torch, dev, local_rank, n, kind_name, nb, threshold, steps, make_i
                 device_id=local_rank, flags=flags)
     streams = [torch.cuda.ExternalStream(plan.slot_stream_handle(s) if overlap else plan.stream_handle, device=dev) for s in range(depth if overlap else 1)]
     vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    prep = [(C.c_void_p(raws[r].data_ptr()), nb, vp(fc), vp(seq), C.c_void_p(outs[r].data_ptr())) for r in range(R)]
+    plan.set_table(fc)  # the centres of a launch are a run of the plan's frequency table: no per-buffer header crosses the boundary
+    prep = [(C.c_void_p(raws[r].data_ptr()), nb, 0, vp(seq), C.c_void_p(outs[r].data_ptr())) for r in range(R)]
     pending = [False] * depth
     state = {"launch": 0}
 
@@ -278,7 +282,7 @@ def quick_leg(torch, dev, local_rank, n, kind_name, nb, threshold, steps, make_i
             s = state["launch"] % depth
             if pending[s]:
                 plan.collect_counts(s)
-            plan.submit_prepared(s, *prep[state["launch"] % R])
+            plan.submit_prepared_indexed(s, *prep[state["launch"] % R])
             pending[s] = True
             state["launch"] += 1
 
@@ -726,6 +730,11 @@ def main():
         the ordered records too if asked)"""
         pending = [False] * depth
         state = {"launch": 0, "hits": 0, "acc": 0, "group": 0}
+        # the centres of a launch are a run of this rank's frequency table, resident on the GPU (scn_plan_set_table): a submit
+        # names its first entry (--per-buffer-centres: the centres travel with every submit, 8 bytes per buffer, as until round 4)
+        table = not args.per_buffer_centres
+        if table:
+            pl.set_table(fc)
         rec_buf = np.zeros(hit_cap, capi.HIT_DTYPE) if want_records else None  # the caller's record buffer, reused
         # counts-only loops with a launch per chunk go through the prepared calls (two ctypes calls per launch, every
         # argument a C value made here once): Python's own cost per step must stay below a 24 us launch
@@ -734,8 +743,9 @@ def main():
         if fast:
             vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
             # (ids that are simply the buffers' indices in the launch are not passed at all: the compaction kernel numbers them itself)
-            prep = [[(C.c_void_p(raws[r][lo:hi].data_ptr()), hi - lo, vp(fc[lo:hi]), None if (first == 0 and lo == 0) else vp(seq[lo:hi]),
+            prep = [[(C.c_void_p(raws[r][lo:hi].data_ptr()), hi - lo, lo if table else vp(fc[lo:hi]), None if (first == 0 and lo == 0) else vp(seq[lo:hi]),
                       C.c_void_p(outs[r][lo:hi].data_ptr()) if spectrum else None) for lo, hi in chunks] for r in range(R)]
+            submit_prepared = pl.submit_prepared_indexed if table else pl.submit_prepared
             state["keep"] = [fc, seq]
 
         def collect(s):
@@ -765,8 +775,8 @@ def main():
             state["launch"] += 1
             if pending[s]:
                 collect(s)
-            pl.submit_device(s, graws[g][:a * shard], a * shard, fc_launch[:a * shard], seq_launch[:a * shard], sync_producer=False,
-                             d_power_db=gouts[g][:a * shard] if spectrum else None)
+            pl.submit_device(s, graws[g][:a * shard], a * shard, None if table else fc_launch[:a * shard], seq_launch[:a * shard], sync_producer=False,
+                             d_power_db=gouts[g][:a * shard] if spectrum else None, first_index=0 if table else None)
             pending[s] = True
             state["acc"] = 0
 
@@ -784,7 +794,7 @@ def main():
                     state["launch"] += 1
                     if pending[s]:
                         pl.collect_counts(s)
-                    pl.submit_prepared(s, *a)
+                    submit_prepared(s, *a)
                     pending[s] = True
                 return
             for lo, hi in chunks:
@@ -792,8 +802,8 @@ def main():
                 state["launch"] += 1
                 if pending[s]:
                     collect(s)
-                pl.submit_device(s, raws[k % R][lo:hi], hi - lo, fc[lo:hi], None if (first == 0 and lo == 0) else seq[lo:hi], sync_producer=False,
-                                 d_power_db=outs[k % R][lo:hi] if spectrum else None)
+                pl.submit_device(s, raws[k % R][lo:hi], hi - lo, None if table else fc[lo:hi], None if (first == 0 and lo == 0) else seq[lo:hi], sync_producer=False,
+                                 d_power_db=outs[k % R][lo:hi] if spectrum else None, first_index=lo if table else None)
                 pending[s] = True
 
         def drain():

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 3 /* 3: SCN_NUM_SLOTS 4, scn_gather_hits_device, scn_gather_fetch, scn_size_path */
+#define SCN_ABI_VERSION 4 /* 3: SCN_NUM_SLOTS 4, scn_gather_hits_device, scn_gather_fetch, scn_size_path; 4: scn_plan_set_table, scn_submit*_indexed */
 
 /* status codes */
 enum {
@@ -161,6 +161,18 @@ int scn_submit(scn_plan *plan, int slot, uint32_t n_buffers,
 int scn_submit_device(scn_plan *plan, int slot, const void *d_raw,
                       uint32_t n_buffers, const double *center_freqs,
                       const uint64_t *seq_ids, float *d_power_db);
+
+/* The plan's frequency table, resident on the GPU: the reference builds its table once (frequencyTable.cpp:31-36) and the
+ * source retunes through it in order, wrapping at the end (GetNextFrequency, frequencyTable.cpp:38-46), so the centre
+ * frequencies of a launch's buffers are a run of consecutive entries.  scn_submit_indexed / scn_submit_device_indexed are
+ * scn_submit / scn_submit_device for such a launch: buffer b carries center_freqs[(first_index + b) % count], and no
+ * per-buffer header crosses the boundary (with seq_ids == NULL none at all: 16 bytes per buffer that made launches of
+ * 16 ... 128-point buffers host-bound).  The records are the same, bit for bit.  count == 0 drops the table.  Not while a
+ * submit is pending (SCN_E_STATE); lists of earlier submits can no longer be re-read afterwards (scn_collect_more). */
+int scn_plan_set_table(scn_plan *plan, const double *center_freqs, uint32_t count);
+int scn_submit_indexed(scn_plan *plan, int slot, uint32_t n_buffers, uint32_t first_index, const uint64_t *seq_ids);
+int scn_submit_device_indexed(scn_plan *plan, int slot, const void *d_raw, uint32_t n_buffers, uint32_t first_index,
+                              const uint64_t *seq_ids, float *d_power_db);
 
 /* Wait for the slot's submit and fetch results.  power_db: host, n_buffers*N
  * floats in natural FFT bin order (bin 0 = DC), or NULL.  hits: host array of

@@ -20,7 +20,7 @@ OUT_SPECTRUM, OUT_HITS = 1, 2
 PLAN_OVERLAP_SLOTS = 4  # each slot on its own compute stream (scanner_hip.h)
 DC_IGNORE_NONE = 0xFFFFFFFF
 NUM_SLOTS = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 PATH_UNSUPPORTED, PATH_FUSED, PATH_FOUR_STEP, PATH_STAGED, PATH_BLUESTEIN = range(5)
 COMM_ID_BYTES = 128
 
@@ -81,6 +81,9 @@ SYMBOLS = {
     "scn_host_buffer": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "scn_submit": (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, _vp]),
     "scn_submit_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "scn_plan_set_table": (C.c_int, [_vp, _vp, C.c_uint32]),
+    "scn_submit_indexed": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp]),
+    "scn_submit_device_indexed": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "scn_collect": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), _vp]),
     "scn_collect_more": (C.c_int, [_vp, C.c_int, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "scn_hits_view": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint32)]),

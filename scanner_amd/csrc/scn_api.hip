@@ -76,6 +76,9 @@ struct Slot {
   uint32_t gen = 0;                 // generation of the pending / last submit
   uint32_t *d_buf_hits[2] = {nullptr, nullptr};
   uint32_t *h_buf_hits = nullptr;
+  unsigned long long *h_total = nullptr;  // pinned (the tail of h_buf_hits): the batch's total, stored by scn_hit_total_kernel
+  unsigned long long *d_total_acc = nullptr;  // its two device words
+  bool total_ready = false;         // the pending / last submit's total is (going to be) in *h_total: scn_collect need not walk the counts
   hipEvent_t kernel_done = nullptr, staged = nullptr;
   hipStream_t stream = nullptr;     // where this slot's kernels run: the plan's compute stream, or its own (SCN_PLAN_OVERLAP_SLOTS)
   // buffer-queue heads of the persistent workgroups (ScnFftArgs::work_counter; 8 heads, never reset) and their values
@@ -96,6 +99,7 @@ struct Slot {
   hipEvent_t list_done[2] = {nullptr, nullptr};  // per generation: scan + compaction (+ prefetch) finished
   bool list_used[2] = {false, false};            // ... and whether that event has ever been recorded
   bool seq_given[2] = {false, false};            // per generation: the submit came with sequence ids (else: the buffer's index)
+  int64_t table_first[2] = {-1, -1};             // per generation: the submit named a range of the plan's frequency table (else -1: its own centres in h_meta)
   bool list_valid = false;          // regions, counts and offsets of the last collected submit are still on the device
   bool list_built = false;          // the scan + compaction of the pending / last submit have been enqueued
   uint32_t total_hits = 0;          // of the last collected submit
@@ -105,6 +109,16 @@ struct Slot {
   bool pending = false;
   uint32_t n_buffers = 0;
 };
+
+// Buffers per launch from which the batch's total is summed on the GPU (scn_hit_total_kernel) instead of by the host's walk over
+// the counts.  The kernel needs CUs the next launch is using: measured on one box (profiles/r05_table_ab.txt, us per step, host
+// walk -> GPU total) 524288 16-point buffers 80.7 -> 72.3 (hits-only plan: 89 -> 73), but 262144 x 128 points 86.2 -> 99.8,
+// 131072 x 256: 75.0 -> 84.6, 32768 x 1024: 75.3 -> 82.9 -- a walk over 2 MB of counts costs more than the kernel's place on the
+// chip, a walk over 1 MB or less does not.
+#ifndef SCN_TOTAL_KERNEL_FROM
+#define SCN_TOTAL_KERNEL_FROM (1u << 19)
+#endif
+constexpr uint32_t kTotalKernelFrom = SCN_TOTAL_KERNEL_FROM;
 
 }  // namespace
 
@@ -137,6 +151,8 @@ struct scn_plan {
   bool big = false;      // 65536 / 32768 points: the four-step pair of scn_big.hip
   uint32_t fft_m = 0, log2m = 0;     // ... and its transform length: n for a power of two, >= 2n - 1 for Bluestein
   double *d_twiddle64 = nullptr;     // [fft_m][2]: W_m^k in double (the staged path applies its tables in double)
+  double *d_table = nullptr;         // [table_count] the plan's frequency table (scn_plan_set_table), read by the compaction kernel
+  uint32_t table_count = 0;
   double *d_chirp = nullptr;         // Bluestein: [n][2], w[i] = exp(-i pi i^2 / n)
   double *d_bfilter = nullptr;       // Bluestein: [fft_m][2], FFT_m of the chirp filter / m
   hipStream_t stream = nullptr;      // compute
@@ -257,7 +273,14 @@ int ensure_slot_outputs(scn_plan *p, Slot &s, uint32_t gen) {
       if (!s.d_buf_hits[g]) SCN_HIP(hipMalloc(&s.d_buf_hits[g], sizeof(uint32_t) * mb));
       if (!s.list_done[g]) SCN_HIP(hipEventCreateWithFlags(&s.list_done[g], hipEventDisableTiming));
     }
-    if (!s.h_buf_hits) SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * mb, hipHostMallocDefault));
+    if (!s.h_buf_hits) {
+      SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * ((size_t)mb + 4u), hipHostMallocDefault));
+      s.h_total = reinterpret_cast<unsigned long long *>(s.h_buf_hits + (((size_t)mb + 1u) & ~(size_t)1u));
+    }
+    if (!s.d_total_acc) {
+      SCN_HIP(hipMalloc(&s.d_total_acc, 2u * sizeof(unsigned long long)));
+      SCN_HIP(hipMemset(s.d_total_acc, 0, 2u * sizeof(unsigned long long)));
+    }
     if (!s.d_offsets) SCN_HIP(hipMalloc(&s.d_offsets, sizeof(uint32_t) * ((size_t)mb + 1u)));
     if (!s.h_meta) SCN_HIP(hipHostMalloc(&s.h_meta, 2u * 16u * (size_t)mb, hipHostMallocDefault));
     if (!s.d_list) SCN_HIP(hipMalloc(&s.d_list, sizeof(scn_hit) * (size_t)p->d.max_hits));
@@ -273,8 +296,12 @@ ScnCompactArgs compact_args(const scn_plan *p, const Slot &s, uint32_t first, ui
   c.hit_region = p->hit_region;
   c.counts = s.d_buf_hits[s.gen];
   c.offsets = s.d_offsets;
-  c.center_freq = static_cast<const double *>(s.h_meta) + (size_t)2u * p->d.max_batch * s.gen;
-  c.seq_id = s.seq_given[s.gen] ? reinterpret_cast<const uint64_t *>(c.center_freq + p->d.max_batch) : nullptr;
+  const double *const h_fc = static_cast<const double *>(s.h_meta) + (size_t)2u * p->d.max_batch * s.gen;
+  const bool table = s.table_first[s.gen] >= 0;
+  c.center_freq = table ? p->d_table : h_fc;
+  c.table_count = table ? p->table_count : 0u;
+  c.table_first = table ? (uint32_t)s.table_first[s.gen] : 0u;
+  c.seq_id = s.seq_given[s.gen] ? reinterpret_cast<const uint64_t *>(h_fc + p->d.max_batch) : nullptr;
   c.out = out;
   c.first = first;
   c.out_cap = std::min<uint32_t>(cap, 0x7fffffffu - first);  // first + out_cap must not wrap
@@ -343,8 +370,9 @@ int fetch_list(scn_plan *p, Slot &s, uint32_t count) {
   return SCN_OK;
 }
 
+// fc == nullptr: the buffers carry entries table_first, table_first + 1, ... (wrapping) of the plan's frequency table
 int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const double *fc, const uint64_t *seq,
-                  float *d_power) {
+                  float *d_power, uint32_t table_first = 0) {
   const bool will_flip = p->d.mode != SCN_MODE_TIME_DOMAIN && (p->d.flags & SCN_OUT_HITS) != 0 && nb != 0;
   int st = ensure_slot_outputs(p, s, will_flip ? s.gen ^ 1u : s.gen);
   if (st) return st;
@@ -373,6 +401,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   s.list_valid = false;
   const bool hits = (p->d.flags & SCN_OUT_HITS) != 0;
   s.list_built = false;
+  s.total_ready = false;
   if (hits && nb) {
     // this submit's generation; the only thing that can still be using it is the list (compaction + copy) of the submit TWO
     // submits back ON THIS SLOT -- 2 x (slots in use) launches back on the plan -- wait for it on the host, where it never
@@ -388,7 +417,10 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     // staging copies cost ~7 us each plus ~10 us of cross-engine hand-off, on the list's critical path)
     double *h_fc = static_cast<double *>(s.h_meta) + (size_t)2u * p->d.max_batch * s.gen;
     uint64_t *h_seq = reinterpret_cast<uint64_t *>(h_fc + p->d.max_batch);
-    memcpy(h_fc, fc, sizeof(double) * nb);
+    // the centres: copied when given; a submit that names a range of the plan's device-resident table writes none (the other
+    // 8 header bytes per buffer: 2 MB per launch of 262144 128-point buffers, written and then read back over PCIe)
+    s.table_first[s.gen] = fc ? -1 : (int64_t)table_first;
+    if (fc) memcpy(h_fc, fc, sizeof(double) * nb);
     // sequence ids: copied when given; otherwise a buffer's id is its index and the compaction kernel computes it -- 8 of the
     // 16 header bytes per buffer that made the 16 .. 128-point steps host-bound (524288 buffers per launch: 4 MB less to write)
     s.seq_given[s.gen] = seq != nullptr;
@@ -502,6 +534,10 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     if (after && !in_packet) SCN_HIP(hipEventRecord(after, s.stream));
     if (cnt != s.stream) SCN_HIP(hipStreamWaitEvent(cnt, after, 0));
     if (fork_list) SCN_HIP(hipStreamWaitEvent(lst, after, 0));
+    // launches of very many small buffers: the total by itself, so that a collect without trigger flags reads one word instead
+    // of walking nb counts; in front of the counts' DMA, behind the kernel
+    s.total_ready = !direct && nb >= kTotalKernelFrom;
+    if (s.total_ready) SCN_HIP(scn_launch_hit_total(s.d_buf_hits[s.gen], nb, s.d_total_acc, s.h_total, cnt));
     if (!direct)
       SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits[s.gen], sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, cnt));
     if (!(after_is_done && after)) SCN_HIP(hipEventRecord(s.done, cnt));
@@ -523,6 +559,7 @@ void free_slot(Slot &s) {
   if (s.d_raw) (void)hipFree(s.d_raw);
   if (s.d_power) (void)hipFree(s.d_power);
   if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
+  if (s.d_total_acc) (void)hipFree(s.d_total_acc);
   for (int g = 0; g < 2; g++) {
     if (s.d_buf_hits[g]) (void)hipFree(s.d_buf_hits[g]);
     if (s.d_hits[g]) (void)hipFree(s.d_hits[g]);
@@ -782,6 +819,7 @@ int scn_plan_destroy(scn_plan *p) {
   if (p->d_window) (void)hipFree(p->d_window);
   if (p->d_twiddle) (void)hipFree(p->d_twiddle);
   if (p->d_twiddle64) (void)hipFree(p->d_twiddle64);
+  if (p->d_table) (void)hipFree(p->d_table);
   if (p->d_chirp) (void)hipFree(p->d_chirp);
   if (p->d_bfilter) (void)hipFree(p->d_bfilter);
   if (p->d_tw1_table) (void)hipFree(p->d_tw1_table);
@@ -814,12 +852,12 @@ int scn_host_buffer(scn_plan *p, int slot, void **ptr, size_t *bytes) {
   return SCN_OK;
 }
 
-int scn_submit(scn_plan *p, int slot, uint32_t nb, const double *fc, const uint64_t *seq) {
-  int st = check_slot(p, slot);
-  if (st) return st;
+namespace {
+// the pinned slot's buffers -> the GPU -> the kernels; fc == nullptr: entries first_index ... of the plan's frequency table
+int submit_host(scn_plan *p, int slot, uint32_t nb, const double *fc, const uint64_t *seq, uint32_t first_index) {
+  int st;
   Slot &s = p->slot[slot];
   if (nb > p->d.max_batch) return fail(SCN_E_INVALID, "n_buffers %u > max_batch %u", nb, p->d.max_batch);
-  if (nb && !fc) return fail(SCN_E_INVALID, "center_freqs is null");
   if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
   if (!s.h_raw) return fail(SCN_E_STATE, "slot %d: scn_host_buffer was never called", slot);
   SCN_HIP(hipSetDevice(p->d.device_id));
@@ -833,7 +871,15 @@ int scn_submit(scn_plan *p, int slot, uint32_t nb, const double *fc, const uint6
     SCN_HIP(hipEventRecord(s.staged, p->h2d_stream));
     SCN_HIP(hipStreamWaitEvent(s.stream, s.staged, 0));
   }
-  return submit_common(p, s, s.d_raw, nb, fc, seq, nullptr);
+  return submit_common(p, s, s.d_raw, nb, fc, seq, nullptr, first_index);
+}
+}  // namespace
+
+int scn_submit(scn_plan *p, int slot, uint32_t nb, const double *fc, const uint64_t *seq) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if (nb && !fc) return fail(SCN_E_INVALID, "center_freqs is null");
+  return submit_host(p, slot, nb, fc, seq, 0);
 }
 
 int scn_submit_device(scn_plan *p, int slot, const void *d_raw, uint32_t nb, const double *fc, const uint64_t *seq,
@@ -847,6 +893,56 @@ int scn_submit_device(scn_plan *p, int slot, const void *d_raw, uint32_t nb, con
   SCN_HIP(hipSetDevice(p->d.device_id));
   if ((st = ensure_slot_stream(p, s))) return st;
   return submit_common(p, s, d_raw, nb, fc, seq, d_power_db);
+}
+
+int scn_plan_set_table(scn_plan *p, const double *fc, uint32_t count) {
+  if (!p) return fail(SCN_E_INVALID, "null plan");
+  if (count && !fc) return fail(SCN_E_INVALID, "center_freqs is null");
+  for (int i = 0; i < SCN_NUM_SLOTS; i++)
+    if (p->slot[i].pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit: its records still read the table", i);
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  // (a list of an already collected submit may still be completed on demand -- scn_collect_more -- from the OLD table: wait for
+  // whatever is queued, then forget those lists)
+  SCN_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < SCN_NUM_SLOTS; i++) p->slot[i].list_valid = false;
+  if (p->d_table) SCN_HIP(hipFree(p->d_table));
+  p->d_table = nullptr;
+  p->table_count = 0;
+  if (!count) return SCN_OK;
+  SCN_HIP(hipMalloc(&p->d_table, sizeof(double) * (size_t)count));
+  SCN_HIP(hipMemcpy(p->d_table, fc, sizeof(double) * (size_t)count, hipMemcpyHostToDevice));
+  p->table_count = count;
+  return SCN_OK;
+}
+
+namespace {
+int check_indexed(scn_plan *p, uint32_t nb, uint32_t first_index) {
+  if (p->d.mode == SCN_MODE_TIME_DOMAIN || !(p->d.flags & SCN_OUT_HITS)) return SCN_OK;  // no records: nothing reads the table
+  if (nb && !p->table_count) return fail(SCN_E_STATE, "scn_plan_set_table was never called");
+  if (nb && first_index >= p->table_count) return fail(SCN_E_INVALID, "first_index %u outside the table of %u entries", first_index, p->table_count);
+  return SCN_OK;
+}
+}  // namespace
+
+int scn_submit_indexed(scn_plan *p, int slot, uint32_t nb, uint32_t first_index, const uint64_t *seq) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if ((st = check_indexed(p, nb, first_index))) return st;
+  return submit_host(p, slot, nb, nullptr, seq, first_index);
+}
+
+int scn_submit_device_indexed(scn_plan *p, int slot, const void *d_raw, uint32_t nb, uint32_t first_index, const uint64_t *seq,
+                              float *d_power_db) {
+  int st = check_slot(p, slot);
+  if (st) return st;
+  if ((st = check_indexed(p, nb, first_index))) return st;
+  Slot &s = p->slot[slot];
+  if (nb > p->d.max_batch) return fail(SCN_E_INVALID, "n_buffers %u > max_batch %u", nb, p->d.max_batch);
+  if (nb && !d_raw) return fail(SCN_E_INVALID, "null argument");
+  if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
+  SCN_HIP(hipSetDevice(p->d.device_id));
+  if ((st = ensure_slot_stream(p, s))) return st;
+  return submit_common(p, s, d_raw, nb, nullptr, seq, d_power_db, first_index);
 }
 
 int scn_convert_raw(scn_plan *p, const void *raw, uint32_t nb, float *out) {
@@ -913,7 +1009,9 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   if (power_db && !s.cur_power) return fail(SCN_E_INVALID, "plan was created without SCN_OUT_SPECTRUM");
 
   uint64_t total = 0;
-  if (have_hits && nb) {
+  if (have_hits && nb && !trigger && s.total_ready) {
+    total = *s.h_total;
+  } else if (have_hits && nb) {
     for (uint32_t b = 0; b < nb; b++) {
       const uint32_t c = s.h_buf_hits[b];
       total += c;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void scn_hit_compact_kernel(ScnCompactArgs a) 
     const ScnDevHit *const region = a.regions + (size_t)b * a.hit_region;
     const uint32_t o0 = a.offsets[b], o1 = a.offsets[b + 1u];
     const ScnDevHit first64 = region[lane < a.hit_region ? lane : 0u];
-    const double fc = a.center_freq[b];
+    const double fc = a.center_freq[a.table_count ? (uint32_t)(((uint64_t)a.table_first + b) % a.table_count) : b];
     const uint64_t seq = a.seq_id ? a.seq_id[b] : (uint64_t)b;  // (no ids given at submit: a buffer's id is its index, messageQueue.h:86 from zero)
     const uint32_t c = o1 - o0;
     if (c == 0 || o0 >= last || o1 <= a.first) continue;  // no hits, or nothing of this buffer inside the window
@@ -165,7 +165,48 @@ __global__ __launch_bounds__(256) void scn_hit_compact_kernel(ScnCompactArgs a) 
   }
 }
 
+// The batch's total alone, for a collect that asks for nothing per buffer: the host's walk over the counts (2 MB read per
+// launch of 524288 16-point buffers: three times the kernel) becomes one 8-byte word in pinned memory.  Partial sums meet in a
+// device word; the last workgroup to arrive stores the total for the host and leaves both words zero for the next launch.
+// (scn_api.hip launches it from 2^19 buffers per launch: below, its place on the chip costs the next launch more than the walk.)
+constexpr uint32_t kTotalThreads = 256, kTotalBlocks = 128;
+
+__global__ __launch_bounds__(kTotalThreads) void scn_hit_total_kernel(const uint32_t *counts, uint32_t nb, unsigned long long *acc,
+                                                                        unsigned long long *host_total) {
+  unsigned long long sum = 0;
+  const uint32_t quads = nb / 4u;  // (hipMalloc'd: 16-byte loads are aligned)
+  const uint4 *const c4 = reinterpret_cast<const uint4 *>(counts);
+  for (uint32_t i = blockIdx.x * kTotalThreads + threadIdx.x; i < quads; i += kTotalBlocks * kTotalThreads) {
+    const uint4 v = c4[i];
+    sum += (unsigned long long)v.x + v.y + v.z + v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < nb - quads * 4u) sum += counts[quads * 4u + threadIdx.x];
+#pragma unroll
+  for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  __shared__ unsigned long long part[kTotalThreads / 64u];
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long block = 0;
+    for (uint32_t w = 0; w < kTotalThreads / 64u; w++) block += part[w];
+    atomicAdd(&acc[0], block);
+    __threadfence();
+    if (atomicAdd(&acc[1], 1ull) == kTotalBlocks - 1u) {  // every other workgroup's sum is in acc[0]
+      __threadfence();
+      const unsigned long long total = atomicExch(&acc[0], 0ull);
+      atomicExch(&acc[1], 0ull);
+      __hip_atomic_store(host_total, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 }  // namespace
+
+hipError_t scn_launch_hit_total(const uint32_t *counts, uint32_t n_buffers, unsigned long long *acc, unsigned long long *host_total,
+                                hipStream_t stream) {
+  hipLaunchKernelGGL(scn_hit_total_kernel, dim3(kTotalBlocks), dim3(kTotalThreads), 0, stream, counts, n_buffers, acc, host_total);
+  return hipGetLastError();
+}
 
 hipError_t scn_launch_hit_scan(const ScnCompactArgs &a, hipStream_t stream) {
   const uint32_t blocks = a.n_buffers ? (a.n_buffers + kScanChunk - 1u) / kScanChunk : 1u;

@@ -97,12 +97,17 @@ struct ScnCompactArgs {
   uint32_t *offsets;         // [n_buffers + 1]: exclusive prefix sums, total at [n_buffers]
   const double *center_freq; // [n_buffers] the submit's MessageHeader fields, read IN PLACE from the plan's pinned host
   const uint64_t *seq_id;    // [n_buffers] copy (two 8-byte reads per buffer that has hits: no staging copies on the stream)
+  uint32_t table_count;      // 0: center_freq is the submit's own [n_buffers]; else center_freq is the plan's device-resident frequency
+  uint32_t table_first;      //    table and buffer b carries entry (table_first + b) % table_count (scn_submit*_indexed)
   void *out;                 // scn_hit[out_cap]
   uint32_t first, out_cap;
   uint32_t n_buffers, n, sample_rate;
 };
 hipError_t scn_launch_hit_scan(const ScnCompactArgs &args, hipStream_t stream);
 hipError_t scn_launch_hit_compact(const ScnCompactArgs &args, hipStream_t stream);
+// sum of counts[0, n_buffers) -> *host_total (pinned host memory); acc: two zeroed device words the kernel leaves zeroed
+hipError_t scn_launch_hit_total(const uint32_t *counts, uint32_t n_buffers, unsigned long long *acc, unsigned long long *host_total,
+                                hipStream_t stream);
 
 // The same path for the power-of-two sizes without a fused kernel (scn_generic.hip): through HBM, stage by stage
 struct ScnGenericArgs {

@@ -43,6 +43,7 @@ class Plan:
         self._nb = [0] * capi.NUM_SLOTS
         self._keep = [None] * capi.NUM_SLOTS
         self._submit_device, self._collect, self._n_hits = self._L.scn_submit_device, self._L.scn_collect, C.c_uint32()
+        self._submit_device_indexed = self._L.scn_submit_device_indexed
 
     # -- lifetime -----------------------------------------------------------
     @property
@@ -81,15 +82,28 @@ class Plan:
         assert fc.size == nb and (seq is None or seq.size == nb)
         return fc, seq
 
-    def submit(self, slot, n_buffers, center_freqs=None, seq_ids=None):
+    def set_table(self, center_freqs):
+        """scn_plan_set_table: the frequency table the source retunes through (frequencyTable.cpp:31-36), uploaded once; a
+        submit with `first_index` then tags buffer b with entry (first_index + b) % len(table) and sends no per-buffer centres."""
+        fc = np.ascontiguousarray(center_freqs, np.float64).reshape(-1)
+        capi.check(self._L.scn_plan_set_table(self._h, fc.ctypes.data_as(C.c_void_p), fc.size), "scn_plan_set_table")
+
+    def submit(self, slot, n_buffers, center_freqs=None, seq_ids=None, first_index=None):
         """Process the first n_buffers raw buffers of the pinned slot (async)."""
+        if first_index is not None:
+            assert center_freqs is None, "a submit names its centres or a run of the plan's table, not both"
+            seq = None if seq_ids is None else np.ascontiguousarray(seq_ids, np.uint64)
+            capi.check(self._L.scn_submit_indexed(self._h, slot, n_buffers, int(first_index),
+                                                  None if seq is None else seq.ctypes.data_as(C.c_void_p)), "scn_submit_indexed")
+            self._nb[slot] = n_buffers
+            return
         fc, seq = self._meta(n_buffers, center_freqs, seq_ids)
         capi.check(self._L.scn_submit(self._h, slot, n_buffers, fc.ctypes.data_as(C.c_void_p),
                                       None if seq is None else seq.ctypes.data_as(C.c_void_p)), "scn_submit")
         self._nb[slot] = n_buffers
 
     def submit_device(self, slot, d_raw, n_buffers=None, center_freqs=None, seq_ids=None, d_power_db=None,
-                      sync_producer=True):
+                      sync_producer=True, first_index=None):
         """Process raw IQ already in device memory (a torch tensor or an int address).
 
         The plan runs on its own non-blocking HIP stream.  With sync_producer (default) the
@@ -112,11 +126,18 @@ class Plan:
         if d_power_db is not None:
             assert d_power_db.is_contiguous() and d_power_db.numel() >= n_buffers * self.n
             out_ptr = C.c_void_p(d_power_db.data_ptr())
-        fc, seq = self._meta(n_buffers, center_freqs, seq_ids)
-        capi.check(self._L.scn_submit_device(self._h, slot, C.c_void_p(ptr), n_buffers,
-                                             fc.ctypes.data_as(C.c_void_p),
-                                             None if seq is None else seq.ctypes.data_as(C.c_void_p), out_ptr),
-                   "scn_submit_device")
+        if first_index is not None:  # a run of the plan's frequency table (set_table)
+            assert center_freqs is None, "a submit names its centres or a run of the plan's table, not both"
+            seq = None if seq_ids is None else np.ascontiguousarray(seq_ids, np.uint64)
+            capi.check(self._L.scn_submit_device_indexed(self._h, slot, C.c_void_p(ptr), n_buffers, int(first_index),
+                                                         None if seq is None else seq.ctypes.data_as(C.c_void_p), out_ptr),
+                       "scn_submit_device_indexed")
+        else:
+            fc, seq = self._meta(n_buffers, center_freqs, seq_ids)
+            capi.check(self._L.scn_submit_device(self._h, slot, C.c_void_p(ptr), n_buffers,
+                                                 fc.ctypes.data_as(C.c_void_p),
+                                                 None if seq is None else seq.ctypes.data_as(C.c_void_p), out_ptr),
+                       "scn_submit_device")
         self._nb[slot] = n_buffers
         self._keep[slot] = (d_raw, d_power_db)  # keep the tensors alive until collected
 
@@ -128,6 +149,13 @@ class Plan:
         st = self._submit_device(self._h, slot, raw_ptr, n_buffers, fc_ptr, seq_ptr, out_ptr)
         if st:
             capi.check(st, "scn_submit_device")
+        self._nb[slot] = n_buffers
+
+    def submit_prepared_indexed(self, slot, raw_ptr, n_buffers, first_index, seq_ptr, out_ptr):
+        """scn_submit_device_indexed the same way: the centres are a run of the plan's table (set_table)."""
+        st = self._submit_device_indexed(self._h, slot, raw_ptr, n_buffers, first_index, seq_ptr, out_ptr)
+        if st:
+            capi.check(st, "scn_submit_device_indexed")
         self._nb[slot] = n_buffers
 
     def collect_counts(self, slot, trigger_ptr=None):

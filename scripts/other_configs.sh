@@ -30,6 +30,7 @@ run --n 32768 --batch 1024 --steps 200 --warmup 20   # the four-step pair, 256 x
 run --n 32768 --batch 1024 --kind int16 --steps 200 --warmup 20
 run --n 128 --batch 262144                          # eight threads per buffer (scn_fft_tiny_kernel)
 run --n 64 --batch 262144
+run --n 128 --batch 262144 --per-buffer-centres      # as until round 4: 8 bytes of centre frequency per buffer with every submit (default now: a run of the plan's GPU-resident table)
 run --n 16 --batch 524288                           # one thread per buffer
 run --n 1000 --batch 32768                           # the mixed-radix fused kernels (scn_mixed.hip)
 run --n 1000 --batch 32768 --kind int16

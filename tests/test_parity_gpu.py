@@ -1057,3 +1057,98 @@ def test_time_domain_mode(torch_cuda, oracle_mod, n, kind, enob, dc):
     assert np.array_equal(ab[clear], ref_hit[clear]) and ref_hit.sum() >= nb // 3
     # the all-zero buffer keeps the reference's odd initial maximum (process.cpp:207)
     assert mx[5] == np.float32(1.17549435e-38) == ref_max[5]
+
+
+@pytest.mark.parametrize("n,kind", [(1024, capi.KIND_FLOAT_COMPLEX), (128, capi.KIND_SHORT_COMPLEX), (1000, capi.KIND_FLOAT_COMPLEX)])
+def test_indexed_submit_gives_the_same_records(torch_cuda, oracle_mod, n, kind):
+    """scn_plan_set_table + scn_submit*_indexed: buffer b of a launch carries entry (first + b) % count of the plan's GPU-resident
+    frequency table -- what GetNextFrequency hands the source retune by retune, wrapping (frequencyTable.cpp:38-46) -- and the
+    records are those of the same launch with the centres passed per buffer, byte for byte, and the oracle's; with and
+    without sequence ids, from device memory and from the pinned slot."""
+    nb, count, first = 300, 37, 11
+    table = 1e9 + 6e6 * np.arange(count) + 0.25
+    fc = table[(first + np.arange(nb)) % count]
+    x = synth.cfloat_batch(n, nb, seed=77, sigma=0.05)
+    raw = synth.quantize(x, kind)
+    enob = 12
+    thr = tol.pick_threshold(oracle_mod.Oracle(n, FS, 1e9, kind=kind, enob=enob).run(raw)[0], n, start=12.0)
+    seq = np.arange(nb, dtype=np.uint64) * 3 + 5
+    _, ref_seq, _ = oracle_mod.Oracle(n, FS, thr, kind=kind, enob=enob).run(raw, fc, seq)
+    _, ref_idx, _ = oracle_mod.Oracle(n, FS, thr, kind=kind, enob=enob).run(raw, fc, np.arange(nb, dtype=np.uint64))
+    assert len(ref_seq) > 50 and len(np.unique(ref_seq["freq_hz"] // 6000000)) > 20
+    d = _to_dev(torch_cuda, raw)
+    with Plan(n, FS, thr, kind=kind, enob=enob, max_batch=nb, max_hits=1 << 16) as plan:
+        with pytest.raises(capi.ScannerError) as e:   # no table yet
+            plan.submit_device(0, d, nb, first_index=0)
+        assert e.value.status == capi.E_STATE
+        plan.set_table(table)
+        with pytest.raises(capi.ScannerError) as e:   # outside the table
+            plan.submit_device(0, d, nb, first_index=count)
+        assert e.value.status == capi.E_INVALID
+        for ids, ref in ((seq, ref_seq), (None, ref_idx)):
+            plan.submit_device(0, d, nb, fc, ids)
+            _, explicit, _ = plan.collect(0, want_power=False, hit_cap=1 << 16)
+            plan.submit_device(1, d, nb, seq_ids=ids, first_index=first)
+            _, indexed, _ = plan.collect(1, want_power=False, hit_cap=1 << 16)
+            assert indexed.tobytes() == explicit.tobytes()
+            _assert_hits_equal(indexed, ref)
+            hb = plan.host_buffer(2)
+            hb[: raw.nbytes] = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+            plan.submit(2, nb, seq_ids=ids, first_index=first)
+            _, staged, _ = plan.collect(2, want_power=False, hit_cap=1 << 16)
+            assert staged.tobytes() == explicit.tobytes()
+        # an explicit submit after an indexed one on the same slot, and the other way round (the two generations of a slot)
+        plan.submit_device(0, d, nb, seq_ids=seq, first_index=first)
+        plan.collect(0, want_power=False, want_hits=False)
+        plan.submit_device(0, d, nb, fc + 1e6, seq)
+        _, shifted, _ = plan.collect(0, want_power=False, hit_cap=1 << 16)
+        assert np.array_equal(shifted["freq_hz"], ref_seq["freq_hz"] + 1000000)
+        # a pending submit reads the table: it cannot be replaced under it
+        plan.submit_device(0, d, nb, seq_ids=seq, first_index=first)
+        with pytest.raises(capi.ScannerError) as e:
+            plan.set_table(table + 1.0)
+        assert e.value.status == capi.E_STATE
+        plan.collect(0, want_power=False, want_hits=False)
+        plan.set_table(table[:5] + 2e6)
+        plan.submit_device(0, d, nb, seq_ids=seq, first_index=4)
+        _, small, _ = plan.collect(0, want_power=False, hit_cap=1 << 16)
+        _, ref_small, _ = oracle_mod.Oracle(n, FS, thr, kind=kind, enob=enob).run(raw, (table[:5] + 2e6)[(4 + np.arange(nb)) % 5], seq)
+        _assert_hits_equal(small, ref_small)
+
+
+@pytest.mark.parametrize("n,nb", [(16, (1 << 19) + 5), (32, 1 << 19), (64, 40000)])
+def test_total_of_a_many_buffer_launch_without_the_walk(torch_cuda, oracle_mod, n, nb):
+    """From 2^19 buffers per launch the batch's total is summed on the GPU and scn_collect without trigger flags reads one word
+    instead of walking the counts (scn_hit_total_kernel): the same number as the walk's (scn_collect with trigger flags; every
+    collect of the smaller launch), as the number of records, and as the oracle's, launch after launch on the same slot (the
+    kernel's two device words return to zero)."""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((nb, n, 2), dtype=np.float32) * np.float32(0.05)).view(np.complex64).reshape(nb, n)
+    # a threshold far enough into the noise's own tail that its guard band is empty over ALL the launch's bins: a few hundred hits
+    p_ref = oracle_mod.Oracle(n, FS, 1e9).run(x, threads=8)[0]
+    vals = p_ref[:, tol.evaluated_mask(n, 0.75, 4)]
+    thr = tol.pick_threshold(p_ref, n, start=float(np.partition(vals.ravel(), -3000)[-3000]))
+    _, ref, _ = oracle_mod.Oracle(n, FS, thr).run(x, threads=8)
+    assert len(ref) > 100
+    d = _to_dev(torch_cuda, x)
+    with Plan(n, FS, thr, max_batch=nb, max_hits=max(len(ref), 1) + 64) as plan:
+        plan.set_table(np.full(1, 1e9))
+        for rep in range(3):
+            for slot in (0, 1):
+                plan.submit_device(slot, d, nb, first_index=0)
+            for slot in (0, 1):
+                assert plan.collect_counts(slot) == len(ref)       # no trigger flags: the word the GPU left
+        part = nb - 7 if n == 64 else (1 << 19) + 1    # another count on the same slot (not a multiple of four) ...
+        _, ref_part, _ = oracle_mod.Oracle(n, FS, thr).run(x[:part], threads=8)
+        with Plan(n, FS, thr, max_batch=part, max_hits=len(ref) + 64) as small:   # ... and in a plan of its own, whatever the first one left behind
+            small.set_table(np.full(1, 1e9))
+            small.submit_device(0, d[: part * n * 8], part, first_index=0)
+            assert small.collect_counts(0) == len(ref_part)
+        plan.submit_device(0, d[: part * n * 8], part, first_index=0)
+        assert plan.collect_counts(0) == len(ref_part)
+        keep = nb // 3
+        plan.submit_device(0, d[: keep * n * 8], keep, first_index=0)         # (below 2^19 buffers: the walk)
+        assert plan.collect_counts(0) == len(oracle_mod.Oracle(n, FS, thr).run(x[:keep], threads=8)[1]) < len(ref)
+        plan.submit_device(0, d, nb, first_index=0)
+        _, hits, trig = plan.collect(0, want_power=False)             # trigger flags: the walk
+        assert plan.last_n_hits == len(ref) == len(hits) and trig.shape == (nb,)

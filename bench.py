@@ -1118,6 +1118,7 @@ def main():
                 "n": n, "batch_per_gpu": shard, "buffers_per_launch": nb, "sample_kind": args.kind,
                 "parallelism": f"table-shard x{world}", "plan_flags": flag_names + ("|SCN_PLAN_OVERLAP_SLOTS" if c4_overlap else ""),
                 "plan_mode": args.plan_mode, "correct_dc": dc, "time_domain": td,
+                "centre_frequencies": "per buffer with every submit" if args.per_buffer_centres else "a run of the plan's GPU-resident frequency table",
                 "rotating_batches": R, "footprint_MiB": round(R * step_bytes / 2**20),
             },
             "swept_GHz_per_s": round(buffers_per_s * USE_BW * FS / 1e9, 1),

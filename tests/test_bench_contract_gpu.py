@@ -116,3 +116,17 @@ def test_bench_on_the_workers_kind_of_plan_and_in_time_domain_mode():
     check_common(d)
     assert d["roofline"]["kernel"] == "scn_time_domain_wave_kernel<SCN_K_BYTE_COMPLEX, false>"
     assert d["roofline"]["algorithmic_bytes_per_sample"] == 2 and d["config"]["time_domain"] is True
+
+
+def test_bench_with_the_centres_per_buffer_and_from_the_table():
+    """the default legs name a run of the plan's GPU-resident frequency table per submit (scn_submit_device_indexed);
+    --per-buffer-centres sends them with every submit as until round 4: the same detections either way"""
+    extra = ["--n", "128", "--no-cpu-baseline", "--no-configs-leg"]
+    t = run_bench(extra, batch=("--batch", "4096"))
+    b = run_bench(extra + ["--per-buffer-centres"], batch=("--batch", "4096"))
+    check_common(t)
+    check_common(b)
+    assert "table" in t["config"]["centre_frequencies"] and "per buffer" in b["config"]["centre_frequencies"]
+    assert t["final_sweep_hits"] == b["final_sweep_hits"] > 0
+    # (the records legs driven from the bench's own process go through the same two forms)
+    assert t["with_hit_records"]["python_torch_runtime"]["hits_per_step"] == b["with_hit_records"]["python_torch_runtime"]["hits_per_step"] > 0

@@ -63,6 +63,7 @@ def run(budget, seed, plans=None):
     budget: seconds of wall clock (the long runs of this script), or -- with `plans` -- exactly that many plans whatever the
     box's speed (the slice in the GPU suite: the same cases on every box)."""
     rng = np.random.default_rng(seed)
+    rng_t = np.random.default_rng(seed + 7919)   # the frequency-table choices (round 5) draw from a stream of their own: the cases of a seed stay the cases they were
     t_end = time.time() + (budget if plans is None else 1e9)
     cases = launches = 0
     near_misses.clear()
@@ -92,6 +93,11 @@ def run(budget, seed, plans=None):
         try:
             with Plan(n, FS, thr, kind=kind, enob=enob, correct_dc=dc, max_batch=max_nb, max_hits=max_hits, flags=flags) as plan:
                 pend = {}
+                # four plans in ten keep a frequency table on the GPU (scn_plan_set_table) and their launches name a run of it
+                # (scn_submit_device_indexed: entry (first + b) % count for buffer b) or send their centres, launch by launch
+                table = (50e6 + 6e6 * rng_t.permutation(int(rng_t.integers(1, 2 * max_nb + 2))) + float(rng_t.integers(0, 1000))) if rng_t.random() < 0.4 else None
+                if table is not None:
+                    plan.set_table(table)
 
                 def check(slot, raw, fc, seq, nb):
                     want_p, want_h = bool(out_flags & 1), bool(out_flags & 2)
@@ -145,7 +151,16 @@ def run(budget, seed, plans=None):
                         raw = (raw + int(rng.integers(1, 60))).astype(raw.dtype)   # positive mean (the negative-sum quirk has its own test)
                     fc = 50e6 + 6e6 * np.arange(nb) + float(rng.integers(0, 1000))
                     seq = (np.arange(nb) + int(rng.integers(0, 1 << 40))).astype(np.uint64)
-                    plan.submit_device(s, dev(raw) if nb else torch.zeros(8, dtype=torch.uint8, device="cuda"), nb, fc, seq)
+                    d_raw = dev(raw) if nb else torch.zeros(8, dtype=torch.uint8, device="cuda")
+                    if table is not None and rng_t.random() < 0.7:
+                        first = int(rng_t.integers(0, len(table)))
+                        fc = table[(first + np.arange(nb)) % len(table)]
+                        ids = None if rng_t.random() < 0.5 else seq          # without ids a buffer's id is its index in the launch
+                        if ids is None:
+                            seq = np.arange(nb, dtype=np.uint64)
+                        plan.submit_device(s, d_raw, nb, seq_ids=ids, first_index=first)
+                    else:
+                        plan.submit_device(s, d_raw, nb, fc, seq)
                     pend[s] = (raw, fc, seq, nb)
                     launches += 1
                 for s in sorted(pend):

@@ -76,6 +76,10 @@ def test_loads_and_reports_errors(built_lib):
         assert L.scn_plan_create(C.byref(d), C.byref(h)) == capi.E_INVALID and b"16 to 65536" in L.scn_last_error()
     d.n, d.sample_kind = 4096, 9
     assert L.scn_plan_create(C.byref(d), C.byref(h)) == capi.E_INVALID
+    # the frequency-table entry points refuse a null plan before they touch the device
+    assert L.scn_plan_set_table(None, None, 0) == capi.E_INVALID and b"null plan" in L.scn_last_error()
+    assert L.scn_submit_indexed(None, 0, 1, 0, None) == capi.E_INVALID
+    assert L.scn_submit_device_indexed(None, 0, None, 1, 0, None, None) == capi.E_INVALID
 
 
 def test_size_paths(built_lib):

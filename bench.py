@@ -143,25 +143,51 @@ def cpu_baseline(args, raw_host, kind_oracle, enob, budget_s, dc=False):
     }
 
 
-def welch_leg(torch, dev, local_rank, seed, npsd, steps, warmup, rotate=0, pinned=False, sync=None):
+class ParityError(Exception):
+    """A timed leg's output differs from the oracle's: the number is void and the run exits non-zero."""
+
+
+WELCH_KINDS = {"cfloat": (4, 8, None), "int16": (3, 4, 2047.0), "int16p": (2, 4, 2047.0), "int8": (1, 2, 127.0)}   # SCN_KIND, B/sample, full scale
+
+
+def welch_leg(torch, dev, local_rank, seed, npsd, steps, warmup, rotate=0, pinned=False, sync=None, kind="cfloat", dc=False, check=None):
     """C5 steps on this GPU: a step = one submit of `npsd` PSDs = (npsd*16 + 1) * 32768 complex samples, device-resident (rotated
     over R streams past the Infinity Cache) or, with `pinned`, staged from pinned host memory through the captured hipGraph
-    (PCIe-bound).  Returns (seconds for `steps` steps, new samples per step); sync() brackets the timed region (N > 1)."""
+    (PCIe-bound).  Returns (seconds for `steps` steps, new samples per step); sync() brackets the timed region (N > 1).
+    check: a dict to receive the comparison of the LAST timed step's first and last PSD with the CPU oracle (outside the timed
+    region; raises ParityError when they differ by more than the parity bar)."""
     from scanner_amd import WelchPlan
 
     N, K = 65536, 16
-    plan = WelchPlan(N, K, max_psd=npsd, device_id=local_rank)
+    okind, bps, full_scale = WELCH_KINDS[kind]
+    enob = 8 if kind == "int8" else 12
+    plan = WelchPlan(N, K, max_psd=npsd, device_id=local_rank, kind=okind, enob=enob, correct_dc=dc)
     m = plan.samples(npsd)
     new_samples = npsd * K * (N // 2)
-    R = rotate or max(2, -(-(3 << 29) // (m * 8)))
+    R = rotate or max(2, -(-(3 << 29) // (m * bps)))
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
+    blk = torch.rand((m // (N // 2), 1, 1), generator=g, device=dev) * 0.6 + 0.4   # a level per delivery block: a PSD built from the wrong segments shows
+
+    def stream():
+        x = (torch.randn((m // (N // 2), N // 2, 2), generator=g, device=dev) * 0.05) * blk
+        if full_scale is None:
+            return x.reshape(m, 2).contiguous()
+        dt = torch.int8 if kind == "int8" else torch.int16
+        q = torch.clamp(torch.round(x * full_scale), -full_scale - 1, full_scale).to(dt)
+        if kind == "int16p":   # planar per delivery block: I[hop] then Q[hop]
+            q = q.permute(0, 2, 1)
+        return q.contiguous().reshape(-1)
+
     if pinned:
+        host_in = []
         for s in range(2):
             hb = plan.host_buffer(s)
-            hb[:m] = (torch.randn((m, 2), generator=g, device=dev) * 0.05).cpu().numpy().view(np.complex64).reshape(-1)
+            flat = stream().cpu().numpy().view(np.uint8).reshape(-1)
+            hb.view(np.uint8)[: flat.size] = flat
+            host_in.append(flat)
     else:
-        xs = [torch.randn((m, 2), generator=g, device=dev) * 0.05 for _ in range(R)]
+        xs = [stream() for _ in range(R)]
         outs = [torch.empty((npsd, N), dtype=torch.float32, device=dev) for _ in range(R)]
     torch.cuda.synchronize()
     pending = [False, False]
@@ -196,16 +222,41 @@ def welch_leg(torch, dev, local_rank, seed, npsd, steps, warmup, rotate=0, pinne
     if sync:
         sync()
     elapsed = time.perf_counter() - t0
+    if check is not None and steps > 0:
+        # the LAST timed step's first and last PSD against the CPU oracle (K1 per delivery block, window, FFT, mean |X|^2, dB)
+        from oracle import oracle as O
+        from tests import tolerances as tol
+
+        last = steps - 1
+        if pinned:
+            plan.submit(last & 1, npsd)       # the slot's pinned input is still the last step's: replay it for its PSDs
+            got = plan.collect(last & 1)
+            raw = host_in[last & 1]
+        else:
+            got = outs[last % R].cpu().numpy()
+            raw = xs[last % R].cpu().numpy().view(np.uint8).reshape(-1)
+        hop_b = (N // 2) * bps
+        worst = 0.0
+        try:
+            for p in sorted({0, npsd - 1}):
+                ref = O.welch_raw(raw[p * K * hop_b:(p * K + K + 1) * hop_b], okind, enob, dc, N, K, 1)
+                worst = max(worst, tol.compare_spectra(got[p:p + 1], ref)["max_rel_power_vs_max_bin_mean"])
+            check.update({"match": True, "psds_checked": sorted({0, npsd - 1}), "max_rel_power_vs_max_bin_mean": worst, "bar": tol.REL_POWER,
+                          "against": "oracle (CPU restatement), the last timed step's output"})
+        except AssertionError as e:
+            check.update({"match": False, "detail": str(e)[:300]})
+            plan.close()
+            raise ParityError(f"C5 output differs from the oracle: {str(e)[:300]}")
     plan.close()
     return elapsed, new_samples
 
 
-def welch_roofline(elapsed, steps, new_samples, npsd):
+def welch_roofline(elapsed, steps, new_samples, npsd, kind="cfloat"):
     N, K = 65536, 16
-    algo = new_samples * 8 + npsd * N * 4  # 8 B per NEW sample + 4N/K per segment
+    algo = new_samples * WELCH_KINDS[kind][1] + npsd * N * 4  # 8 (4, 2) B per NEW sample + 4N/K per segment
     ms = elapsed / steps * 1e3
     achieved = algo / (ms * 1e-3) / 1e9
-    prof = _tracked(f"welch/{N}/{K}/{npsd}")
+    prof = _tracked(f"welch/{N}/{K}/{npsd}" + ("" if kind == "cfloat" else f"/{kind}"))
     r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_is": "frac_wall (host wall time per step: the Welch plan exposes no stream to put events on)",
          "kernel": "scn_welch_cols_kernel + scn_welch_rows_kernel (two-pass four-step FFT: the work "
@@ -229,24 +280,32 @@ def welch_main(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     npsd = args.welch_psd
-    elapsed, new_samples = welch_leg(torch, dev, local_rank, 5 + rank, npsd, args.steps, args.warmup, args.rotate, args.welch_pinned,
-                                     sync=dist.barrier if world > 1 else None)
+    check = {} if rank == 0 else None
+    rc = 0
+    try:
+        elapsed, new_samples = welch_leg(torch, dev, local_rank, 5 + rank, npsd, args.steps, args.warmup, args.rotate, args.welch_pinned,
+                                         sync=dist.barrier if world > 1 else None, kind=args.kind, dc=args.dc, check=check)
+    except ParityError as e:
+        print(f"bench.py: {e}", file=sys.stderr)
+        sys.exit(3)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     if rank == 0:
-        roof, ms = welch_roofline(elapsed, args.steps, new_samples, npsd)
+        roof, ms = welch_roofline(elapsed, args.steps, new_samples, npsd, args.kind)
         emit({
             "metric": "Msamples/s (new complex samples through 65536-pt 50%-overlap Welch PSD)",
             "value": round(world * new_samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C5: 65536-pt 50%-overlap Welch PSD, K=16, {npsd} PSDs per submit, Blackman-Harris, "
+            "config": {"workload": f"C5: 65536-pt 50%-overlap Welch PSD, K=16, {npsd} PSDs per submit, Blackman-Harris, {args.kind} samples"
+                                   f"{' with DC removal per delivery block' if args.dc and args.kind != 'cfloat' else ''}, "
                                    f"{'pinned host staging + hipGraph replay' if args.welch_pinned else 'stream resident in HBM'}; "
                                    f"independent stream per GPU (replicas)",
-                       "n": 65536, "segments_per_psd": 16, "psd_per_submit": npsd, "pinned": bool(args.welch_pinned)},
+                       "n": 65536, "segments_per_psd": 16, "psd_per_submit": npsd, "pinned": bool(args.welch_pinned), "kind": args.kind},
             "roofline": roof,
+            "c5_check": check,
         })
     if world > 1:
         dist.barrier()
@@ -365,11 +424,14 @@ def config_legs(torch, dev, local_rank, steps=200):
                                          "sweep, each slot on its own stream (SCN_PLAN_OVERLAP_SLOTS), three in flight: launches overlap, so the "
                                          "step is shorter than one kernel's own begin-to-end time (frac_kernel_rocprof)")
         # C5: 65536-pt 50%-overlap Welch PSD, 32 PSDs per submit, stream resident in HBM
-        el, new = welch_leg(torch, dev, local_rank, 5, 32, max(50, steps // 2), 10)
+        c5_check = {}
+        el, new = welch_leg(torch, dev, local_rank, 5, 32, max(50, steps // 2), 10, check=c5_check)
         roof, ms = welch_roofline(el, max(50, steps // 2), new, 32)
         legs["c5"] = dict({"value": round(new / (ms * 1e-3) / 1e6, 1), "unit": "Msamples/s (new samples)", "steps": max(50, steps // 2),
-                           "ms_per_step": round(ms, 5)}, **roof,
+                           "ms_per_step": round(ms, 5)}, **roof, c5_check=c5_check,
                           workload="C5: 65536-pt 50%-overlap Welch PSD, K=16, 32 PSDs per submit, stream resident in HBM")
+    except ParityError:  # a leg whose output is wrong is not a side matter: the run fails
+        raise
     except Exception as e:  # a side leg must not cost the run its line
         legs["error"] = f"{type(e).__name__}: {e}"[:300]
     return legs
@@ -1197,7 +1259,12 @@ def main():
         out["overlap"] = overlap
         out["hits_only"] = hits_only
         if world == 1 and not c4 and not args.no_configs_leg and (n, args.kind, nb) == (4096, "cfloat", 8192):
-            out["configs"] = config_legs(torch, dev, local_rank)  # C3, the C4 per-GPU share and C5 beside the C2 headline
+            try:
+                out["configs"] = config_legs(torch, dev, local_rank)  # C3, the C4 per-GPU share and C5 beside the C2 headline
+            except ParityError as e:
+                print(f"bench.py: {e}", file=sys.stderr)
+                plan.close()
+                sys.exit(3)
         # the reference's CPU path beside the GPU number, in the same run on the same box: on rank 0 at every N (north_star; the
         # other ranks wait at the closing barrier meanwhile -- it is outside every timed region)
         if not args.no_cpu_baseline and not td:

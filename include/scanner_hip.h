@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define SCN_ABI_VERSION 4 /* 3: SCN_NUM_SLOTS 4, scn_gather_hits_device, scn_gather_fetch, scn_size_path; 4: scn_plan_set_table, scn_submit*_indexed */
+#define SCN_ABI_VERSION 5 /* 3: SCN_NUM_SLOTS 4, scn_gather_hits_device, scn_gather_fetch, scn_size_path; 4: scn_plan_set_table, scn_submit*_indexed;
+                             5: scn_welch_desc.sample_kind / enob / correct_dc (carved out of its reserved words: same size, zero = the
+                             version-4 behaviour), scn_welch_partition */
 
 /* status codes */
 enum {
@@ -296,13 +298,20 @@ int scn_hackrf_sweep_fixup(void *transfer, uint32_t valid_length, uint32_t scan_
 /* ------------------------------------------------------------------------------------
  * Streaming Welch PSD (BASELINE config 5).  No counterpart in the reference -- it never
  * overlaps or averages -- so these entry points replace nothing; they
- * reuse its arithmetic: the window of process.cpp:14-21, the forward FFT of fft.cpp:20-25,
- * the dB map of utility.cpp:86-98.  Definition: segments of n complex-float samples every
- * n/2 (50 % overlap), |X|^2 averaged over segments_per_psd consecutive segments, output
- * psd_db[k] = 5*log10(mean |X[k]|^2), natural bin order.  A submit of n_psd PSDs consumes
- * (n_psd*segments_per_psd + 1) * n/2 contiguous samples.  Same slot / status conventions as
- * scn_plan.  The pinned path (scn_welch_submit) replays a captured hipGraph:
- * H2D copy -> column kernel -> row kernel -> D2H copy of the PSDs.
+ * reuse its arithmetic: the converters of utility.cpp:9-84, the window of process.cpp:14-21,
+ * the forward FFT of fft.cpp:20-25, the dB map of utility.cpp:86-98.  Definition: segments of
+ * n samples every n/2 (50 % overlap), |X|^2 averaged over segments_per_psd consecutive
+ * segments, output psd_db[k] = 5*log10(mean |X[k]|^2), natural bin order.  A submit of n_psd
+ * PSDs consumes (n_psd*segments_per_psd + 1) * n/2 contiguous samples.
+ * Wire formats: the stream arrives as a device front-end delivers it (int8 HackRF
+ * hackRFSource.cpp:261, int16 bladeRF bladerfSource.cpp:297, planar int16 SDRplay
+ * sdrplaySource.cpp:197, float Airspy airspySource.cpp:197), in DELIVERY BLOCKS of n/2 samples
+ * -- one SampleQueue::AppendSamples call each (messageQueue.h:190-237) -- back to back, and K1
+ * is applied per block on the GPU: with correct_dc the integer mean removed is the block's
+ * (utility.cpp:70-79 sums over the call's count), planar int16 is I[n/2] then Q[n/2] per
+ * block.  Float samples are taken as they are (messageQueue.h:229-236).
+ * Same slot / status conventions as scn_plan.  The pinned path (scn_welch_submit) replays a
+ * captured hipGraph: H2D copy -> (block sums) -> column kernel -> row kernel -> D2H copy of the PSDs.
  * ------------------------------------------------------------------------------------ */
 typedef struct scn_welch_desc {
   uint32_t struct_size;
@@ -311,19 +320,26 @@ typedef struct scn_welch_desc {
   uint32_t window_type;      /* 0 -> SCN_WIN_BLACKMAN_HARRIS */
   uint32_t max_psd;          /* PSDs per submit (>= 1) */
   int32_t device_id;
-  uint32_t reserved[4];
+  uint32_t sample_kind;      /* SCN_KIND_*; 0 -> SCN_KIND_FLOAT_COMPLEX */
+  uint32_t enob;             /* effective bits of the integer kinds (scan.cpp:138,183); 0 -> 12 (int16) / 8 (int8) */
+  uint32_t correct_dc;       /* SampleQueue correctDCOffset, per delivery block; ignored for float samples */
+  uint32_t reserved[1];
 } scn_welch_desc;
 
 typedef struct scn_welch scn_welch;
 
 int scn_welch_create(const scn_welch_desc *desc, scn_welch **out);
 int scn_welch_destroy(scn_welch *w);
-/* complex samples one submit of n_psd PSDs consumes */
+/* complex samples one submit of n_psd PSDs consumes (times 2 / 4 / 8 bytes per sample of the plan's wire format) */
 int scn_welch_samples(const scn_welch *w, uint32_t n_psd, size_t *n_samples);
-/* pinned input staging slot (max_psd PSDs worth of samples), plan-owned */
+/* How a submit of n_psd PSDs is split over workgroups (what a caller sizing max_psd, and the parity tests, want to know):
+ * *parts = workgroups sharing the K segments of one PSD's row tile (fixed at create; > 1 adds the combine kernel),
+ * *column_groups / *segments_per_group = the column kernel's contiguous runs of segments (the last group ragged); each may be NULL. */
+int scn_welch_partition(const scn_welch *w, uint32_t n_psd, uint32_t *parts, uint32_t *column_groups, uint32_t *segments_per_group);
+/* pinned input staging slot (max_psd PSDs worth of samples in the plan's wire format), plan-owned */
 int scn_welch_host_buffer(scn_welch *w, int slot, void **ptr, size_t *bytes);
 int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd);
-/* samples already in device memory; d_psd_db optional device destination (n_psd*n floats) */
+/* samples (the plan's wire format) already in device memory; d_psd_db optional device destination (n_psd*n floats) */
 int scn_welch_submit_device(scn_welch *w, int slot, const void *d_samples, uint32_t n_psd,
                             float *d_psd_db);
 /* wait and fetch the n_psd*n dB values (psd_db may be NULL to only wait) */

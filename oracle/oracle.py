@@ -356,6 +356,25 @@ def welch(x_c64, n=65536, k=16, n_psd=1):
     return out
 
 
+def welch_convert(raw, kind, enob, correct_dc, hop):
+    """K1 of a Welch stream: the raw stream is a run of DELIVERY BLOCKS of `hop` samples (one AppendSamples call each,
+    messageQueue.h:190-237), each converted by the reference's converter for `kind` (utility.cpp:9-84; with correct_dc the
+    integer mean removed is the block's own).  Returns the complex64 stream."""
+    if kind == KIND_FLOAT_COMPLEX:
+        return np.ascontiguousarray(raw).view(np.complex64).reshape(-1).copy()
+    raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+    per = raw_bytes_per_sample(kind) * hop
+    assert raw.size % per == 0, (raw.size, per)
+    conv = Oracle(hop, kind=kind, enob=enob, correct_dc=correct_dc)
+    dt = np.int8 if kind == KIND_BYTE_COMPLEX else np.int16
+    return np.concatenate([conv.convert(raw[b * per:(b + 1) * per].view(dt)) for b in range(raw.size // per)])
+
+
+def welch_raw(raw, kind, enob, correct_dc, n=65536, k=16, n_psd=1):
+    """BASELINE C5 on a wire-format stream: welch_convert (K1 per delivery block of n/2 samples) then welch."""
+    return welch(welch_convert(raw, kind, enob, correct_dc, n // 2), n, k, n_psd)
+
+
 def ref64_welch(x_c64, window_f32, n=65536, k=16, n_psd=1):
     """float64 evaluation of the same definition."""
     x = np.asarray(x_c64).astype(np.complex128)

@@ -20,7 +20,7 @@ OUT_SPECTRUM, OUT_HITS = 1, 2
 PLAN_OVERLAP_SLOTS = 4  # each slot on its own compute stream (scanner_hip.h)
 DC_IGNORE_NONE = 0xFFFFFFFF
 NUM_SLOTS = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 PATH_UNSUPPORTED, PATH_FUSED, PATH_FOUR_STEP, PATH_STAGED, PATH_BLUESTEIN = range(5)
 COMM_ID_BYTES = 128
 
@@ -63,7 +63,10 @@ class WelchDesc(C.Structure):
         ("window_type", C.c_uint32),
         ("max_psd", C.c_uint32),
         ("device_id", C.c_int32),
-        ("reserved", C.c_uint32 * 4),
+        ("sample_kind", C.c_uint32),
+        ("enob", C.c_uint32),
+        ("correct_dc", C.c_uint32),
+        ("reserved", C.c_uint32 * 1),
     ]
 
 
@@ -97,6 +100,7 @@ SYMBOLS = {
     "scn_welch_create": (C.c_int, [C.POINTER(WelchDesc), C.POINTER(_vp)]),
     "scn_welch_destroy": (C.c_int, [_vp]),
     "scn_welch_samples": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_size_t)]),
+    "scn_welch_partition": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "scn_welch_host_buffer": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "scn_welch_submit": (C.c_int, [_vp, C.c_int, C.c_uint32]),
     "scn_welch_submit_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, _vp]),

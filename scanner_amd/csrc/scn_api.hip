@@ -1233,6 +1233,7 @@ struct WelchSlot {
   hipStream_t stream = nullptr;    // the pinned path's own stream: this slot's H2D overlaps the other slot's kernels
   void *d_work = nullptr;          // ... which needs a work buffer of its own ([max_psd*K][n] complex)
   float *d_partial = nullptr;      // ... and its own partial sums
+  int *d_dc = nullptr;             // ... and its own block sums (correct_dc)
   uint32_t graph_npsd = 0;
   hipEvent_t done = nullptr;
   bool pending = false;
@@ -1251,6 +1252,10 @@ struct scn_welch {
   float *d_partial = nullptr;  // [parts][max_psd][n] partial power sums (row kernel -> combine kernel); shared by the slots
                                // through stream order on the device path, per-slot copies on the pinned path
   uint32_t parts = 1;
+  uint32_t bytes_per_sample = 8;
+  float scale = 1.0f;      // K1's 1/max
+  bool dc = false;         // correct_dc on an integer wire format
+  int *d_dc = nullptr;     // [max_psd*K + 1][2] block sums (device path; the pinned path's slots own theirs)
   WelchSlot slot[SCN_NUM_SLOTS];
 };
 
@@ -1260,8 +1265,10 @@ size_t welch_samples(const scn_welch *w, uint32_t n_psd) {
 }
 
 int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd, hipStream_t stream, void *d_work,
-                  float *d_partial) {
+                  float *d_partial, int *d_dc) {
   ScnWelchArgs a;
+  a.scale = w->scale;
+  a.dc_sums = d_dc;
   a.partial = d_partial;
   a.parts = w->parts;
   a.in = d_in;
@@ -1274,7 +1281,7 @@ int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd, 
   a.k = w->d.segments_per_psd;
   a.n_psd = n_psd;
   a.inv_k = 1.0f / (float)w->d.segments_per_psd;
-  SCN_HIP(scn_launch_welch(a, w->num_cus, stream));
+  SCN_HIP(scn_launch_welch((int)w->d.sample_kind, w->dc, a, w->num_cus, stream));
   return SCN_OK;
 }
 
@@ -1293,6 +1300,12 @@ int scn_welch_create(const scn_welch_desc *desc, scn_welch **out) {
   if (desc->struct_size != sizeof(scn_welch_desc)) return fail(SCN_E_INVALID, "scn_welch_desc.struct_size mismatch");
   scn_welch_desc d = *desc;
   if (!d.window_type) d.window_type = SCN_WIN_BLACKMAN_HARRIS;
+  // (sample_kind, enob, correct_dc were reserved words until ABI version 5: a version-4 caller's zeros mean float samples)
+  if (!d.sample_kind) d.sample_kind = SCN_KIND_FLOAT_COMPLEX;
+  if (d.sample_kind < SCN_KIND_BYTE_COMPLEX || d.sample_kind > SCN_KIND_FLOAT_COMPLEX) return fail(SCN_E_INVALID, "unsupported sample_kind %u", d.sample_kind);
+  if (!d.enob) d.enob = d.sample_kind == SCN_KIND_BYTE_COMPLEX ? 8u : 12u;
+  if (d.sample_kind != SCN_KIND_FLOAT_COMPLEX && (d.enob < 1 || d.enob > (d.sample_kind == SCN_KIND_BYTE_COMPLEX ? 8u : 16u)))
+    return fail(SCN_E_INVALID, "enob %u out of range for sample_kind %u", d.enob, d.sample_kind);
   if (d.n != 65536) return fail(SCN_E_INVALID, "unsupported Welch segment length %u (65536)", d.n);
   if (d.segments_per_psd < 1 || d.max_psd < 1) return fail(SCN_E_INVALID, "segments_per_psd and max_psd must be >= 1");
   if (d.window_type != SCN_WIN_BLACKMAN_HARRIS && d.window_type != SCN_WIN_RECTANGULAR)
@@ -1305,6 +1318,9 @@ int scn_welch_create(const scn_welch_desc *desc, scn_welch **out) {
   if (!w) return fail(SCN_E_NOMEM, "out of host memory");
   w->d = d;
   w->hop = d.n / 2;
+  w->bytes_per_sample = (uint32_t)bytes_per_sample(d.sample_kind);
+  w->scale = convert_scale(d.sample_kind, d.enob);
+  w->dc = d.correct_dc && d.sample_kind != SCN_KIND_FLOAT_COMPLEX;
   std::vector<float> win;
   build_window(d.window_type, d.n, win);
   std::vector<float> tw(2 * (size_t)d.n);
@@ -1327,6 +1343,7 @@ int scn_welch_create(const scn_welch_desc *desc, scn_welch **out) {
     // submit: 68.5 / 75.9 / 73.7 Gsamples/s with 1 / 2 / 4 parts; from 16 PSDs per submit up the split only costs)
     while (w->parts < 4u && w->parts * 2u <= d.segments_per_psd && 16u * d.max_psd * w->parts < (uint32_t)w->num_cus) w->parts *= 2u;
     if (w->parts > 1 && (e = hipMalloc(&w->d_partial, sizeof(float) * (size_t)d.n * d.max_psd * w->parts)) != hipSuccess) break;
+    if (w->dc && (e = hipMalloc(&w->d_dc, sizeof(int) * 2u * ((size_t)d.max_psd * d.segments_per_psd + 1u))) != hipSuccess) break;
     if ((e = hipMemcpyAsync(w->d_window, win.data(), sizeof(float) * d.n, hipMemcpyHostToDevice, w->stream)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(w->d_twiddle, tw.data(), sizeof(float) * 2 * d.n, hipMemcpyHostToDevice, w->stream)) != hipSuccess) break;
     e = hipStreamSynchronize(w->stream);
@@ -1355,12 +1372,14 @@ int scn_welch_destroy(scn_welch *w) {
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.d_work) (void)hipFree(s.d_work);
     if (s.d_partial) (void)hipFree(s.d_partial);
+    if (s.d_dc) (void)hipFree(s.d_dc);
     if (s.stream) (void)hipStreamDestroy(s.stream);
   }
   if (w->d_window) (void)hipFree(w->d_window);
   if (w->d_twiddle) (void)hipFree(w->d_twiddle);
   if (w->d_work) (void)hipFree(w->d_work);
   if (w->d_partial) (void)hipFree(w->d_partial);
+  if (w->d_dc) (void)hipFree(w->d_dc);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
   return SCN_OK;
@@ -1372,13 +1391,24 @@ int scn_welch_samples(const scn_welch *w, uint32_t n_psd, size_t *n_samples) {
   return SCN_OK;
 }
 
+int scn_welch_partition(const scn_welch *w, uint32_t n_psd, uint32_t *parts, uint32_t *column_groups, uint32_t *segments_per_group) {
+  if (!w) return fail(SCN_E_INVALID, "null welch plan");
+  if (n_psd < 1 || n_psd > w->d.max_psd) return fail(SCN_E_INVALID, "n_psd %u out of range (1..%u)", n_psd, w->d.max_psd);
+  uint32_t groups = 0, per = 0;
+  scn_welch_column_groups(n_psd * w->d.segments_per_psd, w->num_cus, &groups, &per);
+  if (parts) *parts = w->parts;
+  if (column_groups) *column_groups = groups;
+  if (segments_per_group) *segments_per_group = per;
+  return SCN_OK;
+}
+
 int scn_welch_host_buffer(scn_welch *w, int slot, void **ptr, size_t *bytes) {
   int st = welch_check(w, slot);
   if (st) return st;
   if (!ptr) return fail(SCN_E_INVALID, "null argument");
   WelchSlot &s = w->slot[slot];
   SCN_HIP(hipSetDevice(w->d.device_id));
-  const size_t total = welch_samples(w, w->d.max_psd) * 8u;
+  const size_t total = welch_samples(w, w->d.max_psd) * w->bytes_per_sample;
   if (!s.h_in) SCN_HIP(hipHostMalloc(&s.h_in, total, hipHostMallocDefault));
   *ptr = s.h_in;
   if (bytes) *bytes = total;
@@ -1393,7 +1423,7 @@ int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
   if (s.pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit", slot);
   if (!s.h_in) return fail(SCN_E_STATE, "slot %d: scn_welch_host_buffer was never called", slot);
   SCN_HIP(hipSetDevice(w->d.device_id));
-  const size_t in_bytes = welch_samples(w, w->d.max_psd) * 8u, psd_bytes = sizeof(float) * (size_t)w->d.n * w->d.max_psd;
+  const size_t in_bytes = welch_samples(w, w->d.max_psd) * w->bytes_per_sample, psd_bytes = sizeof(float) * (size_t)w->d.n * w->d.max_psd;
   if (!s.d_in) SCN_HIP(hipMalloc(&s.d_in, in_bytes));
   if (!s.d_psd) SCN_HIP(hipMalloc(&s.d_psd, psd_bytes));
   if (!s.h_psd) SCN_HIP(hipHostMalloc(&s.h_psd, psd_bytes, hipHostMallocDefault));
@@ -1401,6 +1431,7 @@ int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
   if (!s.stream) SCN_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
   if (!s.d_work) SCN_HIP(hipMalloc(&s.d_work, sizeof(float) * 2 * (size_t)w->d.n * w->d.max_psd * w->d.segments_per_psd));
   if (w->parts > 1 && !s.d_partial) SCN_HIP(hipMalloc(&s.d_partial, sizeof(float) * (size_t)w->d.n * w->d.max_psd * w->parts));
+  if (w->dc && !s.d_dc) SCN_HIP(hipMalloc(&s.d_dc, sizeof(int) * 2u * ((size_t)w->d.max_psd * w->d.segments_per_psd + 1u)));
   if (!s.graph || s.graph_npsd != n_psd) {
     // capture the slot's inner loop once per batch size: H2D -> columns -> rows -> D2H
     if (s.graph) {
@@ -1409,9 +1440,9 @@ int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd) {
     }
     hipGraph_t graph = nullptr;
     SCN_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
-    hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, welch_samples(w, n_psd) * 8u, hipMemcpyHostToDevice, s.stream);
+    hipError_t e = hipMemcpyAsync(s.d_in, s.h_in, welch_samples(w, n_psd) * w->bytes_per_sample, hipMemcpyHostToDevice, s.stream);
     int inner = SCN_OK;
-    if (e == hipSuccess) inner = welch_enqueue(w, s.d_in, n_psd, s.d_psd, s.stream, s.d_work, s.d_partial);
+    if (e == hipSuccess) inner = welch_enqueue(w, s.d_in, n_psd, s.d_psd, s.stream, s.d_work, s.d_partial, s.d_dc);
     if (e == hipSuccess && inner == SCN_OK)
       e = hipMemcpyAsync(s.h_psd, s.d_psd, sizeof(float) * (size_t)w->d.n * n_psd, hipMemcpyDeviceToHost, s.stream);
     hipError_t e2 = hipStreamEndCapture(s.stream, &graph);
@@ -1447,7 +1478,7 @@ int scn_welch_submit_device(scn_welch *w, int slot, const void *d_samples, uint3
     d_psd_db = s.d_psd;
   }
   if (!s.done) SCN_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-  st = welch_enqueue(w, d_samples, n_psd, d_psd_db, w->stream, w->d_work, w->d_partial);
+  st = welch_enqueue(w, d_samples, n_psd, d_psd_db, w->stream, w->d_work, w->d_partial, w->d_dc);
   if (st) return st;
   SCN_HIP(hipEventRecord(s.done, w->stream));
   s.pending = true;

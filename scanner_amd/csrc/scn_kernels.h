@@ -75,7 +75,7 @@ hipError_t scn_launch_time_domain(int kind, bool correct_dc, const ScnTdArgs &ar
 
 // Welch PSD (BASELINE C5): 65 536-pt four-step FFT, 50 % overlap, K-segment power average
 struct ScnWelchArgs {
-  const void *in;          // complex-float stream, (n_psd*k + 1) * hop samples
+  const void *in;          // the stream in the plan's wire format, (n_psd*k + 1) delivery blocks of hop samples
   const float *window;     // [65536]
   const scn_v2f *twiddle;  // W_65536^m
   void *work;              // [n_segments][65536] complex: Y[k1][n2] between the two kernels
@@ -84,8 +84,12 @@ struct ScnWelchArgs {
   uint32_t n_segments, hop, k, n_psd;
   uint32_t parts;          // workgroups that share the K segments of one PSD row tile (1: no combine kernel)
   float inv_k;
+  float scale;             // K1's 1/max (utility.cpp:16-17,40-41,64-65); 1 for float samples
+  int *dc_sums;            // [n_segments + 1][2] integer sums per delivery block (correctDC on integer samples), or nullptr
 };
-hipError_t scn_launch_welch(const ScnWelchArgs &args, int num_cus, hipStream_t stream);
+hipError_t scn_launch_welch(int kind, bool correct_dc, const ScnWelchArgs &args, int num_cus, hipStream_t stream);
+// the column kernel's split of a submit: `groups` workgroups per column tile, `per` consecutive segments each (the last ragged)
+void scn_welch_column_groups(uint32_t n_segments, int num_cus, uint32_t *groups, uint32_t *per);
 
 // Ordered hit list (scn_hits.hip): exclusive scan of the per-buffer counts, then one wave per buffer with hits ranks
 // its records by bin (a bitmap in LDS) and writes the completed scn_hit records [first, first + out_cap) of the

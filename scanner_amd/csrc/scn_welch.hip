@@ -24,18 +24,13 @@
 
 #include "scn_device.h"
 
-// tunables, each measured (scripts in git history: welch_variants.sh; profiles/r02_experiments.md, r03_experiments.md section 5)
-#ifndef SCN_WELCH_AUX_IN_POLICY
-#define SCN_WELCH_AUX_IN_POLICY 2
-#endif
-// cache policy of the input stream loads: non-temporal since round 5 -- with the overlapping half of a segment kept in registers
-// (SCN_WELCH_REUSE) a sample is fetched once, and nt then pays like everywhere else: 32 PSDs per step, one box, three rounds:
-// 136.7 .. 139.2 us (round 4's form) / 134.8 .. 136.4 (reuse, default policy) / 126.1 .. 127.0 (reuse + nt)
-constexpr int SCN_WELCH_AUX_IN = SCN_WELCH_AUX_IN_POLICY;
+// tunables, each measured (profiles/r02_experiments.md, r03_experiments.md section 5, r05_welch_ab.txt)
+// cache policy of the input stream loads: non-temporal -- with the overlapping half of a segment kept in registers a sample is
+// fetched once, and nt then pays like everywhere else: 32 PSDs per step, one box, three rounds: 136.7 .. 139.2 us (round 4's
+// form: segments dealt round-robin, every segment loaded whole) / 134.8 .. 136.4 (carry, default policy) / 126.1 .. 127.0
+// (carry + nt) -- profiles/r05_welch_ab.txt
+constexpr int SCN_WELCH_AUX_IN = 2;
 constexpr int SCN_WELCH_PF_CUT = 4;     // how many of the next segment's 8 NEW loads the column kernel issues before pass 1 (the rest after the barrier)
-#ifndef SCN_WELCH_REUSE
-#define SCN_WELCH_REUSE 1               // 0: round 4's form (segments dealt round-robin, every segment loaded whole): the A/B baseline
-#endif
 #define SCN_WELCH_ROWS_WPS 3            // waves per SIMD the row kernel is compiled for
 constexpr int SCN_WELCH_AUX_WK_ST = 0;  // cache policy of the work-buffer stores (columns) ...
 constexpr int SCN_WELCH_AUX_WK_LD = 2;  // ... and loads (rows): read once, non-temporal (measured 152 -> 140 us per 32-PSD step; the store
@@ -46,13 +41,127 @@ constexpr uint32_t WN = 65536;
 constexpr uint32_t WP = 272;  // LDS row pitch (slots): 16 rows of 256 + 16, as exchange 1 of the 4096-pt kernel
 }  // namespace
 
+// ---- the wire formats (K1, utility.cpp:9-84) -----------------------------------------------------------------------------
+// The stream reaches a Welch plan the way it reaches the reference's queue: in DELIVERY BLOCKS, one AppendSamples call each
+// (messageQueue.h:190-237) -- here of hop = N/2 samples, the unit by which a 50 %-overlap consumer advances.  K1 is applied per
+// block: the integer mean removed with correctDC is the block's (utility.cpp:70-79 sums over the call's `count`), and planar
+// int16 is I[hop] then Q[hop] per block (utility.cpp:9-32).  WelchRaw<KIND>::load fetches sample s + 4096 a8 (a8 in [0, 8)) of
+// the block a descriptor covers; conv leaves float(source - dc) -- the scale 1/max is a power of two and rides in the window taps.
+namespace {
+template <int KIND>
+struct WelchRaw;
+template <>
+struct WelchRaw<SCN_K_FLOAT_COMPLEX> {
+  static constexpr uint32_t kBytes = 8;
+  typedef v2f raw_t;
+  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t s, uint32_t a8) {
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, s * 8u, a8 * 32768u, SCN_WELCH_AUX_IN));
+  }
+  static __device__ __forceinline__ cf conv(raw_t r, int, int) { return from_v2f(r); }
+};
+template <>
+struct WelchRaw<SCN_K_SHORT_COMPLEX> {
+  static constexpr uint32_t kBytes = 4;
+  typedef int raw_t;
+  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t s, uint32_t a8) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, s * 4u, a8 * 16384u, SCN_WELCH_AUX_IN);
+  }
+  // float(source - dc), utility.cpp:81-82, in wrapping int arithmetic like the oracle's conv1
+  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im) {
+    const int re = (int)(short)(r & 0xffff), im = r >> 16;
+    return cf{(float)(int)((uint32_t)re - (uint32_t)dc_re), (float)(int)((uint32_t)im - (uint32_t)dc_im)};
+  }
+};
+template <>
+struct WelchRaw<SCN_K_SHORT> {  // planar: I[hop] then Q[hop] per block
+  static constexpr uint32_t kBytes = 4;
+  typedef int raw_t;
+  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t s, uint32_t a8) {
+    const int re = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, a8 * 8192u, SCN_WELCH_AUX_IN);
+    const int im = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, 65536u + a8 * 8192u, SCN_WELCH_AUX_IN);
+    return (re & 0xffff) | (im << 16);
+  }
+  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im) { return WelchRaw<SCN_K_SHORT_COMPLEX>::conv(r, dc_re, dc_im); }
+};
+template <>
+struct WelchRaw<SCN_K_BYTE_COMPLEX> {
+  static constexpr uint32_t kBytes = 2;
+  typedef int raw_t;
+  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, uint32_t s, uint32_t a8) {
+    return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, s * 2u, a8 * 8192u, SCN_WELCH_AUX_IN);
+  }
+  static __device__ __forceinline__ cf conv(raw_t r, int dc_re, int dc_im) {
+    const int re = (int)(signed char)(r & 0xff), im = (int)(signed char)((r >> 8) & 0xff);
+    return cf{(float)(int)((uint32_t)re - (uint32_t)dc_re), (float)(int)((uint32_t)im - (uint32_t)dc_im)};
+  }
+};
+}  // namespace
+
+// ---- DC removal: the integer sums of every delivery block (utility.cpp:15-26, :46-50, :70-76), one more pass over the raw
+// samples -- 2 .. 4 B per sample beside the 20 the transform moves.  grid = 4 quarters x n_blocks, 16-byte loads, one pair of
+// atomics per workgroup into dc_sums (zeroed by the launcher).  int32 sums, as the reference's accumulators (a block of 32 768
+// int16 samples cannot wrap them).
+template <int KIND>
+__global__ __launch_bounds__(256) void scn_welch_dc_kernel(ScnWelchArgs args) {
+  typedef WelchRaw<KIND> L;
+  typedef int v4i __attribute__((__vector_size__(16)));
+  constexpr uint32_t HOP = WN / 2u;
+  __shared__ int part_sums[8];
+  const uint32_t b = blockIdx.x >> 2, part = blockIdx.x & 3u, t = threadIdx.x;
+  const __amdgpu_buffer_rsrc_t r = make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)b * L::kBytes * HOP, L::kBytes * HOP);
+  int sr = 0, si = 0;
+  if constexpr (KIND == SCN_K_SHORT) {  // a quarter of the I plane and the same quarter of the Q plane
+    constexpr uint32_t PB = 2u * HOP / 4u, NV = PB / 16u / 256u;
+#pragma unroll
+    for (uint32_t a = 0; a < NV; a++) {
+      const v4i wi = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r, (a * 256u + t) * 16u, part * PB, 0));
+      const v4i wq = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r, (a * 256u + t) * 16u, 2u * HOP + part * PB, 0));
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        sr += (int)(short)(wi[c] & 0xffff) + (wi[c] >> 16);
+        si += (int)(short)(wq[c] & 0xffff) + (wq[c] >> 16);
+      }
+    }
+  } else {
+    constexpr uint32_t PB = L::kBytes * HOP / 4u, NV = PB / 16u / 256u;
+#pragma unroll
+    for (uint32_t a = 0; a < NV; a++) {
+      const v4i w = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(r, (a * 256u + t) * 16u, part * PB, 0));
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int d = w[c];
+        if constexpr (KIND == SCN_K_SHORT_COMPLEX) {
+          sr += (int)(short)(d & 0xffff);
+          si += d >> 16;
+        } else {  // int8 pairs: two samples per dword
+          sr += (int)(signed char)(d & 0xff) + (int)(signed char)((d >> 16) & 0xff);
+          si += (int)(signed char)((d >> 8) & 0xff) + (d >> 24);
+        }
+      }
+    }
+  }
+  sr = wave_sum(sr);
+  si = wave_sum(si);
+  if ((t & 63u) == 0) {
+    part_sums[t >> 6] = sr;
+    part_sums[4 + (t >> 6)] = si;
+  }
+  __syncthreads();
+  if (t < 2) atomicAdd(&args.dc_sums[2 * b + t], part_sums[4 * t] + part_sums[4 * t + 1] + part_sums[4 * t + 2] + part_sums[4 * t + 3]);
+}
+
 // ---- kernel A: columns -------------------------------------------------------------------
 // grid = 16 column tiles x G workgroups; workgroup (j, g) owns tile j for a CONTIGUOUS range of segments, so everything that
 // depends on (n1, n2, k1) but not on the segment stays in registers -- and so does half of the input: with a hop of N/2 = 128
 // rows of 256, segment s + 1's rows 0 .. 127 are segment s's rows 128 .. 255, which the same thread holds (n1 = 16 a + hi:
-// a' = a - 8).  Only the new half is loaded (round 5; until then the segments were dealt round-robin and every sample was
-// fetched by both segments that contain it: 2.86e8 B of input reads per 32-PSD step where 1.43e8 are new).
+// a' = a - 8).  Segment s is blocks s and s + 1 of the stream; only block s + 2 is loaded while it is transformed (round 5;
+// until then the segments were dealt round-robin and every sample was fetched by both segments that contain it: 2.86e8 B of
+// input reads per 32-PSD step where 1.43e8 are new).  The carried half stays in its RAW form (with DC removal each block has
+// its own mean, which belongs to the block, not to the segment).
+template <int KIND, bool DC>
 __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs args) {
+  typedef WelchRaw<KIND> L;
+  constexpr uint32_t HOP = WN / 2u;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v2f *lds = reinterpret_cast<v2f *>(smem_raw);
   const uint32_t t = threadIdx.x;
@@ -67,11 +176,11 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
 #pragma unroll
   for (int q = 0; q < 16; q++) twb[q] = from_v2f(args.twiddle[(n2 * (hi + 16u * q)) & (WN - 1)]);  // W_N^{n2 k1}
 #pragma unroll
-  for (int a = 0; a < 16; a++) win[a] = args.window[256u * (16u * a + hi) + n2];
+  for (int a = 0; a < 16; a++) win[a] = args.window[256u * (16u * a + hi) + n2] * args.scale;  // (scale: 1 for float samples)
 
   v2f *w1 = lds + t;                // + p*WP           (row p, column b*16+c = t)
   v2f *r1 = lds + hi * WP + lo;     // + b*16
-  const uint32_t ld_voff = (256u * hi + n2) * 8u;        // + a*16*256*8
+  const uint32_t s0 = 256u * hi + n2;                    // sample of a8 = 0 within a block; + 4096 a8
   // The work buffer is private to this file, so it is laid out for both of its users: per segment
   // [row tile i = k1/16][column tile j = n2/16][16 k1][16 n2].  This workgroup's 256 outputs for a fixed q are exactly
   // block (i = q, j) -- 2 KiB contiguous, thread t at slot t -- and the row kernel reads block (i, j = a) the same
@@ -79,44 +188,49 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
   // 2 KiB apart).
   const uint32_t st_voff = t * 8u;                        // + (16 q + j) * 2048
 
-  // the next segment's 16 samples per thread are fetched while this one is transformed (branch-free: a segment past
-  // the end gets a zero-record descriptor)
-  auto in_rsrc = [&](uint32_t seg) {
-    const bool ok = seg < args.n_segments;
-    return make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)(ok ? seg : 0u) * args.hop * 8u, ok ? WN * 8u : 0u);
+  // the next block's 8 samples per thread are fetched while this segment is transformed (branch-free: a block that is
+  // not needed gets a zero-record descriptor)
+  auto blk_rsrc = [&](uint32_t blk, bool ok) {
+    return make_rsrc(reinterpret_cast<const char *>(args.in) + (size_t)(ok ? blk : 0u) * HOP * L::kBytes, ok ? HOP * L::kBytes : 0u);
   };
-  v2f raw[16];
-#if SCN_WELCH_REUSE
+  auto blk_dc = [&](uint32_t blk, bool ok, int &re, int &im) {
+    re = im = 0;
+    if (DC && ok) {
+      re = (int)((uint32_t)args.dc_sums[2 * blk] / HOP);  // int32 /= uint32, utility.cpp:77-78
+      im = (int)((uint32_t)args.dc_sums[2 * blk + 1] / HOP);
+    }
+  };
+  typename L::raw_t raw[16];
   const uint32_t per = (args.n_segments + G - 1u) / G, seg_lo = g * per, seg_hi = seg_lo + per < args.n_segments ? seg_lo + per : args.n_segments;
-  const uint32_t seg_step = 1u;
-#else
-  const uint32_t seg_lo = g, seg_hi = args.n_segments, seg_step = G;
-#endif
+  int dcl_re, dcl_im, dch_re, dch_im;  // the means of the blocks in raw[0..7] and raw[8..15]
   {
-    const __amdgpu_buffer_rsrc_t r0 = in_rsrc(seg_lo < seg_hi ? seg_lo : args.n_segments);
+    const bool ok = seg_lo < seg_hi;
+    const __amdgpu_buffer_rsrc_t r0 = blk_rsrc(seg_lo, ok), r1b = blk_rsrc(seg_lo + 1u, ok);
 #pragma unroll
-    for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
+    for (int a = 0; a < 8; a++) raw[a] = L::load(r0, s0, a);
+#pragma unroll
+    for (int a = 0; a < 8; a++) raw[8 + a] = L::load(r1b, s0, a);
+    blk_dc(seg_lo, ok, dcl_re, dcl_im);
+    blk_dc(seg_lo + 1u, ok, dch_re, dch_im);
   }
-  for (uint32_t seg = seg_lo; seg < seg_hi; seg += seg_step) {
+  for (uint32_t seg = seg_lo; seg < seg_hi; seg++) {
     __amdgpu_buffer_rsrc_t rwk = make_rsrc(reinterpret_cast<char *>(args.work) + (size_t)seg * WN * 8u + j * 2048u, WN * 8u - j * 2048u);
     cf v[16];
 #pragma unroll
-    for (int a = 0; a < 16; a++) v[a] = from_v2f(raw[a]) * win[a];
-    // the next segment's loads go out in two groups, one per barrier-separated phase (a burst of 16 stalls the wave at
+    for (int a = 0; a < 8; a++) v[a] = L::conv(raw[a], dcl_re, dcl_im) * win[a];
+#pragma unroll
+    for (int a = 8; a < 16; a++) v[a] = L::conv(raw[a], dch_re, dch_im) * win[a];
+    // the next block's loads go out in two groups, one per barrier-separated phase (a burst of 16 stalls the wave at
     // issue when the memory pipeline is backed up: profiles/r01_floors.md)
-#if SCN_WELCH_REUSE
-    const __amdgpu_buffer_rsrc_t rn = in_rsrc(seg + 1u < seg_hi ? seg + 1u : args.n_segments);
+    const bool more = seg + 1u < seg_hi;
+    const __amdgpu_buffer_rsrc_t rn = blk_rsrc(seg + 2u, more);
 #pragma unroll
     for (int a = 0; a < 8; a++) raw[a] = raw[a + 8];  // the upper half of this segment is the lower half of the next
+    dcl_re = dch_re;
+    dcl_im = dch_im;
+    blk_dc(seg + 2u, more, dch_re, dch_im);
 #pragma unroll
-    for (int a = 8; a < 8 + SCN_WELCH_PF_CUT; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
-    constexpr int REST_LO = 8 + SCN_WELCH_PF_CUT;
-#else
-    const __amdgpu_buffer_rsrc_t rn = in_rsrc(seg + G);
-#pragma unroll
-    for (int a = 0; a < 8; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
-    constexpr int REST_LO = 8;
-#endif
+    for (int a = 0; a < SCN_WELCH_PF_CUT; a++) raw[8 + a] = L::load(rn, s0, a);
     fft16(v);
 #pragma unroll
     for (int p = 0; p < 16; p++) {
@@ -128,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void scn_welch_cols_kernel(ScnWelchArgs arg
 #pragma unroll
     for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 16]);
 #pragma unroll
-    for (int a = REST_LO; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 32768u, SCN_WELCH_AUX_IN));
+    for (int a = SCN_WELCH_PF_CUT; a < 8; a++) raw[8 + a] = L::load(rn, s0, a);
     fft16(v);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
@@ -238,16 +352,47 @@ __global__ __launch_bounds__(256) void scn_welch_combine_kernel(ScnWelchArgs arg
   }
 }
 
-hipError_t scn_launch_welch(const ScnWelchArgs &a, int num_cus, hipStream_t s) {
+// how the column kernel splits `n_segments` over its workgroups: G groups of `per` consecutive segments each (the last ragged)
+void scn_welch_column_groups(uint32_t n_segments, int num_cus, uint32_t *groups, uint32_t *per) {
+  uint32_t G = (uint32_t)(num_cus * 3) / 16u;  // 16 tiles x G: one resident wave of workgroups
+  if (G < 1) G = 1;
+  if (G > n_segments) G = n_segments;
+  *groups = G;
+  *per = G ? (n_segments + G - 1u) / G : 0u;
+}
+
+namespace {
+template <int KIND>
+hipError_t launch_cols(const ScnWelchArgs &a, bool dc, uint32_t G, size_t lds, hipStream_t s) {
+  if constexpr (KIND != SCN_K_FLOAT_COMPLEX) {  // (no DC removal for float samples, messageQueue.h:229-236)
+    if (dc) {
+      hipError_t e = hipMemsetAsync(a.dc_sums, 0, sizeof(int) * 2u * (a.n_segments + 1u), s);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(scn_welch_dc_kernel<KIND>, dim3(4u * (a.n_segments + 1u)), dim3(256), 0, s, a);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      hipLaunchKernelGGL((scn_welch_cols_kernel<KIND, true>), dim3(16 * G), dim3(256), lds, s, a);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((scn_welch_cols_kernel<KIND, false>), dim3(16 * G), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+}  // namespace
+
+hipError_t scn_launch_welch(int kind, bool correct_dc, const ScnWelchArgs &a, int num_cus, hipStream_t s) {
   if (a.n_segments == 0) return hipSuccess;
   if (a.hop != WN / 2u) return hipErrorInvalidValue;  // (the column kernel's in-register overlap is the 50 % one)
   const size_t lds = 16 * WP * sizeof(v2f);
-  // kernel A: 16 tiles x G groups, G so that the grid is one resident wave of workgroups
-  uint32_t G = (uint32_t)(num_cus * 3) / 16u;
-  if (G < 1) G = 1;
-  if (G > a.n_segments) G = a.n_segments;
-  hipLaunchKernelGGL(scn_welch_cols_kernel, dim3(16 * G), dim3(256), lds, s, a);
-  hipError_t e = hipGetLastError();
+  uint32_t G, per;
+  scn_welch_column_groups(a.n_segments, num_cus, &G, &per);
+  hipError_t e;
+  switch (kind) {
+    case SCN_K_FLOAT_COMPLEX: e = launch_cols<SCN_K_FLOAT_COMPLEX>(a, false, G, lds, s); break;
+    case SCN_K_SHORT_COMPLEX: e = launch_cols<SCN_K_SHORT_COMPLEX>(a, correct_dc, G, lds, s); break;
+    case SCN_K_SHORT: e = launch_cols<SCN_K_SHORT>(a, correct_dc, G, lds, s); break;
+    case SCN_K_BYTE_COMPLEX: e = launch_cols<SCN_K_BYTE_COMPLEX>(a, correct_dc, G, lds, s); break;
+    default: return hipErrorInvalidValue;
+  }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(scn_welch_rows_kernel, dim3(16 * a.n_psd * a.parts), dim3(256), lds, s, a);
   e = hipGetLastError();

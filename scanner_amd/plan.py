@@ -262,12 +262,15 @@ class Plan:
 class WelchPlan:
     """Streaming 65 536-pt, 50 %-overlap Welch PSD (BASELINE config C5) -- wrapper over scn_welch."""
 
-    def __init__(self, n=65536, segments_per_psd=16, max_psd=1, device_id=0, window_type=capi.WIN_BLACKMAN_HARRIS):
+    def __init__(self, n=65536, segments_per_psd=16, max_psd=1, device_id=0, window_type=capi.WIN_BLACKMAN_HARRIS,
+                 kind=capi.KIND_FLOAT_COMPLEX, enob=0, correct_dc=False):
         self._L = capi.lib()
         d = capi.WelchDesc()
         d.struct_size = C.sizeof(capi.WelchDesc)
         d.n, d.segments_per_psd, d.window_type, d.max_psd, d.device_id = n, segments_per_psd, window_type, max_psd, device_id
-        self.n, self.k, self.max_psd, self.hop = n, segments_per_psd, max_psd, n // 2
+        d.sample_kind, d.enob, d.correct_dc = kind, enob, int(bool(correct_dc))
+        self.n, self.k, self.max_psd, self.hop, self.kind = n, segments_per_psd, max_psd, n // 2, kind
+        self.bytes_per_sample = capi.BYTES_PER_SAMPLE[kind]
         self._h = C.c_void_p()
         capi.check(self._L.scn_welch_create(C.byref(d), C.byref(self._h)), "scn_welch_create")
         self._npsd = [0] * capi.NUM_SLOTS
@@ -295,10 +298,18 @@ class WelchPlan:
         capi.check(self._L.scn_welch_samples(self._h, n_psd, C.byref(n)), "scn_welch_samples")
         return n.value
 
+    def partition(self, n_psd):
+        """(parts, column groups, segments per column group) of a submit of n_psd PSDs -- scn_welch_partition."""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        capi.check(self._L.scn_welch_partition(self._h, n_psd, C.byref(a), C.byref(b), C.byref(c)), "scn_welch_partition")
+        return a.value, b.value, c.value
+
     def host_buffer(self, slot):
-        """pinned complex64 staging view (max_psd PSDs worth of samples)"""
+        """pinned staging view (max_psd PSDs worth of samples): complex64 for float samples, bytes for the integer wire formats"""
         ptr, nbytes = C.c_void_p(), C.c_size_t()
         capi.check(self._L.scn_welch_host_buffer(self._h, slot, C.byref(ptr), C.byref(nbytes)), "scn_welch_host_buffer")
+        if self.kind != capi.KIND_FLOAT_COMPLEX:
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes.value,))
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(nbytes.value // 4,)).view(np.complex64)
 
     def submit(self, slot, n_psd):
@@ -310,7 +321,7 @@ class WelchPlan:
             import torch
 
             torch.cuda.current_stream(d_samples.device).synchronize()
-        assert d_samples.is_contiguous() and d_samples.numel() * d_samples.element_size() >= self.samples(n_psd) * 8
+        assert d_samples.is_contiguous() and d_samples.numel() * d_samples.element_size() >= self.samples(n_psd) * self.bytes_per_sample
         out = None if d_psd_db is None else C.c_void_p(d_psd_db.data_ptr())
         capi.check(self._L.scn_welch_submit_device(self._h, slot, C.c_void_p(d_samples.data_ptr()), n_psd, out),
                    "scn_welch_submit_device")

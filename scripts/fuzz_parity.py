@@ -1,8 +1,9 @@
 """Randomised differential test of the C-ABI path against the CPU oracle (test tooling; run on the GPU box):
    python scripts/fuzz_parity.py [seconds] [seed]
-Every case draws a size, wire format, ENOB, DC flag, threshold, output flags, overlapped-slots flag and a short
+Every case draws a size, wire format, ENOB, DC flag, sample rate, threshold, output flags, overlapped-slots flag and a short
 sequence of launches with random batch sizes over both slots; spectra are held to tests/tolerances.py, hit lists
-and trigger flags must be identical wherever no evaluated bin sits within the guard band of the threshold."""
+and trigger flags must be identical wherever no evaluated bin sits within the guard band of the threshold.  One case in
+sixteen is a Welch plan (BASELINE C5): K, PSDs per submit, wire format and DC drawn, device and pinned/hipGraph submits."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +13,9 @@ from oracle import oracle as O
 from tests import tolerances as tol
 
 FS = 8000000
+# the rates the reference's front-ends run at (hackRFSource.cpp:156-161: 8 / 10 / 12.5 / 16 / 20 Msps; B210 61.44; RTL 2.4) and odd ones:
+# process.cpp:38-39 truncates fs / 2 and fs / N in uint32
+RATES = [8000000, 8000000, 10000000, 12500000, 16000000, 20000000, 61440000, 2400000, 7999999, 2048001]
 kinds = [capi.KIND_FLOAT_COMPLEX, capi.KIND_SHORT_COMPLEX, capi.KIND_SHORT, capi.KIND_BYTE_COMPLEX]
 
 
@@ -19,7 +23,7 @@ def dev(raw):
     return torch.from_numpy(np.ascontiguousarray(raw).view(np.uint8).reshape(-1)).cuda()
 
 
-def time_domain_case(rng, n, kind, enob, dc):
+def time_domain_case(rng, n, kind, enob, dc, FS=FS):
     thr = float(rng.choice([-1.5, -20.0, 3.0]))
     o = O.Oracle(n, FS, thr, kind=kind, enob=enob, correct_dc=dc)
     flags = capi.PLAN_OVERLAP_SLOTS if rng.integers(0, 2) else 0
@@ -54,6 +58,47 @@ def time_domain_case(rng, n, kind, enob, dc):
         raise
 
 
+def welch_case(rng):
+    """One Welch plan against the oracle: K segments per PSD, up to max_psd PSDs per submit, a wire format, DC removal per
+    delivery block; a device-resident submit and a pinned / hipGraph one in flight together."""
+    from scanner_amd import WelchPlan
+
+    N = 65536
+    k = int(rng.choice([1, 2, 3, 5, 7, 16, 16]))
+    max_psd = int(rng.choice([1, 2, 4, 8, 16, 32]))
+    kind = int(rng.choice(kinds))
+    enob = 8 if kind == capi.KIND_BYTE_COMPLEX else int(rng.choice([12, 14, 16]))
+    dc = bool(rng.integers(0, 2)) and kind != capi.KIND_FLOAT_COMPLEX
+    desc = f"welch k={k} max_psd={max_psd} kind={kind} enob={enob} dc={dc}"
+    try:
+        with WelchPlan(N, k, max_psd=max_psd, kind=kind, enob=enob, correct_dc=dc) as w:
+            subs = []
+            for s in (0, 1):
+                n_psd = int(rng.integers(1, max_psd + 1))
+                blocks = n_psd * k + 1
+                x = synth.cfloat_batch(N // 2, blocks, seed=int(rng.integers(1 << 30)), max_tones=2)
+                x *= rng.uniform(0.3, 1.0, (blocks, 1)).astype(np.float32)          # a level per delivery block: segments are told apart
+                raw = synth.quantize(x, kind)
+                if dc:
+                    raw = (raw + int(rng.integers(1, 60))).astype(raw.dtype)
+                flat = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+                if s == 0:
+                    w.submit_device(0, dev(flat), n_psd)
+                else:
+                    hb = w.host_buffer(1)
+                    hb.view(np.uint8)[: flat.size] = flat
+                    w.submit(1, n_psd)
+                subs.append((raw, n_psd))
+            for s, (raw, n_psd) in enumerate(subs):
+                got = w.collect(s)
+                fig = tol.compare_spectra(got, O.welch_raw(raw, kind, enob, dc, N, k, n_psd))
+                worst_by_n["welch"] = max(worst_by_n.get("welch", 0.0), fig["max_rel_power_vs_max_bin_mean"])
+    except Exception:
+        print("FAILED CASE:", desc, file=sys.stderr)
+        raise
+    return 2
+
+
 near_misses = []   # (max_rel_power, case description, what the worst buffer looks like) of the last run()
 worst_by_n = {}    # size -> the largest value of the parity metric any of its spectra showed in the last run()
 
@@ -64,6 +109,7 @@ def run(budget, seed, plans=None):
     box's speed (the slice in the GPU suite: the same cases on every box)."""
     rng = np.random.default_rng(seed)
     rng_t = np.random.default_rng(seed + 7919)   # the frequency-table choices (round 5) draw from a stream of their own: the cases of a seed stay the cases they were
+    rng_f = np.random.default_rng(seed + 104729)  # ... and so do the sample rates and the Welch cases (round 6)
     t_end = time.time() + (budget if plans is None else 1e9)
     cases = launches = 0
     near_misses.clear()
@@ -72,6 +118,11 @@ def run(budget, seed, plans=None):
         # 16 ... 512: several buffers per workgroup; 65536, 32768: the four-step pairs; 1000, 6000: the mixed-radix fused kernels; 1023: the staged path (Bluestein)
         sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else \
             [1024, 2048, 4096, 8192, 16384, 16384, 256, 512, 65536, 32768, 1000, 6000, 12000, 1023, 16, 32, 64, 128]
+        if not os.environ.get("FUZZ_SIZES") and rng_f.random() < 1.0 / 16.0:
+            launches += welch_case(rng_f)
+            cases += 1
+            continue
+        FS = int(rng_f.choice(RATES))
         n = int(rng.choice(sizes))
         kind = int(rng.choice(kinds))
         enob = 8 if kind == capi.KIND_BYTE_COMPLEX else int(rng.choice([12, 12, 14, 16, 10]))
@@ -81,7 +132,7 @@ def run(budget, seed, plans=None):
         flags = out_flags | (capi.PLAN_OVERLAP_SLOTS if rng.integers(0, 2) else 0)
         max_nb = int(rng.choice([3, 40, 150])) if n == 1023 else int(rng.choice([3, 64, 700, 2600])) if n == 1000 else int(rng.choice([3, 64, 400, 900])) if n in (6000, 12000) else int(rng.choice([3, 64, 700, 2600, 5000])) if n <= 512 else int(rng.choice([3, 64, 700, 1300, 2600])) if n <= 4096 else int(rng.choice([3, 64, 600, 1100])) if n == 8192 else int(rng.choice([3, 64, 300, 520])) if n == 16384 else int(rng.choice([3, 40, 130])) if n == 32768 else int(rng.choice([3, 20, 70])) if n == 65536 else int(rng.choice([3, 64, 700, 2600]))
         if rng.random() < 0.15:   # time-domain mode (process.cpp:203-237): a few small launches against the oracle
-            time_domain_case(rng, n, kind, enob, dc)
+            time_domain_case(rng, n, kind, enob, dc, FS)
             cases += 1
             launches += 2
             continue
@@ -89,7 +140,7 @@ def run(budget, seed, plans=None):
         max_hits = max(64, max_nb * region_scale)
         nl = int(rng.integers(1, 6))
         o = O.Oracle(n, FS, thr, kind=kind, enob=enob, correct_dc=dc)
-        desc = f"n={n} kind={kind} enob={enob} dc={dc} thr={thr} flags={flags} max_nb={max_nb} max_hits={max_hits}"
+        desc = f"n={n} fs={FS} kind={kind} enob={enob} dc={dc} thr={thr} flags={flags} max_nb={max_nb} max_hits={max_hits}"
         try:
             with Plan(n, FS, thr, kind=kind, enob=enob, correct_dc=dc, max_batch=max_nb, max_hits=max_hits, flags=flags) as plan:
                 pend = {}
@@ -180,4 +231,4 @@ if __name__ == "__main__":
           f"{len(near_misses)} spectra between 1x and 2x the bar")
     for m in sorted(near_misses, reverse=True)[:10]:
         print("   near miss %.3g  %s  %s" % m)
-    print("largest parity metric per size (bar 1e-5):", ", ".join(f"{k}: {v:.3g}" for k, v in sorted(worst_by_n.items())))
+    print("largest parity metric per size (bar 1e-5):", ", ".join(f"{k}: {v:.3g}" for k, v in sorted(worst_by_n.items(), key=lambda kv: str(kv[0]))))

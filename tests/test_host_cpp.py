@@ -145,11 +145,13 @@ KINDS = {"float": 4, "short_complex": 3, "short": 2, "byte": 1}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,enob,dc", [("short_complex", 12, False), ("float", 12, False), ("byte", 8, False),
-                                          ("short", 12, True)])
-def test_scan_synth_transcript_matches_oracle(host_build, oracle_mod, tmp_path, kind, enob, dc):
+@pytest.mark.parametrize("kind,enob,dc,fs", [("short_complex", 12, False, 8000000), ("float", 12, False, 8000000), ("byte", 8, False, 8000000),
+                                             ("short", 12, True, 8000000),
+                                             # the HackRF's other rates (hackRFSource.cpp:156-161): fs / N does not divide, bin_step truncates
+                                             ("short_complex", 12, False, 20000000), ("byte", 8, False, 12500000)])
+def test_scan_synth_transcript_matches_oracle(host_build, oracle_mod, tmp_path, kind, enob, dc, fs):
     _, demo = host_build
-    n, fs, iters = 4096, 8000000, 2
+    n, iters = 4096, 2
     dump = tmp_path / "raw.bin"
     cmd = [demo, "--kind", kind, "--n", str(n), "--fs", str(fs), "--start", "88e6", "--stop", "130e6",
            "--niterations", str(iters), "--threshold", "10", "--enob", str(enob), "--sigma", "0.02", "--batch", "5",

@@ -69,6 +69,22 @@ def test_known_answer_tone(oracle_mod):
     assert trig.tolist() == [0]
 
 
+@pytest.mark.parametrize("tag", ["12m5", "20m"])
+def test_known_answer_tone_other_sample_rates(oracle_mod, tag):
+    """process.cpp:38-39 where fs / N does not divide: bin_step = uint32(fs / N) truncated (12.5e6 / 8192 -> 1525,
+    20e6 / 4096 -> 4882), start = fc - fs / 2 -- hand-derived in tests/golden/make_golden.py section 2b."""
+    g = np.load(os.path.join(GOLD, "known_answer_rates.npz"))
+    n, fs, fc, m = (int(g[f"{tag}_n"]), int(g[f"{tag}_sample_rate"]), float(g[f"{tag}_center_freq"]), int(g[f"{tag}_tone_bin"]))
+    x = (float(g[f"{tag}_amplitude"]) * np.exp(2j * np.pi * m * np.arange(n) / n)).astype(np.complex64)
+    _, hits, trig = oracle_mod.Oracle(n, fs, float(g[f"{tag}_threshold"])).run(x, center_freqs=[fc], seq_ids=[3])
+    assert hits["i"].tolist() == g[f"{tag}_hit_i"].tolist()
+    assert hits["freq_hz"].tolist() == g[f"{tag}_hit_freq"].tolist()
+    assert np.abs(hits["power_db"] - g[f"{tag}_hit_db64"]).max() < 5e-6
+    peak = len(hits) // 2
+    assert int(hits["freq_hz"][peak]) == {"12m5": 435441400, "20m": 2408580936}[tag]      # 427670000 + 5096 * 1525; 2402000000 + 1348 * 4882
+    assert trig.tolist() == [0]
+
+
 def test_convert_known_answers(oracle_mod):
     k = np.load(os.path.join(GOLD, "convert_known_answers.npz"))
     O = oracle_mod

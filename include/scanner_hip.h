@@ -26,6 +26,14 @@
 extern "C" {
 #endif
 
+/* Marks the entry points: the ONLY symbols the shared library exports (it is built with hidden visibility and a version
+ * script generated from these declarations).  Expands to nothing in a caller's translation unit. */
+#if defined(SCN_BUILDING_LIBRARY)
+#define SCN_API __attribute__((visibility("default")))
+#else
+#define SCN_API
+#endif
+
 #define SCN_ABI_VERSION 5 /* 3: SCN_NUM_SLOTS 4, scn_gather_hits_device, scn_gather_fetch, scn_size_path; 4: scn_plan_set_table, scn_submit*_indexed;
                              5: scn_welch_desc.sample_kind / enob / correct_dc (carved out of its reserved words: same size, zero = the
                              version-4 behaviour), scn_welch_partition */
@@ -118,12 +126,12 @@ typedef struct scn_plan_desc {
 
 typedef struct scn_plan scn_plan;
 
-const char *scn_error_name(int status);
+SCN_API const char *scn_error_name(int status);
 /* Text of the most recent failure on this thread ("" if none). */
-const char *scn_last_error(void);
-uint32_t scn_abi_version(void);
+SCN_API const char *scn_last_error(void);
+SCN_API uint32_t scn_abi_version(void);
 /* Number of HIP devices visible to this process (0 and SCN_E_NO_DEVICE if none). */
-int scn_device_count(int *count);
+SCN_API int scn_device_count(int *count);
 
 /* Which implementation a frequency-domain plan of n points runs (needs no device): what a caller sizing its batches
  * wants to know, and what the parity tests walk so that no fused specialisation goes untested. */
@@ -135,32 +143,32 @@ enum {
                              16 ... 128); the stages live on as the transform inside SCN_PATH_BLUESTEIN */
   SCN_PATH_BLUESTEIN = 4  /* the staged path around a chirp-z convolution (sizes that are not powers of two) */
 };
-int scn_size_path(uint32_t n, uint32_t *path);
+SCN_API int scn_size_path(uint32_t n, uint32_t *path);
 
-int scn_plan_create(const scn_plan_desc *desc, scn_plan **out);
-int scn_plan_destroy(scn_plan *plan);
+SCN_API int scn_plan_create(const scn_plan_desc *desc, scn_plan **out);
+SCN_API int scn_plan_destroy(scn_plan *plan);
 
 /* Bytes of one raw buffer (N samples) in the plan's wire format. */
-int scn_buffer_bytes(const scn_plan *plan, size_t *bytes);
+SCN_API int scn_buffer_bytes(const scn_plan *plan, size_t *bytes);
 
 /* The plan's pinned host staging slot (max_batch raw buffers back to back),
  * slot in [0, SCN_NUM_SLOTS).  Replaces MemoryPool/SampleQueue storage
  * (memoryPool.h:32-77): producers write device-format IQ straight into it.
  * Plan-owned, valid until scn_plan_destroy; allocated on first use. */
-int scn_host_buffer(scn_plan *plan, int slot, void **ptr, size_t *bytes);
+SCN_API int scn_host_buffer(scn_plan *plan, int slot, void **ptr, size_t *bytes);
 
 /* Asynchronously copy n_buffers raw buffers from the pinned slot to the GPU
  * and run convert -> window -> FFT -> dB -> threshold on the plan's stream.
  * center_freqs / seq_ids (n_buffers each, host) are the MessageHeader fields
  * m_frequency / m_sequenceId (messageQueue.h:25-26); seq_ids may be NULL
  * (0,1,2,...).  Returns without waiting for the GPU. */
-int scn_submit(scn_plan *plan, int slot, uint32_t n_buffers,
+SCN_API int scn_submit(scn_plan *plan, int slot, uint32_t n_buffers,
                const double *center_freqs, const uint64_t *seq_ids);
 
 /* Same, for raw IQ already resident in device memory (d_raw: n_buffers raw
  * buffers back to back).  d_power_db: optional device destination for the
  * dB spectra (n_buffers*N floats); NULL uses the plan's own buffer. */
-int scn_submit_device(scn_plan *plan, int slot, const void *d_raw,
+SCN_API int scn_submit_device(scn_plan *plan, int slot, const void *d_raw,
                       uint32_t n_buffers, const double *center_freqs,
                       const uint64_t *seq_ids, float *d_power_db);
 
@@ -171,9 +179,9 @@ int scn_submit_device(scn_plan *plan, int slot, const void *d_raw,
  * per-buffer header crosses the boundary (with seq_ids == NULL none at all: 16 bytes per buffer that made launches of
  * 16 ... 128-point buffers host-bound).  The records are the same, bit for bit.  count == 0 drops the table.  Not while a
  * submit is pending (SCN_E_STATE); lists of earlier submits can no longer be re-read afterwards (scn_collect_more). */
-int scn_plan_set_table(scn_plan *plan, const double *center_freqs, uint32_t count);
-int scn_submit_indexed(scn_plan *plan, int slot, uint32_t n_buffers, uint32_t first_index, const uint64_t *seq_ids);
-int scn_submit_device_indexed(scn_plan *plan, int slot, const void *d_raw, uint32_t n_buffers, uint32_t first_index,
+SCN_API int scn_plan_set_table(scn_plan *plan, const double *center_freqs, uint32_t count);
+SCN_API int scn_submit_indexed(scn_plan *plan, int slot, uint32_t n_buffers, uint32_t first_index, const uint64_t *seq_ids);
+SCN_API int scn_submit_device_indexed(scn_plan *plan, int slot, const void *d_raw, uint32_t n_buffers, uint32_t first_index,
                               const uint64_t *seq_ids, float *d_power_db);
 
 /* Wait for the slot's submit and fetch results.  power_db: host, n_buffers*N
@@ -186,18 +194,18 @@ int scn_submit_device_indexed(scn_plan *plan, int slot, const void *d_raw, uint3
  * SCN_E_TRUNCATED when that is not all of them.  trigger: n_buffers bytes,
  * process_fft's return value (hits > trigger_count) per buffer, or NULL.
  * With hits == NULL the call waits for the kernel and the per-buffer counts only. */
-int scn_collect(scn_plan *plan, int slot, float *power_db, scn_hit *hits,
+SCN_API int scn_collect(scn_plan *plan, int slot, float *power_db, scn_hit *hits,
                 uint32_t hit_cap, uint32_t *n_hits, uint8_t *trigger);
 
 /* Records [first, first + hit_cap) of the ordered hit list of the slot's last COLLECTED submit (valid until the
  * slot's next submit): how a caller with a bounded buffer walks a list of any length -- a wideband burst makes every
  * buffer of a batch report > 1047 hits (process.cpp:62) and the reference prints each of them.  *n_written receives
  * the number of records stored (0 once first >= n_hits). */
-int scn_collect_more(scn_plan *plan, int slot, uint32_t first, scn_hit *hits, uint32_t hit_cap, uint32_t *n_written);
+SCN_API int scn_collect_more(scn_plan *plan, int slot, uint32_t first, scn_hit *hits, uint32_t hit_cap, uint32_t *n_written);
 
 /* Zero-copy alternative to the hits argument of scn_collect: the plan's own pinned copy of the ordered list
  * (min(n_hits, max_hits) records), valid from scn_collect until the slot's next submit. */
-int scn_hits_view(scn_plan *plan, int slot, const scn_hit **hits, uint32_t *n);
+SCN_API int scn_hits_view(scn_plan *plan, int slot, const scn_hit **hits, uint32_t *n);
 
 /* Time-domain plans (mode = SCN_MODE_TIME_DOMAIN; ProcessSamples::DoTimeDomainThresholding,
  * process.cpp:203-237): wait for the slot's submit and fetch, per buffer, the maximum and
@@ -206,7 +214,7 @@ int scn_hits_view(scn_plan *plan, int slot, const scn_hit **hits, uint32_t *n);
  *   "Max signal %f above threshold %f frequency %.0f, min %f"
  * is printed from max_db[b], the plan threshold, the buffer's centre frequency and min_db[b].
  * Any of the three outputs may be NULL. */
-int scn_collect_time_domain(scn_plan *plan, int slot, float *max_db, float *min_db,
+SCN_API int scn_collect_time_domain(scn_plan *plan, int slot, float *max_db, float *min_db,
                             uint8_t *above);
 
 /* K1 alone, synchronously: convert n_buffers raw buffers (host memory, the plan's wire format) to
@@ -214,24 +222,24 @@ int scn_collect_time_domain(scn_plan *plan, int slot, float *max_db, float *min_
  * correct_dc), writing n_buffers*N {re,im} float pairs to out (host).  This is what the
  * triggered-capture writer needs (messageQueue.h:98-139 dumps fftwf_complex[N] records); it runs on
  * its own stream and does not disturb pending slots. */
-int scn_convert_raw(scn_plan *plan, const void *raw, uint32_t n_buffers, float *out);
+SCN_API int scn_convert_raw(scn_plan *plan, const void *raw, uint32_t n_buffers, float *out);
 
 /* Wait for the slot's submit without copying anything back. */
-int scn_wait(scn_plan *plan, int slot);
+SCN_API int scn_wait(scn_plan *plan, int slot);
 
 /* Plumbing for callers that keep results on the GPU or time the stream. */
-int scn_plan_stream(scn_plan *plan, void **hip_stream);
+SCN_API int scn_plan_stream(scn_plan *plan, void **hip_stream);
 /* The stream slot's kernels run on (the plan's one compute stream unless SCN_PLAN_OVERLAP_SLOTS). */
-int scn_slot_stream(scn_plan *plan, int slot, void **hip_stream);
-int scn_device_spectrum(scn_plan *plan, int slot, float **d_power_db);
+SCN_API int scn_slot_stream(scn_plan *plan, int slot, void **hip_stream);
+SCN_API int scn_device_spectrum(scn_plan *plan, int slot, float **d_power_db);
 /* Window coefficients the plan uses (host copy, n floats). */
-int scn_plan_window(const scn_plan *plan, float *w, uint32_t n);
+SCN_API int scn_plan_window(const scn_plan *plan, float *w, uint32_t n);
 
 /* frequencyTable.cpp:9-37: centre frequencies f1 + i*step*fs covering
  * [start, stop).  Writes min(count, cap) entries, returns count in *count.
  * shard / n_shards select the contiguous index range a rank owns
  * (n_shards = 1, shard = 0 for the whole table): *first is its first index. */
-int scn_frequency_table(uint32_t sample_rate, double start, double stop,
+SCN_API int scn_frequency_table(uint32_t sample_rate, double start, double stop,
                         double use_bandwidth, double dc_ignore_width,
                         uint32_t shard, uint32_t n_shards, double *out,
                         uint32_t cap, uint32_t *count, uint32_t *first);
@@ -268,15 +276,15 @@ int scn_frequency_table(uint32_t sample_rate, double start, double stop,
  * ------------------------------------------------------------------------------------ */
 #define SCN_COMM_ID_BYTES 128
 typedef struct scn_comm scn_comm;
-int scn_comm_unique_id(void *id);
-int scn_comm_create(const void *id, int rank, int world_size, int device_id, scn_comm **out);
-int scn_comm_destroy(scn_comm *comm);
-int scn_gather_hits(scn_comm *comm, const scn_hit *local, uint32_t n_local, uint32_t root, scn_hit *all,
+SCN_API int scn_comm_unique_id(void *id);
+SCN_API int scn_comm_create(const void *id, int rank, int world_size, int device_id, scn_comm **out);
+SCN_API int scn_comm_destroy(scn_comm *comm);
+SCN_API int scn_gather_hits(scn_comm *comm, const scn_hit *local, uint32_t n_local, uint32_t root, scn_hit *all,
                     uint64_t all_cap, uint64_t *n_total, uint32_t *per_rank);
-int scn_gather_hits_device(scn_comm *comm, scn_plan *plan, int slot, uint32_t root, scn_hit *all, uint64_t all_cap,
+SCN_API int scn_gather_hits_device(scn_comm *comm, scn_plan *plan, int slot, uint32_t root, scn_hit *all, uint64_t all_cap,
                            uint64_t *n_total, uint32_t *per_rank);
-int scn_gather_fetch(scn_comm *comm, uint64_t first, scn_hit *out, uint64_t cap, uint64_t *n_written);
-int scn_gather_layout(const uint32_t *per_rank, uint32_t world_size, uint64_t *offsets);
+SCN_API int scn_gather_fetch(scn_comm *comm, uint64_t first, scn_hit *out, uint64_t cap, uint64_t *n_written);
+SCN_API int scn_gather_layout(const uint32_t *per_rank, uint32_t world_size, uint64_t *offsets);
 
 /* HackRFSource::interpolateSamples (hackRFSource.cpp:186-222), the in-band header of HackRF
  * sweep-mode transfers: when the transfer starts with the bytes 0x7F 0x7F, bytes 2..9 hold the
@@ -292,7 +300,7 @@ int scn_gather_layout(const uint32_t *per_rank, uint32_t world_size, uint64_t *o
  * (:210-213) -- also reproduced.  *n_mismatch (optional) counts the iterations at which the
  * reference prints "interpolateSamples: frequencyHz[..] != thisFrequencyHz[..]" (:204-208); the
  * library itself prints nothing. */
-int scn_hackrf_sweep_fixup(void *transfer, uint32_t valid_length, uint32_t scan_offset_hz,
+SCN_API int scn_hackrf_sweep_fixup(void *transfer, uint32_t valid_length, uint32_t scan_offset_hz,
                            double *center_frequency, uint32_t *n_mismatch);
 
 /* ------------------------------------------------------------------------------------
@@ -328,22 +336,22 @@ typedef struct scn_welch_desc {
 
 typedef struct scn_welch scn_welch;
 
-int scn_welch_create(const scn_welch_desc *desc, scn_welch **out);
-int scn_welch_destroy(scn_welch *w);
+SCN_API int scn_welch_create(const scn_welch_desc *desc, scn_welch **out);
+SCN_API int scn_welch_destroy(scn_welch *w);
 /* complex samples one submit of n_psd PSDs consumes (times 2 / 4 / 8 bytes per sample of the plan's wire format) */
-int scn_welch_samples(const scn_welch *w, uint32_t n_psd, size_t *n_samples);
+SCN_API int scn_welch_samples(const scn_welch *w, uint32_t n_psd, size_t *n_samples);
 /* How a submit of n_psd PSDs is split over workgroups (what a caller sizing max_psd, and the parity tests, want to know):
  * *parts = workgroups sharing the K segments of one PSD's row tile (fixed at create; > 1 adds the combine kernel),
  * *column_groups / *segments_per_group = the column kernel's contiguous runs of segments (the last group ragged); each may be NULL. */
-int scn_welch_partition(const scn_welch *w, uint32_t n_psd, uint32_t *parts, uint32_t *column_groups, uint32_t *segments_per_group);
+SCN_API int scn_welch_partition(const scn_welch *w, uint32_t n_psd, uint32_t *parts, uint32_t *column_groups, uint32_t *segments_per_group);
 /* pinned input staging slot (max_psd PSDs worth of samples in the plan's wire format), plan-owned */
-int scn_welch_host_buffer(scn_welch *w, int slot, void **ptr, size_t *bytes);
-int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd);
+SCN_API int scn_welch_host_buffer(scn_welch *w, int slot, void **ptr, size_t *bytes);
+SCN_API int scn_welch_submit(scn_welch *w, int slot, uint32_t n_psd);
 /* samples (the plan's wire format) already in device memory; d_psd_db optional device destination (n_psd*n floats) */
-int scn_welch_submit_device(scn_welch *w, int slot, const void *d_samples, uint32_t n_psd,
+SCN_API int scn_welch_submit_device(scn_welch *w, int slot, const void *d_samples, uint32_t n_psd,
                             float *d_psd_db);
 /* wait and fetch the n_psd*n dB values (psd_db may be NULL to only wait) */
-int scn_welch_collect(scn_welch *w, int slot, float *psd_db);
+SCN_API int scn_welch_collect(scn_welch *w, int slot, float *psd_db);
 
 #ifdef __cplusplus
 }

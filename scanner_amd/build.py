@@ -14,6 +14,28 @@ LIB = os.path.join(HERE, "libscanner_hip.so")
 SOURCES = ["scn_kernels.hip", "scn_mixed.hip", "scn_generic.hip", "scn_big.hip", "scn_hits.hip", "scn_welch.hip", "scn_gather.hip", "scn_api.hip"]
 HEADERS = ["scn_kernels.h", "scn_device.h", "scn_mixed_dft.h", "scn_mixed_plans.h", "scn_gather_protocol.h", os.path.join("..", "..", "include", "scanner_hip.h")]
 ARCH = "gfx950"
+# The library's dynamic symbol table is the C-ABI and nothing else: everything is compiled with hidden visibility, the entry
+# points of include/scanner_hip.h carry SCN_API (default visibility while SCN_BUILDING_LIBRARY is defined), and the link takes
+# a version script generated from the header's own declarations (which also keeps libstdc++'s weak template instantiations --
+# default visibility whatever the flags say -- out of the table).  tests/test_capi_cpu.py holds `nm -D` to the header.
+EXTRA_FLAGS = ["-fvisibility=hidden", "-fvisibility-inlines-hidden", "-DSCN_BUILDING_LIBRARY"]
+PUBLIC_HEADER = os.path.join(HERE, "..", "include", "scanner_hip.h")
+MAP_FILE = os.path.join(HERE, "libscanner_hip.map")
+LINK_FLAGS = ["-Wl,--version-script=" + MAP_FILE]
+
+
+def declared_symbols():
+    """The functions include/scanner_hip.h declares (every one carries SCN_API)."""
+    import re
+
+    with open(PUBLIC_HEADER) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\bSCN_API\b[^;{]*?\b(scn_\w+)\s*\(", text)))
+
+
+def write_map():
+    with open(MAP_FILE, "w") as fh:
+        fh.write("{\n  global:\n" + "".join(f"    {n};\n" for n in declared_symbols()) + "  local:\n    *;\n};\n")
 # files compiled once per value of a macro, side by side, each translation unit instantiating one group of sizes
 SPLIT = {"scn_kernels.hip": ("SCN_TU", 8), "scn_mixed.hip": ("SCN_MIXED_TU", 8)}
 
@@ -34,6 +56,8 @@ def source_hash():
     for f in sorted(SOURCES + HEADERS):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.abspath(__file__), "rb") as fh:  # the flags, ARCH and the split of the translation units live in this file
+        h.update(b"build.py\0" + fh.read())
     return h.hexdigest()[:16]
 
 
@@ -56,7 +80,18 @@ def build(force=False, verbose=False, defines=(), out=None):
     target = out or LIB
     if not out and not force and not _stale():
         return LIB
+    import fcntl
+
+    with open(LIB + ".lock", "w") as lock:  # several ranks (or pytest workers) finding the library stale build it ONCE, one after the other
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not out and not force and not _stale():
+            return LIB
+        return _build_locked(target, verbose, defines, out)
+
+
+def _build_locked(target, verbose, defines, out):
     built_from = source_hash()
+    write_map()
     objs, cmds = [], []
     tag = "" if not out else "." + os.path.basename(out).replace(".so", "")
     units = [(src, None) for src in SOURCES if src not in SPLIT] + [(src, tu) for src, (_, count) in SPLIT.items() for tu in range(count)]
@@ -68,7 +103,7 @@ def build(force=False, verbose=False, defines=(), out=None):
         # needs ~180 extra v_mov/v_pk_mov per FFT to pair registers (measured: 801 vs 668 VALU
         # instructions in the loop body).
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
-               "-fno-slp-vectorize", *[f"-D{d}" for d in defines], *([] if tu is None else [f"-D{SPLIT[src][0]}={tu}"]),
+               "-fno-slp-vectorize", *EXTRA_FLAGS, *[f"-D{d}" for d in defines], *([] if tu is None else [f"-D{SPLIT[src][0]}={tu}"]),
                "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -78,7 +113,7 @@ def build(force=False, verbose=False, defines=(), out=None):
 
     with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1)) as pool:  # one hipcc per translation unit, side by side
         list(pool.map(subprocess.check_call, cmds))
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs + ["-ldl"]
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *LINK_FLAGS, "-o", target] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -31,6 +31,18 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert sorted(capi.SYMBOLS) == names
 
 
+def test_library_exports_nothing_but_the_header(built_lib):
+    """A maintainer links this library into a C++ program: its dynamic symbol table is the C-ABI and nothing else -- no kernel
+    launch stubs, no launchers, no cross-file helpers, no libstdc++ template instantiations (hidden visibility + SCN_API + a
+    version script generated from the header, scanner_amd/build.py)."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built_lib], text=True)
+    defined = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert defined == declared_symbols(), sorted(set(defined) ^ set(declared_symbols()))
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name in declared_symbols():     # every declaration carries the export macro
+        assert re.search(r"\bSCN_API\b[^;{]*?\b%s\s*\(" % name, src), name
+
+
 def test_python_constants_follow_the_header():
     """capi.py restates a few of the header's constants for ctypes callers: they must be the header's (SCN_NUM_SLOTS went from
     2 to 4 in round 3; a stale copy would make Plan refuse -- or worse, mis-size -- the slots the library has)."""

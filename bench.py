@@ -85,6 +85,10 @@ def parse():
     ap.add_argument("--centres", type=int, default=16384, help="c4: number of centre frequencies in the table")
     ap.add_argument("--sweeps-per-launch", type=int, default=0,
                     help="c4: sweeps of the rank's shard batched into one launch (0: as many as fit 8192 buffers; 1: a launch per sweep)")
+    ap.add_argument("--gather-every-sweep", action="store_true",
+                    help="c4: add the steady-state leg -- a launch per sweep, every launch's ordered hit list gathered to rank 0 inside the timed "
+                         "region (scn_gather_post / scn_gather_wait on a communicator created once), beside the same sweeps without the gather "
+                         "(the default --gpus N > 1 line carries this leg as configs.c4)")
     ap.add_argument("--no-hits-only-leg", action="store_true", help="skip the extra leg on a plan without SCN_OUT_SPECTRUM")
     ap.add_argument("--no-copy-ref", action="store_true", help="skip the device-to-device copy measured beside the roofline")
     ap.add_argument("--records-depth", type=int, default=4, help="records legs: submits in flight (<= SCN_NUM_SLOTS)")
@@ -249,6 +253,176 @@ def welch_leg(torch, dev, local_rank, seed, npsd, steps, warmup, rotate=0, pinne
             raise ParityError(f"C5 output differs from the oracle: {str(e)[:300]}")
     plan.close()
     return elapsed, new_samples
+
+
+def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60, sync=None, threshold=10.0):
+    """BASELINE config 4 in its steady state, the ONE collective inside the timed region: this rank sweeps its contiguous shard of the
+    n_centres-entry table once per step (one launch per sweep, launches of at most 8192 buffers; four slots in flight, each on its
+    own stream below 8192 buffers), and every launch's ordered hit list goes to rank 0 through scn_gather_post / scn_gather_wait on
+    a communicator created ONCE, before the region -- posted two launches behind the newest submit, waited for two launches later,
+    so that the exchange runs beside the next sweeps' kernels.  Timed twice over the same launches: without the gather (the
+    counts are collected at the same place) and with it.  Returns the figures; raises ParityError when the root's last list
+    differs from the planted emitters' closed form."""
+    import ctypes as C
+
+    from scanner_amd import Plan, capi, sweep, synth
+
+    n = 4096
+    _, fc_all = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0)
+    first, fc = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
+    shard = len(fc)
+    nb = min(shard, 8192)
+    chunks = [(lo, min(lo + nb, shard)) for lo in range(0, shard, nb)]
+    centres, i0 = synth.c4_emitters(n_centres, n)
+    step_bytes = shard * n * 12
+    R = max(2, -(-(3 << 29) // step_bytes))
+    raws = [synth.c4_shard_torch(n, first, shard, centres, i0, seed=4 + 1000 * r, device=dev) for r in range(R)]
+    outs = [torch.empty((shard, n), dtype=torch.float32, device=dev) for _ in range(R)]
+    seq = np.arange(first, first + shard, dtype=np.uint64)
+    D, LAG = 4, 2
+    hit_cap = nb * 64
+    cap = 7 * (-(-nb // 4) + 1) * 2          # per launch: an emitter on every 4th centre, seven bins each, and as much again
+    flags = capi.OUT_SPECTRUM | capi.OUT_HITS | (capi.PLAN_OVERLAP_SLOTS if nb < 8192 else 0)
+    plan = Plan(n, FS, threshold, max_batch=nb, max_hits=hit_cap, device_id=local_rank, flags=flags)
+    plan.set_table(fc)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    prep = [[(C.c_void_p(raws[r][lo:hi].data_ptr()), hi - lo, lo, vp(seq[lo:hi]), C.c_void_p(outs[r][lo:hi].data_ptr())) for lo, hi in chunks]
+            for r in range(R)]
+    g = sweep.HitGather(dev)               # rendezvous + ncclCommInitRank: once, outside every timed region
+    L = capi.lib()
+    post, wait_ = L.scn_gather_post, L.scn_gather_wait
+    comm, ph = g._comm, plan.handle
+    tk = C.c_uint32()
+    lst, tot = C.c_void_p(), C.c_uint64()
+    per_rank = np.zeros(world, np.uint32)
+    per_rank_p = vp(per_rank)
+    state = {"launch": 0, "records": 0, "lists": 0, "wait_s": 0.0, "last": None, "keep": False}
+    tickets = [None] * D
+    pending = [False] * D
+
+    def finish(s):                         # the gather of the launch in slot s has arrived (root: the list is read where it lies)
+        t0 = time.perf_counter()
+        st = wait_(comm, tickets[s], C.byref(lst), C.byref(tot), per_rank_p)
+        state["wait_s"] += time.perf_counter() - t0
+        if st:
+            capi.check(st, "scn_gather_wait")
+        tickets[s] = None
+        state["records"] += tot.value
+        state["lists"] += 1
+        if state["keep"] and rank == 0:
+            raw = np.ctypeslib.as_array(C.cast(lst, C.POINTER(C.c_uint8)), shape=(tot.value * 24,)).view(capi.HIT_DTYPE) if tot.value else np.zeros(0, capi.HIT_DTYPE)
+            state["last"].append(raw.copy())
+
+    def launch(k, a, gather):
+        j = state["launch"]
+        s = j % D
+        if tickets[s] is not None:
+            finish(s)
+        elif pending[s]:
+            plan.collect_counts(s)
+            pending[s] = False
+        plan.submit_prepared_indexed(s, *a)
+        pending[s] = True
+        state["launch"] = j + 1
+        if j >= LAG:
+            s2 = (j - LAG) % D
+            plan.collect_counts(s2)
+            pending[s2] = False
+            if gather:
+                st = post(comm, ph, s2, 0, cap, C.byref(tk))
+                if st:
+                    capi.check(st, "scn_gather_post")
+                tickets[s2] = tk.value
+
+    def drain(gather):
+        j = state["launch"]
+        for jj in range(max(j - LAG, 0), j):   # the launches not yet collected, oldest first
+            s2 = jj % D
+            if pending[s2]:
+                plan.collect_counts(s2)
+                pending[s2] = False
+                if gather:
+                    st = post(comm, ph, s2, 0, cap, C.byref(tk))
+                    if st:
+                        capi.check(st, "scn_gather_post")
+                    tickets[s2] = tk.value
+        for jj in range(max(j - D, 0), j):
+            if tickets[jj % D] is not None:
+                finish(jj % D)
+
+    def run(k_steps, gather, keep_last=False):
+        for k in range(k_steps):
+            if keep_last and k == k_steps - 1:
+                drain(gather)                  # everything before the last sweep has arrived; now record the last sweep's lists
+                state["keep"], state["last"] = True, []
+            for a in prep[k % R]:
+                launch(k, a, gather)
+        drain(gather)
+        state["keep"] = False
+
+    def timed(gather):
+        run(warm, gather)
+        torch.cuda.synchronize()
+        if sync:
+            sync()
+        state["records"] = state["lists"] = 0
+        state["wait_s"] = 0.0
+        t0 = time.perf_counter()
+        run(steps, gather, keep_last=gather)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if sync:
+            sync()
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        return el
+
+    try:
+        el_plain = timed(False)
+        el_gather = timed(True)
+        lists, records, wait_s = state["lists"], state["records"], state["wait_s"]
+        last = np.concatenate(state["last"]) if (rank == 0 and state["last"]) else np.zeros(0, capi.HIT_DTYPE)
+        # the gather alone, nothing to hide behind: post + wait back to back on an idle GPU (every rank takes part)
+        plan.submit_prepared_indexed(0, *prep[0][0])
+        plan.collect_counts(0)
+        lat = []
+        for _ in range(40):
+            t0 = time.perf_counter()
+            capi.check(post(comm, ph, 0, 0, cap, C.byref(tk)), "scn_gather_post")
+            capi.check(wait_(comm, tk.value, C.byref(lst), C.byref(tot), per_rank_p), "scn_gather_wait")
+            lat.append((time.perf_counter() - t0) * 1e6)
+        out = None
+        if rank == 0:
+            want = synth.c4_expected_hits(plan.window(), fc_all, centres, i0, n, FS, threshold)
+            ok, worst = compare_hit_lists(last, want)
+            sweep_us = el_plain / steps * 1e6
+            gsweep_us = el_gather / steps * 1e6
+            out = {"value": round(n_centres * n * steps / el_gather / 1e6, 1), "unit": "Msamples/s", "steps": steps, "scaling": "strong",
+                   "centres": n_centres, "centres_per_gpu": shard, "launches_per_sweep": len(chunks), "n_gpus": world,
+                   "sweep_us": round(sweep_us, 2), "sweep_with_gather_us": round(gsweep_us, 2),
+                   "exposed_gather_us": round(gsweep_us - sweep_us, 2), "exposed_frac": round((gsweep_us - sweep_us) / sweep_us, 4),
+                   "gather_us": round(float(np.median(lat)), 1), "gather_us_min": round(float(min(lat)), 1),
+                   "value_without_gather": round(n_centres * n * steps / el_plain / 1e6, 1),
+                   "lists_gathered": lists, "records_per_sweep": round(records / max(steps, 1), 1), "cap_per_rank": cap,
+                   "root_blocked_in_wait_us_per_sweep": round(wait_s / steps * 1e6, 2),
+                   "check": {"expected_hits": int(len(want)), "gathered_hits": int(len(last)), "match": bool(ok), "max_power_db_diff": worst,
+                             "of": "the LAST timed sweep's gathered list against the planted emitters' closed form"},
+                   "transport": ("scn_gather_post / scn_gather_wait: one fixed-size message per rank per launch (header + cap records), ONE group of "
+                                 "ncclSend / ncclRecv on the communicator's stream, compaction into the root's pinned list; posted two launches "
+                                 "behind the newest submit, waited for two launches later; communicator created once before the region"
+                                 + ("; one rank: no peers, the root's own part only" if world == 1 else "")),
+                   "workload": f"C4: {n_centres} centres x 4096-pt cfloat, {shard} per GPU per sweep over {world} GPU(s), a launch per "
+                               f"{'sweep' if len(chunks) == 1 else 'half sweep'}, four slots in flight"
+                               + (", each on its own stream (SCN_PLAN_OVERLAP_SLOTS)" if nb < 8192 else "") + ", the hit list of every launch gathered to rank 0"}
+            if not ok:
+                raise ParityError(f"C4 gathered list differs from the closed form: {out['check']}")
+        return out
+    finally:
+        g.close()
+        plan.close()
 
 
 def welch_roofline(elapsed, steps, new_samples, npsd, kind="cfloat"):
@@ -423,6 +597,9 @@ def config_legs(torch, dev, local_rank, steps=200):
                                 workload="C4 per-GPU share at 8 GPUs: centres [0, 2048) of the 16384-centre table x 4096-pt cfloat, a launch per "
                                          "sweep, each slot on its own stream (SCN_PLAN_OVERLAP_SLOTS), three in flight: launches overlap, so the "
                                          "step is shorter than one kernel's own begin-to-end time (frac_kernel_rocprof)")
+        # ... and the same share in steady state with the ONE collective inside the region: every sweep's hit list gathered through the
+        # one-rank communicator (no peers: pack + compaction + the root's wait -- what a rank adds to its own sweep)
+        legs["c4_share_gather"] = c4_gather_leg(torch, dev, local_rank, 0, 1, 2048, 3 * steps)
         # C5: 65536-pt 50%-overlap Welch PSD, 32 PSDs per submit, stream resident in HBM
         c5_check = {}
         el, new = welch_leg(torch, dev, local_rank, 5, 32, max(50, steps // 2), 10, check=c5_check)
@@ -545,6 +722,24 @@ def dry_run_main(args):
     with sweep.HitGather(torch.device("cpu")) as g:
         got, per_rank = g.gather(mine)
     elapsed = time.perf_counter() - t0
+    # the steady-state form's control flow (c4_gather_leg): a list per sweep, posted two sweeps behind, waited for two sweeps later,
+    # over the same message format (HitGather.post / wait on gloo)
+    sweeps, steady_ok, steady_lists = 7, True, 0
+    with sweep.HitGather(torch.device("cpu")) as g:
+        cap = max(1, 2 * len(want))          # (every rank must pass the same cap)
+        tickets = []
+        for sw in range(sweeps):
+            if len(tickets) == 2:
+                lst, _ = g.wait(tickets.pop(0))
+                if rank == 0:
+                    steady_ok &= compare_hit_lists(lst, want, power_tol=0.0)[0]
+                    steady_lists += 1
+            tickets.append(g.post(mine, cap_per_rank=cap))
+        for t in tickets:
+            lst, _ = g.wait(t)
+            if rank == 0:
+                steady_ok &= compare_hit_lists(lst, want, power_tol=0.0)[0]
+                steady_lists += 1
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:
@@ -557,7 +752,9 @@ def dry_run_main(args):
                                      f"rank(s), planted-emitter hit lists gathered to rank 0", "n": n, "centres": n_centres,
                          "batch_per_gpu": n_centres // world},
               "c4_check": {"expected_hits": int(len(want)), "gathered_hits": int(len(got)), "match": ok,
-                           "per_rank": [int(c) for c in per_rank]}})
+                           "per_rank": [int(c) for c in per_rank]},
+              "gather_every_sweep": {"sweeps": sweeps, "lists_gathered": steady_lists, "match": bool(steady_ok),
+                                     "transport": "HitGather.post / wait over gloo: the message format and header reading of scn_gather_post / scn_gather_wait"}})
         if not ok:
             sys.exit(3)
     if dist.is_initialized():
@@ -1131,6 +1328,22 @@ def main():
             all_hits, per_rank = fb._gather_torch(np.ascontiguousarray(hits, dtype=capi.HIT_DTYPE), 0)
             gather_info = {"transport": "torch.distributed fallback", "scn_gather_hits_error": res.get("error", "failed on another rank")}
     gather_ms = (time.perf_counter() - tg0) * 1e3
+
+    # BASELINE config 4 in steady state -- strong scaling, the hit list of every sweep gathered inside the timed region: a leg of its
+    # own (collective: every rank runs it), on the default N > 1 line as configs.c4 beside the weak-scaling value, and on --config c4
+    # --gather-every-sweep at any N
+    default_shape = not c4 and (n, args.kind, nb) == (4096, "cfloat", 8192) and args.plan_mode == "both" and not td
+    c4_steady = None
+    if not stuck and ((args.gather_every_sweep and c4) or (world > 1 and default_shape and not args.no_configs_leg)):
+        try:
+            c4_steady = c4_gather_leg(torch, dev, local_rank, rank, world, args.centres, max(200, min(args.steps, 2000)),
+                                      sync=dist.barrier if world > 1 else None, threshold=args.threshold)
+        except ParityError as e:
+            print(f"bench.py: {e}", file=sys.stderr)
+            sys.stdout.flush()
+            os._exit(3)
+        except Exception as e:  # a side leg must not cost the run its line (a rank that fails here fails on every rank: the calls are collective)
+            c4_steady = {"error": f"{type(e).__name__}: {e}"[:300]} if rank == 0 else None
     if rank == 0:
         sid = all_hits["seq_id"].astype(np.int64)
         order_ok = bool(np.all((np.diff(sid) > 0) | ((np.diff(sid) == 0) & (np.diff(all_hits["i"].astype(np.int64)) > 0)))) if len(all_hits) > 1 else True
@@ -1265,6 +1478,11 @@ def main():
                 print(f"bench.py: {e}", file=sys.stderr)
                 plan.close()
                 sys.exit(3)
+        if c4_steady is not None:
+            if c4:
+                out["gather_every_sweep"] = c4_steady
+            else:
+                out["configs"] = dict(out.get("configs") or {}, c4=c4_steady)
         # the reference's CPU path beside the GPU number, in the same run on the same box: on rank 0 at every N (north_star; the
         # other ranks wait at the closing barrier meanwhile -- it is outside every timed region)
         if not args.no_cpu_baseline and not td:

@@ -36,7 +36,7 @@ extern "C" {
 
 #define SCN_ABI_VERSION 5 /* 3: SCN_NUM_SLOTS 4, scn_gather_hits_device, scn_gather_fetch, scn_size_path; 4: scn_plan_set_table, scn_submit*_indexed;
                              5: scn_welch_desc.sample_kind / enob / correct_dc (carved out of its reserved words: same size, zero = the
-                             version-4 behaviour), scn_welch_partition */
+                             version-4 behaviour), scn_welch_partition, scn_gather_post, scn_gather_wait */
 
 /* status codes */
 enum {
@@ -272,9 +272,25 @@ SCN_API int scn_frequency_table(uint32_t sample_rate, double start, double stop,
  *                        root's device copy
  *   scn_gather_layout    host-only helper: offsets[r] = first index of rank r's records in the gathered list,
  *                        offsets[world_size] = total
+ *   scn_gather_post / scn_gather_wait   the STEADY-STATE form, for a list per sweep (the table wraps every sweep,
+ *                        frequencyTable.cpp:39-47, and a GPU's share of a sweep takes tens of microseconds): collective and
+ *                        ASYNCHRONOUS.  Every rank's part is the collected slot's device list (as scn_gather_hits_device) and
+ *                        travels in ONE fixed-size message -- a header and cap_per_rank records, the same on every rank -- so
+ *                        no counts are exchanged first and nothing waits for the host: pack -> one group of ncclSend / ncclRecv
+ *                        -> compaction into the root's pinned list, all on the communicator's stream, overlapping the next
+ *                        sweep's kernels.  scn_gather_post returns a ticket at once (up to SCN_GATHER_TICKETS in flight; the
+ *                        slot must not be submitted again before its ticket has been waited for); scn_gather_wait blocks until
+ *                        that post has completed and, on the root, hands out the rank-major list IN PLACE (pinned memory, valid
+ *                        until SCN_GATHER_TICKETS further posts), its length and the per-rank counts.  A rank whose list exceeds
+ *                        cap_per_rank sends its first cap_per_rank records (SCN_E_TRUNCATED from its post and from the root's
+ *                        wait, per_rank holding the true counts); a rank that cannot prepare its part still sends its message,
+ *                        marked, and the ROOT's wait reports it (SCN_E_COMM) -- unlike the forms above the other ranks do not
+ *                        learn of it: that is the price of having no round trip.  Every rank posts the same sequence of
+ *                        (root, cap_per_rank).
  * RCCL is loaded on first use (dlopen), not at link time.
  * ------------------------------------------------------------------------------------ */
 #define SCN_COMM_ID_BYTES 128
+#define SCN_GATHER_TICKETS 4 /* scn_gather_post: posts in flight per communicator */
 typedef struct scn_comm scn_comm;
 SCN_API int scn_comm_unique_id(void *id);
 SCN_API int scn_comm_create(const void *id, int rank, int world_size, int device_id, scn_comm **out);
@@ -285,6 +301,8 @@ SCN_API int scn_gather_hits_device(scn_comm *comm, scn_plan *plan, int slot, uin
                            uint64_t *n_total, uint32_t *per_rank);
 SCN_API int scn_gather_fetch(scn_comm *comm, uint64_t first, scn_hit *out, uint64_t cap, uint64_t *n_written);
 SCN_API int scn_gather_layout(const uint32_t *per_rank, uint32_t world_size, uint64_t *offsets);
+SCN_API int scn_gather_post(scn_comm *comm, scn_plan *plan, int slot, uint32_t root, uint32_t cap_per_rank, uint32_t *ticket);
+SCN_API int scn_gather_wait(scn_comm *comm, uint32_t ticket, const scn_hit **list, uint64_t *n_total, uint32_t *per_rank);
 
 /* HackRFSource::interpolateSamples (hackRFSource.cpp:186-222), the in-band header of HackRF
  * sweep-mode transfers: when the transfer starts with the bytes 0x7F 0x7F, bytes 2..9 hold the

@@ -23,6 +23,7 @@ NUM_SLOTS = 4
 ABI_VERSION = 5
 PATH_UNSUPPORTED, PATH_FUSED, PATH_FOUR_STEP, PATH_STAGED, PATH_BLUESTEIN = range(5)
 COMM_ID_BYTES = 128
+GATHER_TICKETS = 4
 
 BYTES_PER_SAMPLE = {KIND_BYTE_COMPLEX: 2, KIND_SHORT: 4, KIND_SHORT_COMPLEX: 4, KIND_FLOAT_COMPLEX: 8}
 
@@ -97,6 +98,8 @@ SYMBOLS = {
     "scn_slot_stream": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "scn_device_spectrum": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "scn_plan_window": (C.c_int, [_vp, _vp, C.c_uint32]),
+    "scn_gather_post": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "scn_gather_wait": (C.c_int, [_vp, C.c_uint32, C.POINTER(_vp), C.POINTER(C.c_uint64), _vp]),
     "scn_welch_create": (C.c_int, [C.POINTER(WelchDesc), C.POINTER(_vp)]),
     "scn_welch_destroy": (C.c_int, [_vp]),
     "scn_welch_samples": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_size_t)]),

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -72,7 +73,22 @@ RcclApi &rccl() {
 
 }  // namespace
 
+// scn_gather_post / scn_gather_wait: a ring of posts in flight (scn_gather_protocol.h, the steady-state form)
+struct StreamGather {
+  uint32_t cap = 0;                  // records per rank per message (the buffers below are sized for it)
+  scn_hit *d_msg = nullptr;          // [SCN_GATHER_TICKETS][cap + 1]: this rank's outgoing messages (header + records)
+  scn_hit *d_ring = nullptr;         // root: [SCN_GATHER_TICKETS][world][cap + 1]: the messages as they arrive
+  scn_hit *h_list = nullptr;         // root: pinned [SCN_GATHER_TICKETS][world * cap]: the compacted, rank-major lists
+  ScnStreamHeader *h_head = nullptr; // root: pinned [SCN_GATHER_TICKETS][world]: the headers, for scn_gather_wait
+  hipEvent_t done[SCN_GATHER_TICKETS] = {};
+  bool posted[SCN_GATHER_TICKETS] = {};
+  bool as_root[SCN_GATHER_TICKETS] = {};
+  uint64_t seq_of[SCN_GATHER_TICKETS] = {};
+  uint64_t next_seq = 0;
+};
+
 struct scn_comm {
+  StreamGather sg;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   hipStream_t stream = nullptr;
@@ -174,6 +190,12 @@ int scn_comm_destroy(scn_comm *c) {
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_send) (void)hipFree(c->d_send);
   if (c->d_recv) (void)hipFree(c->d_recv);
+  if (c->sg.d_msg) (void)hipFree(c->sg.d_msg);
+  if (c->sg.d_ring) (void)hipFree(c->sg.d_ring);
+  if (c->sg.h_list) (void)hipHostFree(c->sg.h_list);
+  if (c->sg.h_head) (void)hipHostFree(c->sg.h_head);
+  for (int k = 0; k < SCN_GATHER_TICKETS; k++)
+    if (c->sg.done[k]) (void)hipEventDestroy(c->sg.done[k]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SCN_OK;
@@ -355,6 +377,156 @@ int scn_gather_hits_device(scn_comm *c, scn_plan *plan, int slot, uint32_t root,
   }
   if (n_total) *n_total = total;
   return gather_copy_out(c, all, all_cap, total);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The steady-state form (scn_gather_protocol.h): pack -> ONE group of fixed-size sends / receives -> compaction, all on the
+// communicator's stream; the host comes back for the result whenever it likes (scn_gather_wait).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+// message = [header][cap records]; the first `h.sent` records of `src` follow the header
+__global__ __launch_bounds__(256) void scn_gather_pack_kernel(const scn_hit *src, ScnStreamHeader h, scn_hit *msg) {
+  typedef unsigned long long u64;
+  const u64 *s = reinterpret_cast<const u64 *>(src);
+  u64 *d = reinterpret_cast<u64 *>(msg + 1);
+  const size_t words = (size_t)h.sent * 3u;  // 24-byte records as three 8-byte words: coalesced
+  for (size_t e = (size_t)blockIdx.x * 256u + threadIdx.x; e < words; e += (size_t)gridDim.x * 256u) d[e] = s[e];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<ScnStreamHeader *>(msg) = h;
+}
+
+// root: the world's messages [world][cap + 1] -> the rank-major list and the headers, both in pinned host memory.
+// grid = world x chunks; workgroup (r, c) finds rank r's place from the headers before it (world is a node's GPU count).
+__global__ __launch_bounds__(256) void scn_gather_compact_kernel(const scn_hit *ring, uint32_t world, uint32_t cap, uint64_t seq, scn_hit *list,
+                                                                  ScnStreamHeader *heads) {
+  typedef unsigned long long u64;
+  const uint32_t r = blockIdx.x % world, chunk = blockIdx.x / world, chunks = gridDim.x / world;
+  auto sent_of = [&](uint32_t q) -> uint32_t {
+    const ScnStreamHeader h = *reinterpret_cast<const ScnStreamHeader *>(ring + (size_t)q * (cap + 1u));
+    return (h.magic == SCN_STREAM_MAGIC && h.seq == seq && h.sent <= cap && h.sent <= h.count) ? h.sent : 0u;  // as scn_stream_outcome reads it
+  };
+  size_t off = 0;
+  for (uint32_t q = 0; q < r; q++) off += sent_of(q);
+  const size_t words = (size_t)sent_of(r) * 3u;
+  const u64 *s = reinterpret_cast<const u64 *>(ring + (size_t)r * (cap + 1u) + 1u);
+  u64 *d = reinterpret_cast<u64 *>(list + off);
+  for (size_t e = (size_t)chunk * 256u + threadIdx.x; e < words; e += (size_t)chunks * 256u) d[e] = s[e];
+  if (chunk == 0 && threadIdx.x == 0) heads[r] = *reinterpret_cast<const ScnStreamHeader *>(ring + (size_t)r * (cap + 1u));
+}
+
+int stream_buffers(scn_comm *c, uint32_t cap, bool root) {
+  StreamGather &g = c->sg;
+  if (g.cap != cap) {
+    for (int k = 0; k < SCN_GATHER_TICKETS; k++)
+      if (g.posted[k]) return scn_set_last_error(SCN_E_STATE, "cap_per_rank changed (%u -> %u) while a post is in flight", g.cap, cap);
+    if (g.d_msg) (void)hipFree(g.d_msg);
+    if (g.d_ring) (void)hipFree(g.d_ring);
+    if (g.h_list) (void)hipHostFree(g.h_list);
+    if (g.h_head) (void)hipHostFree(g.h_head);
+    g.d_msg = g.d_ring = g.h_list = nullptr;
+    g.h_head = nullptr;
+    g.cap = cap;
+  }
+  const size_t msg = (size_t)cap + 1u;
+  if (!g.d_msg) SCN_G_HIP(hipMalloc(&g.d_msg, sizeof(scn_hit) * msg * SCN_GATHER_TICKETS));
+  for (int k = 0; k < SCN_GATHER_TICKETS; k++)
+    if (!g.done[k]) SCN_G_HIP(hipEventCreateWithFlags(&g.done[k], hipEventDisableTiming));
+  if (root) {
+    if (!g.d_ring) SCN_G_HIP(hipMalloc(&g.d_ring, sizeof(scn_hit) * msg * (size_t)c->world * SCN_GATHER_TICKETS));
+    if (!g.h_list) SCN_G_HIP(hipHostMalloc(&g.h_list, sizeof(scn_hit) * std::max<size_t>((size_t)cap * c->world, 1u) * SCN_GATHER_TICKETS, hipHostMallocDefault));
+    if (!g.h_head) SCN_G_HIP(hipHostMalloc(&g.h_head, sizeof(ScnStreamHeader) * (size_t)c->world * SCN_GATHER_TICKETS, hipHostMallocDefault));
+  }
+  return SCN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int scn_gather_post(scn_comm *c, scn_plan *plan, int slot, uint32_t root, uint32_t cap_per_rank, uint32_t *ticket) {
+  if (!c || !ticket) return scn_set_last_error(SCN_E_INVALID, "null argument");
+  if (root >= (uint32_t)c->world || cap_per_rank == 0) return scn_set_last_error(SCN_E_INVALID, "root %u / cap_per_rank %u out of range", root, cap_per_rank);
+  RcclApi &api = rccl();
+  StreamGather &g = c->sg;
+  const uint32_t tk = (uint32_t)(g.next_seq % SCN_GATHER_TICKETS);
+  if (g.posted[tk]) return scn_set_last_error(SCN_E_STATE, "%d posts in flight: scn_gather_wait the oldest (ticket %u) first", SCN_GATHER_TICKETS, tk);
+  SCN_G_HIP(hipSetDevice(c->device));
+  const bool is_root = (uint32_t)c->rank == root;
+  if (int st = stream_buffers(c, cap_per_rank, is_root)) return st;  // (nothing has been enqueued: the peers see a post that never came, like any rank that never calls)
+  // this rank's part: whatever goes wrong from here on travels in the header, the message still goes out
+  const scn_hit *d_list = nullptr;
+  uint32_t n_local = 0;
+  int dev = c->device;
+  int status = plan ? scn_plan_device_hits(plan, slot, &d_list, &n_local, &dev) : scn_set_last_error(SCN_E_INVALID, "null plan");
+  if (status == SCN_OK && dev != c->device) status = scn_set_last_error(SCN_E_INVALID, "the plan lives on device %d, the communicator on device %d", dev, c->device);
+  if (status != SCN_OK) n_local = 0;
+  ScnStreamHeader h;
+  h.count = n_local;
+  h.sent = n_local < cap_per_rank ? n_local : cap_per_rank;
+  h.status = (uint32_t)(status != SCN_OK ? status : h.sent < n_local ? SCN_E_TRUNCATED : SCN_OK);
+  h.magic = SCN_STREAM_MAGIC;
+  h.seq = g.next_seq;
+  const size_t msg = (size_t)cap_per_rank + 1u;
+  scn_hit *out = is_root ? g.d_ring + ((size_t)tk * c->world + c->rank) * msg : g.d_msg + (size_t)tk * msg;
+  const uint32_t blocks = h.sent ? std::min<uint32_t>((h.sent * 3u + 255u) / 256u, 64u) : 1u;
+  hipLaunchKernelGGL(scn_gather_pack_kernel, dim3(blocks), dim3(256), 0, c->stream, d_list, h, out);
+  SCN_G_HIP(hipGetLastError());
+  if (c->world > 1) {
+    ncclResult_t first_err = api.GroupStart();
+    if (first_err == ncclSuccess) {
+      if (is_root) {
+        for (int r = 0; r < c->world; r++)
+          if (r != c->rank) {
+            const ncclResult_t e = api.Recv(g.d_ring + ((size_t)tk * c->world + r) * msg, sizeof(scn_hit) * msg, ncclUint8, r, c->comm, c->stream);
+            if (e != ncclSuccess && first_err == ncclSuccess) first_err = e;  // keep posting: the peers' sends are coming
+          }
+      } else {
+        first_err = api.Send(out, sizeof(scn_hit) * msg, ncclUint8, (int)root, c->comm, c->stream);
+      }
+      const ncclResult_t e = api.GroupEnd();  // always closed
+      if (e != ncclSuccess && first_err == ncclSuccess) first_err = e;
+    }
+    if (first_err != ncclSuccess) return scn_set_last_error(SCN_E_COMM, "scn_gather_post: %s", api.GetErrorString(first_err));
+  }
+  if (is_root) {
+    const uint32_t chunks = std::max<uint32_t>(1u, std::min<uint32_t>((cap_per_rank * 3u + 2047u) / 2048u, 16u));
+    hipLaunchKernelGGL(scn_gather_compact_kernel, dim3((uint32_t)c->world * chunks), dim3(256), 0, c->stream, g.d_ring + (size_t)tk * c->world * msg,
+                       (uint32_t)c->world, cap_per_rank, h.seq, g.h_list + (size_t)tk * cap_per_rank * c->world, g.h_head + (size_t)tk * c->world);
+    SCN_G_HIP(hipGetLastError());
+  }
+  SCN_G_HIP(hipEventRecord(g.done[tk], c->stream));
+  g.posted[tk] = true;
+  g.as_root[tk] = is_root;
+  g.seq_of[tk] = h.seq;
+  g.next_seq++;
+  *ticket = tk;
+  return status == SCN_OK && h.sent < n_local
+             ? scn_set_last_error(SCN_E_TRUNCATED, "slot %d holds %u hits, a message %u (cap_per_rank): the first %u went out", slot, n_local, cap_per_rank, h.sent)
+             : status;
+}
+
+int scn_gather_wait(scn_comm *c, uint32_t ticket, const scn_hit **list, uint64_t *n_total, uint32_t *per_rank) {
+  if (!c) return scn_set_last_error(SCN_E_INVALID, "null communicator");
+  if (list) *list = nullptr;
+  if (n_total) *n_total = 0;
+  StreamGather &g = c->sg;
+  if (ticket >= SCN_GATHER_TICKETS || !g.posted[ticket]) return scn_set_last_error(SCN_E_STATE, "ticket %u is not in flight", ticket);
+  SCN_G_HIP(hipSetDevice(c->device));
+  const hipError_t e = hipEventSynchronize(g.done[ticket]);
+  g.posted[ticket] = false;
+  if (e != hipSuccess) return scn_set_last_error(SCN_E_HIP, "scn_gather_wait: %s", hipGetErrorString(e));
+  if (!g.as_root[ticket]) return SCN_OK;
+  const ScnGatherOutcome o = scn_stream_outcome(g.h_head + (size_t)ticket * c->world, (uint32_t)c->world, g.cap, g.seq_of[ticket]);
+  if (per_rank) memcpy(per_rank, o.counts.data(), sizeof(uint32_t) * (size_t)c->world);
+  if (n_total) *n_total = o.total;
+  if (list) *list = g.h_list + (size_t)ticket * g.cap * c->world;
+  if (o.status == SCN_OK) return SCN_OK;
+  if (o.status == SCN_E_TRUNCATED)
+    return scn_set_last_error(SCN_E_TRUNCATED, "rank %d holds %u hits, its message %u (cap_per_rank): the list has the first %u of them", o.bad_rank,
+                              o.counts[o.bad_rank], g.cap, g.cap);
+  return scn_set_last_error(SCN_E_COMM, o.step == 1 ? "rank %d could not prepare its part of the gather (status %u)"
+                                                    : "the message of rank %d does not belong to this post (status %u): the ranks' posts are out of step",
+                            o.bad_rank, o.bad_status);
 }
 
 }  // extern "C"

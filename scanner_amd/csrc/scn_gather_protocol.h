@@ -107,3 +107,56 @@ ScnGatherOutcome scn_gather_protocol(Transport &t, uint32_t n_local, int local_s
   o.step = 3;
   return o;
 }
+
+// ---- the steady-state form: one list PER SWEEP with no host round trip inside (scn_gather_post / scn_gather_wait) ----------
+// The table wraps every sweep (frequencyTable.cpp:39-47) and the per-GPU share of a sweep takes tens of microseconds, so a
+// gather whose steps each wait for the host (the three-step protocol above: two announces and the transfers, a stream
+// synchronisation each) cannot keep up.  Here every rank sends ONE fixed-size message to the root -- a header of one record's size
+// followed by cap records, of which the first `sent` are meant -- so that every size is known to every rank without exchanging
+// counts and the whole gather is stream-ordered: pack -> one group of sends / receives -> compaction into the root's pinned list.
+// What the three-step form guarantees to EVERY rank (all return an error when anyone failed) only the ROOT learns here: a rank
+// that could not prepare its part still sends its message, marked; the root's scn_gather_wait names it.
+#define SCN_STREAM_MAGIC 0x53434e47u
+struct ScnStreamHeader {
+  uint32_t count;   // records of this rank's ordered list (the true number)
+  uint32_t status;  // SCN_OK, SCN_E_TRUNCATED (count > cap: the first cap records follow) or why the part could not be prepared
+  uint32_t sent;    // records that follow: min(count, cap), 0 on a failure
+  uint32_t magic;   // SCN_STREAM_MAGIC
+  uint64_t seq;     // the post's sequence number on this communicator: a message of another post is a broken collective order
+};
+static_assert(sizeof(ScnStreamHeader) == sizeof(scn_hit), "the header takes one record's place in the message");
+
+// what the root makes of the headers of one post: counts = the ranks' true counts, offsets by what was sent (= the list)
+inline ScnGatherOutcome scn_stream_outcome(const ScnStreamHeader *h, uint32_t world, uint32_t cap, uint64_t seq) {
+  ScnGatherOutcome o;
+  o.step = 3;
+  o.counts.assign(world, 0u);
+  o.offsets.assign(world + 1u, 0u);
+  for (uint32_t r = 0; r < world; r++) {
+    const bool intact = h[r].magic == SCN_STREAM_MAGIC && h[r].seq == seq && h[r].sent <= cap && h[r].sent <= h[r].count;
+    o.counts[r] = intact ? h[r].count : 0u;
+    o.offsets[r + 1u] = o.offsets[r] + (intact ? h[r].sent : 0u);
+    if (o.bad_rank >= 0) continue;
+    if (!intact) {
+      o.bad_rank = (int)r;
+      o.bad_status = (uint32_t)SCN_E_COMM;
+      o.status = SCN_E_COMM;
+    } else if (h[r].status != (uint32_t)SCN_OK && !(h[r].status == (uint32_t)SCN_E_TRUNCATED && h[r].sent < h[r].count)) {
+      // (SCN_E_TRUNCATED with nothing cut off is the PLAN's device list being shorter than its hits: nothing was sent)
+      o.bad_rank = (int)r;
+      o.bad_status = h[r].status;
+      o.status = SCN_E_COMM;
+      o.step = 1;
+    }
+  }
+  o.total = o.offsets[world];
+  if (o.status == SCN_OK)
+    for (uint32_t r = 0; r < world; r++)
+      if (h[r].sent < h[r].count) {  // a rank's list did not fit its message: the list holds its first cap records
+        o.status = SCN_E_TRUNCATED;
+        o.bad_rank = (int)r;
+        o.bad_status = (uint32_t)SCN_E_TRUNCATED;
+        break;
+      }
+  return o;
+}

@@ -97,6 +97,119 @@ class HitGather:
             raise RuntimeError("gather_device needs the RCCL communicator (a cuda device)")
         return self._gather_rccl(None, dst, plan=plan, slot=slot)
 
+    # ---- the steady-state form: a list per sweep, posted asynchronously (scn_gather_post / scn_gather_wait) ----------------
+    def post(self, plan_or_hits, slot=0, cap_per_rank=8192, dst=0, local_status=capi.OK):
+        """Collective, asynchronous.  On a GPU: `plan_or_hits` is a Plan whose `slot` has been collected; its device list
+        travels in one fixed-size message (a header + cap_per_rank records) on the communicator's stream, and the call
+        returns a ticket at once (capi.GATHER_TICKETS in flight; the slot must not be submitted again before wait(ticket)).
+        A rank whose part cannot go out whole raises AFTER having posted -- its ticket is in .last_ticket and must still
+        be waited for.  On CPU (gloo): `plan_or_hits` is this rank's ordered scn_hit array, same message format over
+        torch.distributed (the control-flow twin the world-8 dry run exercises)."""
+        if self._comm:
+            tk = C.c_uint32()
+            st = self._L_post(self._comm, plan_or_hits.handle, slot, dst, cap_per_rank, C.byref(tk))
+            self.last_ticket = tk.value
+            if st:
+                capi.check(st, "scn_gather_post")
+            return tk.value
+        return self._post_torch(np.ascontiguousarray(plan_or_hits, dtype=capi.HIT_DTYPE), cap_per_rank, dst, local_status)
+
+    def wait(self, ticket, copy=True):
+        """Blocks until post `ticket` has completed.  Root: (the rank-major list, per-rank true counts) -- the list is a
+        view of the communicator's pinned memory with copy=False (valid for GATHER_TICKETS further posts); raises
+        ScannerError(E_TRUNCATED) when a rank's list did not fit its message, ScannerError(E_COMM) naming the rank that
+        could not prepare its part.  Other ranks: (empty, zeros)."""
+        if not self._comm:
+            return self._wait_torch(ticket)
+        ptr, total = C.c_void_p(), C.c_uint64()
+        per_rank = np.zeros(self.world, np.uint32)
+        st = self._L_wait(self._comm, ticket, C.byref(ptr), C.byref(total), per_rank.ctypes.data_as(C.c_void_p))
+        self.last_per_rank = per_rank
+        if not ptr.value or not total.value:
+            raw = np.zeros(0, capi.HIT_DTYPE)
+        else:
+            raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(total.value * capi.HIT_DTYPE.itemsize,)).view(capi.HIT_DTYPE)
+        self.last_list = raw.copy() if copy else raw   # (what did arrive stays readable after a truncated / marked post)
+        if st:
+            capi.check(st, "scn_gather_wait")
+        return self.last_list, per_rank
+
+    @property
+    def _L_post(self):
+        return capi.lib().scn_gather_post
+
+    @property
+    def _L_wait(self):
+        return capi.lib().scn_gather_wait
+
+    _STREAM_MAGIC = 0x53434E47
+    _HEAD = np.dtype([("count", "<u4"), ("status", "<u4"), ("sent", "<u4"), ("magic", "<u4"), ("seq", "<u8")])
+
+    def _post_torch(self, hits, cap, dst, local_status):
+        import torch
+        import torch.distributed as dist
+
+        st = getattr(self, "_tickets", None)
+        if st is None:
+            st = self._tickets = {"next": 0, "slots": [None] * capi.GATHER_TICKETS}
+        tk = st["next"] % capi.GATHER_TICKETS
+        if st["slots"][tk] is not None:
+            raise capi.ScannerError(capi.E_STATE, "gather post", f"{capi.GATHER_TICKETS} posts in flight")
+        n = len(hits) if local_status == capi.OK else 0
+        sent = min(n, cap)
+        msg = np.zeros(cap + 1, capi.HIT_DTYPE)
+        head = np.zeros(1, self._HEAD)
+        head[0] = (n, local_status if local_status != capi.OK else (capi.E_TRUNCATED if sent < n else capi.OK), sent, self._STREAM_MAGIC, st["next"])
+        msg[:1] = head.view(capi.HIT_DTYPE)
+        msg[1:1 + sent] = hits[:sent]
+        buf = torch.from_numpy(msg.view(np.uint8).reshape(-1).copy())
+        out = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == dst else None
+        work = dist.gather(buf, out, dst=dst, group=self.group, async_op=True) if self.world > 1 else None
+        if self.world == 1:
+            out = [buf]
+        st["slots"][tk] = (work, out, cap, st["next"], dst, buf)
+        st["next"] += 1
+        self.last_ticket = tk
+        if local_status != capi.OK:
+            raise capi.ScannerError(local_status, "gather post", "this rank could not prepare its part")
+        if sent < n:
+            raise capi.ScannerError(capi.E_TRUNCATED, "gather post", f"{n} hits, a message holds {cap}")
+        return tk
+
+    def _wait_torch(self, ticket):
+        st = getattr(self, "_tickets", None)
+        if st is None or ticket >= capi.GATHER_TICKETS or st["slots"][ticket] is None:
+            raise capi.ScannerError(capi.E_STATE, "gather wait", f"ticket {ticket} is not in flight")
+        work, out, cap, seq, dst, _ = st["slots"][ticket]
+        st["slots"][ticket] = None
+        if work is not None:
+            work.wait()
+        per_rank = np.zeros(self.world, np.uint32)
+        if self.rank != dst:
+            return np.zeros(0, capi.HIT_DTYPE), per_rank
+        # the root's reading of the headers: scn_stream_outcome (scn_gather_protocol.h), restated
+        parts, bad, trunc = [], None, None
+        for r in range(self.world):
+            m = out[r].numpy().view(capi.HIT_DTYPE)
+            h = m[:1].view(self._HEAD)[0]
+            intact = h["magic"] == self._STREAM_MAGIC and h["seq"] == seq and h["sent"] <= cap and h["sent"] <= h["count"]
+            if not intact:
+                bad = bad or (r, capi.E_COMM, "does not belong to this post")
+                continue
+            per_rank[r] = h["count"]
+            parts.append(m[1:1 + int(h["sent"])])
+            if h["status"] != capi.OK and not (h["status"] == capi.E_TRUNCATED and h["sent"] < h["count"]):
+                bad = bad or (r, int(h["status"]), "could not prepare its part of the gather")
+            elif h["sent"] < h["count"]:
+                trunc = trunc if trunc is not None else r
+        self.last_per_rank = per_rank
+        self.last_list = np.concatenate(parts) if parts else np.zeros(0, capi.HIT_DTYPE)
+        if bad:
+            raise capi.ScannerError(capi.E_COMM, "gather wait", f"rank {bad[0]} {bad[2]} (status {bad[1]})")
+        if trunc is not None:
+            raise capi.ScannerError(capi.E_TRUNCATED, "gather wait", f"rank {trunc} holds {per_rank[trunc]} hits, its message {cap}")
+        return self.last_list, per_rank
+
     def _gather_torch(self, hits, dst, local_status=capi.OK):
         """The steps of scn_gather_protocol.h over torch.distributed: all-gather {count, status}; if anybody announced a
         failure every rank raises and nothing is transferred; else the records go to dst."""

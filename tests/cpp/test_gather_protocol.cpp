@@ -166,6 +166,46 @@ int main() {
     CHECK(st[0] == SCN_E_NOMEM && w->transfers == 0);
     delete w;
   }
+  // ---- the steady-state form's root-side reading of the headers (scn_stream_outcome; scn_gather_post / scn_gather_wait) ----
+  for (uint32_t world : {1u, 3u, 8u}) {
+    const uint32_t cap = 10;
+    const uint64_t seq = 41;
+    std::vector<ScnStreamHeader> h(world);
+    for (uint32_t r = 0; r < world; r++) h[r] = ScnStreamHeader{r == 1 ? 0u : 3u + r, (uint32_t)SCN_OK, r == 1 ? 0u : 3u + r, SCN_STREAM_MAGIC, seq};
+    ScnGatherOutcome o = scn_stream_outcome(h.data(), world, cap, seq);
+    CHECK(o.status == SCN_OK && o.bad_rank < 0);
+    uint64_t run_ = 0;
+    for (uint32_t r = 0; r < world; r++) {
+      CHECK(o.offsets[r] == run_ && o.counts[r] == h[r].count);
+      run_ += h[r].sent;
+    }
+    CHECK(o.total == run_ && o.offsets[world] == run_);
+    // a rank's list did not fit its message: the list holds its first cap records, the true count is reported
+    std::vector<ScnStreamHeader> t = h;
+    t[world - 1].count = 25;
+    t[world - 1].sent = cap;
+    t[world - 1].status = (uint32_t)SCN_E_TRUNCATED;
+    o = scn_stream_outcome(t.data(), world, cap, seq);
+    CHECK(o.status == SCN_E_TRUNCATED && o.bad_rank == (int)world - 1 && o.counts[world - 1] == 25 && o.total == run_ - h[world - 1].sent + cap);
+    // a rank that could not prepare its part: marked message, nothing of it in the list, the root names it
+    t = h;
+    t[0] = ScnStreamHeader{0u, (uint32_t)SCN_E_STATE, 0u, SCN_STREAM_MAGIC, seq};
+    o = scn_stream_outcome(t.data(), world, cap, seq);
+    CHECK(o.status == SCN_E_COMM && o.bad_rank == 0 && o.bad_status == (uint32_t)SCN_E_STATE && o.step == 1 && o.offsets[1] == 0);
+    // ... including the plan whose device list is shorter than its hits (SCN_E_TRUNCATED with nothing cut off in the MESSAGE)
+    t[0].status = (uint32_t)SCN_E_TRUNCATED;
+    o = scn_stream_outcome(t.data(), world, cap, seq);
+    CHECK(o.status == SCN_E_COMM && o.bad_rank == 0 && o.bad_status == (uint32_t)SCN_E_TRUNCATED);
+    // a message of another post (the ranks' posts out of step), a corrupt one, one claiming more than fits: broken collective order
+    for (int kind = 0; kind < 3; kind++) {
+      t = h;
+      if (kind == 0) t[world - 1].seq = seq - 1;
+      if (kind == 1) t[world - 1].magic = 0;
+      if (kind == 2) t[world - 1].sent = t[world - 1].count = cap + 1;
+      o = scn_stream_outcome(t.data(), world, cap, seq);
+      CHECK(o.status == SCN_E_COMM && o.bad_rank == (int)world - 1 && o.step == 3 && o.counts[world - 1] == 0 && o.total == run_ - h[world - 1].sent);
+    }
+  }
   if (g_failures) return 1;
   printf("gather protocol tests ok\n");
   return 0;

@@ -102,6 +102,32 @@ def test_default_line_carries_a_leg_per_baseline_config():
             assert k in g, (leg, k)
     assert c["c3"]["algorithmic_bytes_per_launch"] == 4096 * 8192 * 8 and c["c4_share"]["algorithmic_bytes_per_launch"] == 2048 * 4096 * 12
     assert c["c4_share"]["submits_in_flight"] == 3
+    # C5's timed output is held to the oracle in the same run ...
+    assert c["c5"]["c5_check"]["match"] is True and c["c5"]["c5_check"]["psds_checked"] == [0, 31]
+    # ... and the C4 share runs once more in steady state with the ONE collective inside the timed region
+    check_gather_leg(c["c4_share_gather"], centres=2048, per_gpu=2048)
+
+
+def check_gather_leg(g, centres, per_gpu):
+    for k in ("sweep_us", "sweep_with_gather_us", "exposed_gather_us", "gather_us", "records_per_sweep", "lists_gathered", "cap_per_rank"):
+        assert k in g and isinstance(g[k], (int, float)), k
+    assert g["scaling"] == "strong" and g["centres"] == centres and g["centres_per_gpu"] == per_gpu and g["n_gpus"] == 1
+    assert g["sweep_us"] > 0 and g["gather_us"] > 0 and abs(g["exposed_gather_us"] - (g["sweep_with_gather_us"] - g["sweep_us"])) < 0.02
+    assert g["check"]["match"] is True and g["check"]["gathered_hits"] == g["check"]["expected_hits"] == 7 * (centres // 4)
+    assert g["records_per_sweep"] == 7 * (centres // 4) and g["lists_gathered"] == g["steps"] * g["launches_per_sweep"]
+    assert "scn_gather_post" in g["transport"]
+
+
+def test_c4_line_with_a_gather_every_sweep():
+    """`bench.py --config c4 --gather-every-sweep`: the strong-scaling sweep with every launch's hit list gathered to rank 0 inside
+    the timed region, beside the same sweeps without the gather (one rank here: the communicator has no peers)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4", "--centres", "4096", "--steps", "4", "--warmup", "1",
+                          "--settle", "0.05", "--no-cpu-baseline", "--no-overlap-leg", "--no-records-leg", "--no-hits-only-leg", "--no-copy-ref",
+                          "--gather-every-sweep"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip())
+    assert d["scaling"] == "strong" and d["c4_check"]["match"] is True
+    check_gather_leg(d["gather_every_sweep"], centres=4096, per_gpu=4096)
 
 
 def test_bench_on_the_workers_kind_of_plan_and_in_time_domain_mode():

@@ -27,6 +27,8 @@ def test_self_launch_two_ranks_dry_run(built_lib):
     c = d["c4_check"]
     assert c["match"] is True and c["expected_hits"] == c["gathered_hits"] == 75 * 7
     assert sum(c["per_rank"]) == c["gathered_hits"] and len(c["per_rank"]) == 2 and min(c["per_rank"]) > 0
+    g = d["gather_every_sweep"]       # the steady-state form: a list per sweep, two posts in flight
+    assert g["match"] is True and g["lists_gathered"] == g["sweeps"] == 7
 
 
 def test_self_launch_three_ranks_ragged(built_lib):
@@ -84,3 +86,5 @@ def test_self_launch_eight_ranks_both_configs_one_shard_empty(built_lib):
         c = d["c4_check"]
         assert c["match"] is True and len(c["per_rank"]) == 8 and c["per_rank"][5] == 0
         assert all(v > 0 for r, v in enumerate(c["per_rank"]) if r != 5) and sum(c["per_rank"]) == c["gathered_hits"] == c["expected_hits"]
+        g = d["gather_every_sweep"]   # ... and so does every sweep's list in the steady-state form (post / wait, two in flight)
+        assert g["match"] is True and g["lists_gathered"] == g["sweeps"] == 7

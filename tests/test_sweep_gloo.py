@@ -146,3 +146,81 @@ def test_gather_with_a_failing_rank_over_gloo(tmp_path, built_lib):
         word, status, seconds = open(tmp_path / f"rank{r}.txt").read().split()
         assert word == "error" and float(seconds) < 20.0, (r, word, status, seconds)
         assert int(status) == (3 if r == 1 else 7)   # E_NOMEM on the failing rank, E_COMM on its peers
+
+
+def _stream_worker(rank, world, port, out_dir):
+    """Six sweeps, a list per sweep posted asynchronously (HitGather.post / wait over gloo: the message format and the root's
+    reading of the headers are those of scn_gather_post / scn_gather_wait), up to GATHER_TICKETS in flight."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scanner_amd import capi, sweep
+
+    def part(sweep_no, r):   # rank r's ordered records of sweep `sweep_no`: r + 2 * sweep_no + 1 of them (rank 1: none on odd sweeps)
+        k = 0 if (r == 1 and sweep_no % 2) else r + 2 * sweep_no + 1
+        h = np.zeros(k, capi.HIT_DTYPE)
+        h["seq_id"] = 1000 * r + np.arange(k)
+        h["i"] = 600 + sweep_no
+        h["power_db"] = 10.0 + r
+        h["freq_hz"] = 7 * r + sweep_no
+        return h
+
+    cap = 16
+    g = sweep.HitGather(torch.device("cpu"))
+    tickets, results = [], []
+    for sw in range(6):
+        if len(tickets) == capi.GATHER_TICKETS:
+            results.append(g.wait(tickets.pop(0))[0])
+        tickets.append(g.post(part(sw, rank), cap_per_rank=cap))
+    if rank == 0:                                   # a fifth post while four are in flight is refused before anything is sent
+        try:
+            g._post_torch(part(0, 0), cap, 0, capi.OK)
+            raise AssertionError("the ring should be full")
+        except capi.ScannerError as e:
+            assert e.status == capi.E_STATE
+    for t in tickets:
+        results.append(g.wait(t)[0])
+    if rank == 0:
+        for sw, got in enumerate(results):
+            want = np.concatenate([part(sw, r) for r in range(world)])
+            assert got.tobytes() == want.tobytes(), sw
+    else:
+        assert all(len(r) == 0 for r in results)
+    # sweep 7: rank 2's list does not fit its message -- it learns so from its own post, the root from its wait (true count reported)
+    big = part(9, rank)
+    try:
+        tk = g.post(big, cap_per_rank=18)
+        assert len(big) <= 18
+    except capi.ScannerError as e:
+        assert e.status == capi.E_TRUNCATED and len(big) > 18
+        tk = g.last_ticket
+    try:
+        g.wait(tk)
+        assert rank != 0
+    except capi.ScannerError as e:
+        assert rank == 0 and e.status == capi.E_TRUNCATED and g.last_per_rank.tolist() == [len(part(9, r)) for r in range(world)]
+        want = np.concatenate([part(9, r)[:18] for r in range(world)])
+        assert g.last_list.tobytes() == want.tobytes()
+    # sweep 8: the last rank could not prepare its part -- it still posts (marked), the root names it, nobody hangs
+    try:
+        tk = g.post(part(1, rank), cap_per_rank=cap, local_status=capi.E_NOMEM if rank == world - 1 else capi.OK)
+        assert rank != world - 1
+    except capi.ScannerError as e:
+        assert rank == world - 1 and e.status == capi.E_NOMEM
+        tk = g.last_ticket
+    try:
+        g.wait(tk)
+        assert rank != 0
+    except capi.ScannerError as e:
+        assert rank == 0 and e.status == capi.E_COMM and f"rank {world - 1}" in str(e)
+    dist.barrier()
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_gather_post_wait_over_gloo(tmp_path, built_lib, world):
+    mp.spawn(_stream_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok").read_text() == "ok"

@@ -145,3 +145,64 @@ def test_bench_c4_line(torch_cuda):
     assert c["match"] is True and c["expected_hits"] == c["gathered_hits"] == 7 * 1024
     assert d["roofline"]["kernel"].startswith("scn_fft_kernel<16, SCN_K_FLOAT_COMPLEX")
     assert d["with_hit_records"]["hits_per_step"] == 7 * 1024
+
+
+def test_gather_post_wait_one_rank(torch_cuda):
+    """The steady-state form (scn_gather_post / scn_gather_wait) with a one-rank communicator: a collected slot's device list
+    goes through pack -> (no peers) -> compaction into the communicator's pinned list on its own stream; four posts in flight,
+    tickets come back in order, the lists are the slots' own; a list longer than the message is cut and reported with the true
+    count; a slot that was never collected travels as a marked message the root names."""
+    import ctypes as C
+
+    from scanner_amd import Plan, synth
+
+    L = capi.lib()
+    dev = torch_cuda.device("cuda", 0)
+    n, nb, fs, thr = 4096, 64, 8000000, 9.5
+    with Plan(n, fs, thr, max_batch=nb, max_hits=1 << 16) as plan, sweep.HitGather(dev) as g:
+        lists = []
+        for s in range(4):
+            x = synth.cfloat_batch(n, nb, seed=50 + s)
+            plan.submit_device(s, torch_cuda.from_numpy(x.view(np.uint8).reshape(-1)).cuda(), nb, 3e6 + 6e6 * np.arange(nb))
+        for s in range(4):
+            lists.append(plan.collect(s, want_power=False, hit_cap=1 << 16)[1])
+            assert len(lists[-1]) > 100
+        cap = max(len(h) for h in lists) + 7
+        tickets = [g.post(plan, s, cap) for s in range(4)]                 # four in flight
+        assert tickets == [0, 1, 2, 3]
+        tk = C.c_uint32()
+        assert L.scn_gather_post(g._comm, plan.handle, 0, 0, cap, C.byref(tk)) == capi.E_STATE   # the ring is full
+        for s in (0, 1, 2, 3):
+            got, per_rank = g.wait(tickets[s])
+            assert per_rank.tolist() == [len(lists[s])] and got.tobytes() == lists[s].tobytes()
+        with pytest.raises(capi.ScannerError):
+            g.wait(0)                                                      # not in flight any more
+        # the view form, and a ring that goes round
+        for rep in range(6):
+            s = rep % 4
+            got, _ = g.wait(g.post(plan, s, cap), copy=False)
+            assert got.tobytes() == lists[s].tobytes()
+        # a list longer than the message: the first cap records, the true count, SCN_E_TRUNCATED on both calls
+        small = len(lists[1]) - 10
+        with pytest.raises(capi.ScannerError) as e:
+            g.post(plan, 1, small)
+        assert e.value.status == capi.E_TRUNCATED
+        with pytest.raises(capi.ScannerError) as e:
+            g.wait(g.last_ticket)
+        assert e.value.status == capi.E_TRUNCATED and g.last_per_rank.tolist() == [len(lists[1])]
+        assert g.last_list.tobytes() == lists[1][:small].tobytes()
+        # a part that cannot be prepared (the slot has a submit pending, never collected): posted all the same, marked
+        x = synth.cfloat_batch(n, nb, seed=99)
+        plan.submit_device(2, torch_cuda.from_numpy(x.view(np.uint8).reshape(-1)).cuda(), nb, 3e6 + 6e6 * np.arange(nb))
+        with pytest.raises(capi.ScannerError) as e:
+            g.post(plan, 2, cap)
+        assert e.value.status == capi.E_STATE
+        with pytest.raises(capi.ScannerError) as e:
+            g.wait(g.last_ticket)
+        assert e.value.status == capi.E_COMM and "rank 0" in str(e.value) and len(g.last_list) == 0
+        plan.collect(2, want_power=False)
+        got, _ = g.wait(g.post(plan, 2, cap))                              # and the communicator is still usable
+        assert len(got) > 100
+        # the three-step form and the steady-state form share the communicator
+        got2, _ = g.gather_device(plan, 2)
+        assert got2.tobytes() == got.tobytes()

@@ -296,7 +296,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
     lst, tot = C.c_void_p(), C.c_uint64()
     per_rank = np.zeros(world, np.uint32)
     per_rank_p = vp(per_rank)
-    state = {"launch": 0, "records": 0, "lists": 0, "wait_s": 0.0, "last": None, "keep": False}
+    state = {"launch": 0, "base": 0, "records": 0, "lists": 0, "wait_s": 0.0, "last": None, "keep": False}
     tickets = [None] * D
     pending = [False] * D
 
@@ -324,7 +324,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
         plan.submit_prepared_indexed(s, *a)
         pending[s] = True
         state["launch"] = j + 1
-        if j >= LAG:
+        if j - LAG >= state["base"]:           # (launches before `base` were drained)
             s2 = (j - LAG) % D
             plan.collect_counts(s2)
             pending[s2] = False
@@ -336,7 +336,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
 
     def drain(gather):
         j = state["launch"]
-        for jj in range(max(j - LAG, 0), j):   # the launches not yet collected, oldest first
+        for jj in range(max(j - LAG, state["base"]), j):   # the launches not yet collected, oldest first
             s2 = jj % D
             if pending[s2]:
                 plan.collect_counts(s2)
@@ -349,6 +349,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
         for jj in range(max(j - D, 0), j):
             if tickets[jj % D] is not None:
                 finish(jj % D)
+        state["base"] = j
 
     def run(k_steps, gather, keep_last=False):
         for k in range(k_steps):

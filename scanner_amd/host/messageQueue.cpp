@@ -47,7 +47,7 @@ SampleQueue::SampleQueue(SampleKind kind, uint32_t enob, uint32_t sampleCount, u
                          bool correctDCOffset, bool doWrite)
     : m_kind(kind), m_enob(enob), m_sampleCount(sampleCount), m_bufferCount(bufferCount),
       m_correctDCOffset(correctDCOffset), m_doWrite(doWrite), m_bufferBytes(bytesPerSample(kind) * sampleCount),
-      m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_stagingCapacity(0), m_fillSlot(0), m_unstagedQueued(0),
+      m_historyCapacity(bufferCount / 10), m_poolSize(uint32_t(bufferCount * 1.1)), m_attachedRings(0), m_fillRing(0), m_stagedQueued(0), m_stagingCapacity(0), m_unstagedQueued(0),
       m_nextSequenceId(0), m_iterationCount(0), m_done(false), m_acknowledged(true), m_writeStart(0), m_writeEnd(0),
       m_writeShutdown(false), m_writeErrors(0), m_producerWaitNs(0), m_stagedAppends(0), m_copiedAppends(0), m_queuedAtAttach(0) {
   assert(kind > Illegal && kind <= FloatComplex);  // messageQueue.h:163
@@ -65,7 +65,7 @@ SampleQueue::SampleQueue(SampleKind kind, uint32_t enob, uint32_t sampleCount, u
 }
 
 SampleQueue::~SampleQueue() {
-  assert(m_buffer.empty());  // messageQueue.h:173
+  assert(m_buffer.empty() && m_stagedQueued == 0);  // messageQueue.h:173
   if (m_doWrite && m_writeThread) {
     printf("Stopping write thread...\n");  // messageQueue.h:176
     {
@@ -110,36 +110,47 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
     m_notFull.wait(l);
     m_producerWaitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   };
-  // a place in the consumer's pinned slot: wait for room in the queue AND in a slot (the one being filled, or -- once that
-  // one is full or has been taken -- the next in the ring, as soon as the consumer has released it).  False once there are no
-  // staging slots (never attached, or detached while waiting).
+  // a place in a consumer's pinned slot: wait for room in the queue AND in a slot.  The batch being filled goes on while its slot
+  // is open and has room; a new batch starts in the NEXT attached ring (round-robin over the consumers) that has a usable slot --
+  // the ring's fill slot if it is free, or the one after it once that one is full and still queued.  False once no ring is attached
+  // (never attached, or detached while waiting).
   auto acquirePlace = [&]() -> bool {
-    while (!m_staging.empty()) {
-      if (m_unstagedQueued || m_buffer.size() >= m_bufferCount) {  // (messages queued before the attach go first, through slots the consumer is given)
+    while (m_attachedRings) {
+      if (m_unstagedQueued || m_buffer.size() + m_stagedQueued >= m_bufferCount) {  // (messages queued before the attach go first, through slots the consumers are given)
         timedWait(lock);
         continue;
       }
-      StagingSlot &fs = m_staging[m_fillSlot];
+      const int R = (int)m_rings.size();
+      int ring = -1;
+      {
+        StagingRing &cur = m_rings[m_fillRing];
+        if (cur.attached) {
+          StagingSlot &fs = cur.slots[cur.fillSlot];
+          if (fs.state == StagingSlot::Open && fs.fill < m_stagingCapacity) ring = m_fillRing;  // the batch in progress
+        }
+      }
+      for (int k = 1; ring < 0 && k <= R; k++) {  // a new batch: the next consumer's turn
+        const int r = (m_fillRing + k) % R;
+        if (m_rings[r].attached && UsableSlot(m_rings[r])) ring = r;
+      }
+      if (ring < 0) {
+        timedWait(lock);  // (every ring's next slot is still in flight; ReleaseStaging and DetachStaging signal this too)
+        continue;
+      }
+      m_fillRing = ring;
+      StagingRing &g = m_rings[ring];
+      StagingSlot &fs = g.slots[g.fillSlot];
       if (fs.state == StagingSlot::Free) {
         fs.state = StagingSlot::Open;
         fs.fill = 0;
       }
-      if (fs.state == StagingSlot::Open && fs.fill < m_stagingCapacity) {
-        // the message object is the slot's own (one per buffer place): a staged buffer costs no pool round trip
-        message = m_stagingMessages[(size_t)m_fillSlot * m_stagingCapacity + fs.fill].get();
-        message->m_slot = m_fillSlot;
-        message->m_staged = fs.base + (size_t)fs.fill * m_bufferBytes;
-        fs.fill++;
-        return true;
-      }
-      if (fs.state == StagingSlot::Open) {  // full and still queued: on to the next slot of the ring, once the consumer has released it
-        const int next = (m_fillSlot + 1) % (int)m_staging.size();
-        if (m_staging[next].state == StagingSlot::Free) {
-          m_fillSlot = next;
-          continue;
-        }
-      }
-      timedWait(lock);  // (the fill slot, or the one after a full one, is still in flight; ReleaseStaging and DetachStaging signal this too)
+      // the message object is the slot's own (one per buffer place): a staged buffer costs no pool round trip
+      message = g.messages[(size_t)g.fillSlot * m_stagingCapacity + fs.fill].get();
+      message->m_ring = ring;
+      message->m_slot = g.fillSlot;
+      message->m_staged = fs.base + (size_t)fs.fill * m_bufferBytes;
+      fs.fill++;
+      return true;
     }
     return false;
   };
@@ -154,6 +165,7 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
     message = Allocate();
     message->m_staged = nullptr;
     message->m_slot = -1;
+    message->m_ring = -1;
     memcpy(message->GetRawData(), a, aBytes);
     if (bBytes) memcpy(static_cast<unsigned char *>(message->GetRawData()) + aBytes, b, bBytes);
     lock.lock();
@@ -161,7 +173,7 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
     // slot like any later one (behind whatever was queued at the attach), so that from the attach on every NEW message is a
     // staged one and the consumer never has to fit a copied message between slots the producer is writing to.
     MessageType *const pooled = message;
-    while (m_staging.empty() && m_buffer.size() >= m_bufferCount) timedWait(lock);  // (room in the queue first: an attach may come while waiting)
+    while (!m_attachedRings && m_buffer.size() >= m_bufferCount) timedWait(lock);  // (room in the queue first: an attach may come while waiting)
     if (acquirePlace()) {
       memcpy(message->m_staged, pooled->GetRawData(), m_bufferBytes);
       m_stagedAppends++;
@@ -178,10 +190,18 @@ void SampleQueue::SynchronizedAppend(const void *a, size_t aBytes, const void *b
   h.m_kind = MessageHeader::ProcessData;
   h.m_referenceCount = 0;
   h.m_sequenceId = m_nextSequenceId++;
-  while (m_buffer.size() >= m_bufferCount) timedWait(lock);
-  bool wake = m_buffer.empty();
-  m_buffer.push_front(message);
-  if (wake) m_notEmpty.notify_one();
+  if (message->m_ring >= 0) {  // (room in the queue was waited for when the place was taken)
+    StagingRing &g = m_rings[message->m_ring];
+    const bool wake = g.queued.empty();
+    g.queued.push_back(message);
+    m_stagedQueued++;
+    if (wake) m_notEmpty.notify_all();  // (every consumer waits on the one condition, each for its own ring)
+  } else {
+    while (m_buffer.size() + m_stagedQueued >= m_bufferCount) timedWait(lock);
+    const bool wake = m_buffer.empty();
+    m_buffer.push_front(message);
+    if (wake) m_notEmpty.notify_all();
+  }
   ClearAck();
 }
 
@@ -206,64 +226,97 @@ SampleQueue::MessageType *SampleQueue::GetNextSamples() {
   std::unique_lock<std::mutex> lock(m_mutex);
   while (!m_done && m_buffer.empty()) m_notEmpty.wait(lock);
   if (m_buffer.empty()) return nullptr;  // done and drained
-  bool wake = m_buffer.size() >= m_bufferCount;
+  bool wake = m_buffer.size() + m_stagedQueued >= m_bufferCount;
   MessageType *m = m_buffer.back();
   m_buffer.pop_back();
-  if (wake) m_notFull.notify_one();
+  if (m_unstagedQueued) m_unstagedQueued--;  // (a consumer without a ring taking what was queued before the first attach)
+  if (wake || m_attachedRings) m_notFull.notify_all();
   return m;
 }
 
 SampleQueue::MessageType *SampleQueue::TryGetNextSamples() {
   std::unique_lock<std::mutex> lock(m_mutex);
   if (m_buffer.empty()) return nullptr;
-  bool wake = m_buffer.size() >= m_bufferCount;
+  bool wake = m_buffer.size() + m_stagedQueued >= m_bufferCount;
   MessageType *m = m_buffer.back();
   m_buffer.pop_back();
-  if (wake) m_notFull.notify_one();
+  if (m_unstagedQueued) m_unstagedQueued--;
+  if (wake || m_attachedRings) m_notFull.notify_all();
   return m;
 }
 
-bool SampleQueue::AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot) {
-  if (m_doWrite || nSlots < 2 || buffersPerSlot == 0) return false;  // (the capture writer's history needs storage of its own)
+bool SampleQueue::UsableSlot(StagingRing &g) {
+  const int n = (int)g.slots.size();
+  StagingSlot &fs = g.slots[g.fillSlot];
+  if (fs.state == StagingSlot::Free || (fs.state == StagingSlot::Open && fs.fill < m_stagingCapacity)) return true;
+  if (fs.state == StagingSlot::Open) {  // full and still queued: on to the next slot of the ring, once the consumer has released it
+    const int next = (g.fillSlot + 1) % n;
+    if (g.slots[next].state == StagingSlot::Free) {
+      g.fillSlot = next;
+      return true;
+    }
+  }
+  return false;  // (the ring's next slot in submit order is still in flight)
+}
+
+int SampleQueue::AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot) {
+  if (m_doWrite || nSlots < 2 || buffersPerSlot == 0) return -1;  // (the capture writer's history needs storage of its own)
   std::unique_lock<std::mutex> lock(m_mutex);
-  if (!m_staging.empty()) return false;  // one consumer
+  if (m_attachedRings && buffersPerSlot != m_stagingCapacity) return -1;  // one batch size for all the consumers of a queue
   // The documented start order is Start, StartStreaming, THEN StartProcessing (signalSource.h:5, scan.cpp:234-238), and a plan
   // takes hundreds of milliseconds to create: the producer has almost always queued buffers by now, often a full queue of
   // them.  (Until round 5 a non-empty queue refused the attach -- silently, so the zero-copy path all but never engaged.)
-  // Those messages stay what they are, pooled and unstaged; the consumer takes them first, a slot's worth at a time, into
-  // slots the queue reserves for it in ring order (TakeStagedBatch), and the producer opens no slot before the last of them
-  // is gone: at no time do the consumer's copy and the producer's append write to the same slot, and nothing is reordered.
-  for (uint32_t i = 0; i < nSlots; i++) m_staging.push_back(StagingSlot{static_cast<unsigned char *>(slotBases[i]), 0, StagingSlot::Free});
-  m_stagingMessages.clear();
-  for (size_t i = 0; i < (size_t)nSlots * buffersPerSlot; i++) m_stagingMessages.emplace_back(new MessageType(0));  // headers only
-  m_stagingCapacity = buffersPerSlot;
-  m_fillSlot = 0;
-  m_unstagedQueued = m_buffer.size();
-  m_queuedAtAttach = m_buffer.size();
-  return true;
+  // Those messages stay what they are, pooled and unstaged; the consumers take them first, a slot's worth at a time, into
+  // slots the queue reserves for them in ring order (TakeStagedBatch), and the producer opens no slot before the last of them
+  // is gone: at no time do a consumer's copy and the producer's append write to the same slot, and nothing is reordered.
+  m_rings.emplace_back();
+  StagingRing &g = m_rings.back();
+  for (uint32_t i = 0; i < nSlots; i++) g.slots.push_back(StagingSlot{static_cast<unsigned char *>(slotBases[i]), 0, StagingSlot::Free});
+  for (size_t i = 0; i < (size_t)nSlots * buffersPerSlot; i++) g.messages.emplace_back(new MessageType(0));  // headers only
+  g.fillSlot = 0;
+  g.attached = true;
+  if (!m_attachedRings) {  // the first consumer: from here on every NEW message is a staged one
+    m_stagingCapacity = buffersPerSlot;
+    m_unstagedQueued = m_buffer.size();
+    m_queuedAtAttach = m_buffer.size();
+    m_fillRing = (int)m_rings.size() - 1;
+  }
+  m_attachedRings++;
+  m_notFull.notify_all();  // (a producer waiting for a slot has one more ring to look at)
+  return (int)m_rings.size() - 1;
 }
 
-void SampleQueue::DetachStaging() {
+void SampleQueue::DetachStaging(int ring) {
   std::unique_lock<std::mutex> lock(m_mutex);
-  m_staging.clear();
-  m_unstagedQueued = 0;
-  m_notFull.notify_all();  // a producer waiting for a slot goes on with the messages' own storage
+  if (ring < 0 || (size_t)ring >= m_rings.size() || !m_rings[ring].attached) return;
+  StagingRing &g = m_rings[ring];
+  g.attached = false;
+  m_stagedQueued -= g.queued.size();  // (a consumer that gives up: what it had queued lives in its plan's slots and goes with them)
+  for (MessageType *m : g.queued) m->m_header.m_kind = MessageHeader::Free;
+  g.queued.clear();
+  m_attachedRings--;
+  if (!m_attachedRings) m_unstagedQueued = 0;
+  m_notFull.notify_all();  // a producer waiting for a slot goes on with another ring, or with the messages' own storage
+  m_notEmpty.notify_all();
 }
 
-uint32_t SampleQueue::TakeStagedBatch(std::vector<MessageType *> &out, int *slot, bool block, uint32_t lingerMicros) {
+uint32_t SampleQueue::TakeStagedBatch(int ring, std::vector<MessageType *> &out, int *slot, bool block, uint32_t lingerMicros) {
   std::unique_lock<std::mutex> lock(m_mutex);
-  while (block && !m_done && m_buffer.empty()) m_notEmpty.wait(lock);
+  if (ring < 0 || (size_t)ring >= m_rings.size() || !m_rings[ring].attached) return 0;
+  StagingRing &g = m_rings[ring];
+  auto nothing = [&] { return g.queued.empty() && !(m_unstagedQueued && !m_buffer.empty()); };
+  while (block && !m_done && nothing()) m_notEmpty.wait(lock);
   // An idle consumer woken by the first buffer of a burst lingers a moment before it seals the slot: taking that one
-  // buffer at once would make the producer pay a futex wake for EVERY append (it signals whenever it finds the queue
+  // buffer at once would make the producer pay a futex wake for EVERY append (it signals whenever it finds the ring
   // empty: ~1 us per 32 KiB buffer, as much as the copy) and the GPU a launch per buffer.  A front-end that delivers a
   // buffer every 80 us is not held up: the wait ends after lingerMicros at the latest.
-  if (block && lingerMicros && !m_done && !m_buffer.empty() && m_buffer.size() < m_stagingCapacity)
+  if (block && lingerMicros && !m_done && !m_unstagedQueued && !g.queued.empty() && g.queued.size() < m_stagingCapacity)
     m_notEmpty.wait_until(lock, std::chrono::system_clock::now() + std::chrono::microseconds(lingerMicros));  // (system clock -> pthread_cond_timedwait: gcc 11's TSan does not know the steady-clock wait)
-  if (m_buffer.empty()) return 0;
-  if (m_unstagedQueued && !m_staging.empty()) {
-    // messages queued before the attach: up to a slot's worth of them, oldest first, and the next slot of the ring to copy
+  if (nothing()) return 0;
+  if (m_unstagedQueued) {
+    // messages queued before the attach: up to a slot's worth of them, oldest first, and this ring's next slot to copy
     // them into -- reserved (in flight) from here on; the producer opens no slot while any of them is left
-    const int rs = m_fillSlot;
+    const int rs = g.fillSlot;
     uint32_t n = 0;
     while (m_unstagedQueued && n < m_stagingCapacity) {
       out.push_back(m_buffer.back());
@@ -271,32 +324,32 @@ uint32_t SampleQueue::TakeStagedBatch(std::vector<MessageType *> &out, int *slot
       m_unstagedQueued--;
       n++;
     }
-    m_staging[rs].state = StagingSlot::InFlight;
-    m_staging[rs].fill = 0;
-    m_fillSlot = (rs + 1) % (int)m_staging.size();
+    g.slots[rs].state = StagingSlot::InFlight;
+    g.slots[rs].fill = 0;
+    g.fillSlot = (rs + 1) % (int)g.slots.size();
     *slot = rs;
     m_notFull.notify_all();
     return n;
   }
-  const int s = m_buffer.back()->m_slot;
+  const int s = g.queued.front()->m_slot;
   uint32_t n = 0;
-  while (!m_buffer.empty() && m_buffer.back()->m_slot == s && (s >= 0 || n == 0)) {  // (an unstaged message -- only after DetachStaging -- travels alone)
-    out.push_back(m_buffer.back());
-    m_buffer.pop_back();
+  while (!g.queued.empty() && g.queued.front()->m_slot == s) {
+    out.push_back(g.queued.front());
+    g.queued.pop_front();
     n++;
   }
-  if (s >= 0 && (size_t)s < m_staging.size()) {
-    m_staging[s].state = StagingSlot::InFlight;  // sealed: the producer moves on -- strictly in ring order, which is the
-    if (s == m_fillSlot) m_fillSlot = (s + 1) % (int)m_staging.size();  // order the consumer submits its slots in
-  }
+  m_stagedQueued -= n;
+  g.slots[s].state = StagingSlot::InFlight;  // sealed: the producer moves on -- within this ring strictly in ring order, which is
+  if (s == g.fillSlot) g.fillSlot = (s + 1) % (int)g.slots.size();  // the order the consumer submits its slots in
   *slot = s;
   m_notFull.notify_all();
   return n;
 }
 
-void SampleQueue::ReleaseStaging(int slot) {
+void SampleQueue::ReleaseStaging(int ring, int slot) {
   std::unique_lock<std::mutex> lock(m_mutex);
-  if (slot >= 0 && (size_t)slot < m_staging.size()) m_staging[slot].state = StagingSlot::Free;
+  if (ring >= 0 && (size_t)ring < m_rings.size() && slot >= 0 && (size_t)slot < m_rings[ring].slots.size())
+    m_rings[ring].slots[slot].state = StagingSlot::Free;
   m_notFull.notify_all();
 }
 

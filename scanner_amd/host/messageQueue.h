@@ -38,7 +38,7 @@ class SampleQueue {
   class MessageType {  // Buffer<MessageHeader, T> of memoryPool.h:7-30
    public:
     MessageHeader m_header;
-    explicit MessageType(size_t bytes) : m_header(), m_raw(bytes), m_staged(nullptr), m_slot(-1) {}
+    explicit MessageType(size_t bytes) : m_header(), m_raw(bytes), m_staged(nullptr), m_slot(-1), m_ring(-1) {}
     MessageHeader &GetHeader() { return m_header; }
     void *GetRawData() { return m_staged ? static_cast<void *>(m_staged) : static_cast<void *>(m_raw.data()); }
     size_t GetRawBytes() const { return m_raw.size(); }
@@ -50,7 +50,7 @@ class SampleQueue {
     friend class SampleQueue;
     std::vector<unsigned char> m_raw;
     unsigned char *m_staged;  // staged queues: the samples' place in the consumer's pinned submit slot (AttachStaging)
-    int m_slot;
+    int m_slot, m_ring;
   };
 
   SampleKind m_kind;
@@ -83,20 +83,25 @@ class SampleQueue {
   typedef std::function<void(const void *raw, uint32_t nBuffers, float *out)> Converter;
   void SetConverter(Converter c);  // install before the consumers start; the writer calls a copy taken under the lock
 
-  // Zero-copy staging (sampleBuffer.cpp's host staging "replaced by pinned double-buffered hipMemcpyAsync", BASELINE.json): a
-  // single consumer lends the queue the pinned submit slots of its scn_plan (scn_host_buffer).  AppendSamples then writes a
-  // buffer straight into the next free place of the slot being filled -- the producer's one copy lands in pinned memory --
-  // and the consumer submits a slot as it is, without copying: TakeStagedBatch hands out every queued message of the oldest
-  // slot (buffers 0 .. n-1 of it, in order) and seals that slot, so that the producer moves on to the next one; the slot
-  // returns to the producer with ReleaseStaging, after the consumer has collected its results.  Sequence ids, the discarded
-  // warm-up sweep (messageQueue.h:67-72), the queue's bound and its blocking behaviour are unchanged; a staged message is
-  // recycled as soon as it is processed (the history ring of the capture writer needs storage of its own: a queue built
-  // with doWrite refuses staging and keeps the copying path).  Messages that were queued before the attach are handed out
-  // first, unstaged, a slot's worth at a time together with the slot reserved for them: the consumer copies those itself.
-  bool AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot);
-  void DetachStaging();  // the consumer is leaving: appends fall back to the messages' own storage
-  uint32_t TakeStagedBatch(std::vector<MessageType *> &out, int *slot, bool block, uint32_t lingerMicros = 0);
-  void ReleaseStaging(int slot);
+  // Zero-copy staging (sampleBuffer.cpp's host staging "replaced by pinned double-buffered hipMemcpyAsync", BASELINE.json): every
+  // consumer thread lends the queue the pinned submit slots of its scn_plan (scn_host_buffer) as a RING of its own.  AppendSamples
+  // then writes a buffer straight into the next free place of the slot being filled -- the producer's one copy lands in pinned
+  // memory -- and the consumer submits a slot as it is, without copying: TakeStagedBatch hands out every queued message of that
+  // consumer's oldest slot (buffers 0 .. n-1 of it, in order) and seals the slot, so that the producer moves on; the slot returns
+  // to the producer with ReleaseStaging, after the consumer has collected its results.  With several consumers (scan.cpp:217 runs
+  // two) the producer deals its batches round-robin: when the slot it is filling is full or has been sealed it goes on to the
+  // NEXT consumer's ring that has a usable slot.  Sequence ids are the queue's own, in append order, so every consumer sees
+  // increasing ids and the consumers' outputs interleave as the reference's threads' do (messageQueue.h:239-257 hands a message
+  // to whichever thread asks first).  The discarded warm-up sweep (messageQueue.h:67-72), the queue's bound and its blocking
+  // behaviour are unchanged; a staged message is recycled as soon as it is processed (the history ring of the capture writer
+  // needs storage of its own: a queue built with doWrite refuses staging and keeps the copying path).  Messages that were queued
+  // before the first attach are handed out first, unstaged, a slot's worth at a time together with a slot of the asking
+  // consumer's ring reserved for them: the consumer copies those itself.
+  // AttachStaging returns the consumer's ring id (>= 0), or -1 when staging is refused.
+  int AttachStaging(void *const *slotBases, uint32_t nSlots, uint32_t buffersPerSlot);
+  void DetachStaging(int ring);  // the consumer is leaving; with the last ring gone appends fall back to the messages' own storage
+  uint32_t TakeStagedBatch(int ring, std::vector<MessageType *> &out, int *slot, bool block, uint32_t lingerMicros = 0);
+  void ReleaseStaging(int ring, int slot);
 
   void SetIsDone();
   bool GetIsDone();
@@ -137,17 +142,26 @@ class SampleQueue {
   uint32_t m_poolSize;
   std::mutex m_mutex, m_poolMutex, m_historyMutex;
   std::condition_variable m_notEmpty, m_notFull, m_poolNotEmpty;
-  // staging slots (guarded by m_mutex): Free -> Open (being filled / holding queued messages) -> InFlight (taken) -> Free
+  // staging (guarded by m_mutex).  A slot: Free -> Open (being filled / holding queued messages) -> InFlight (taken) -> Free
   struct StagingSlot {
     unsigned char *base;
     uint32_t fill;
     enum { Free, Open, InFlight } state;
   };
-  std::vector<StagingSlot> m_staging;
-  std::vector<std::unique_ptr<MessageType>> m_stagingMessages;  // [slot][place]: the message objects of the staged buffers
-  uint32_t m_stagingCapacity;
-  int m_fillSlot;
-  size_t m_unstagedQueued;  // messages queued before AttachStaging that the consumer has not taken yet (the oldest in the queue)
+  struct StagingRing {  // one per consumer
+    std::vector<StagingSlot> slots;
+    std::vector<std::unique_ptr<MessageType>> messages;  // [slot][place]: the message objects of the staged buffers
+    std::deque<MessageType *> queued;                     // appended and not yet taken; front = oldest
+    int fillSlot;                                         // the slot the producer fills next in this ring (ring order = the consumer's submit order)
+    bool attached;
+  };
+  std::deque<StagingRing> m_rings;   // index = the id AttachStaging returned; entries stay (detached) until the queue goes (a deque: rings are never moved)
+  uint32_t m_attachedRings;
+  int m_fillRing;                    // the ring whose slot the producer is filling
+  size_t m_stagedQueued;             // messages queued in the rings (they count towards the queue's bound)
+  uint32_t m_stagingCapacity;        // buffers per slot (the same for every ring: ProcessSamples' max batch)
+  size_t m_unstagedQueued;  // messages queued before the first AttachStaging that no consumer has taken yet (the oldest in the queue)
+  bool UsableSlot(StagingRing &g);   // positions g.fillSlot on a slot the producer may write to, if the ring has one
   uint64_t m_nextSequenceId;
   uint32_t m_iterationCount;
   std::atomic<bool> m_done;

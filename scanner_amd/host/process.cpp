@@ -117,8 +117,9 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   d.max_hits = d.max_batch * 64u;
   d.flags = SCN_OUT_HITS;  // the reference reports hits only; the spectra never leave the GPU
   // a worker that cannot go on still has to empty the queue, or the producer blocks on a full one forever
+  int ring = -1;  // this consumer's staging ring in the queue (SampleQueue::AttachStaging); -1: the copying path
   auto abandon = [&](scn_plan *plan) {
-    q.DetachStaging();  // (the producer may be waiting for a slot of this plan)
+    q.DetachStaging(ring);  // (the producer may be waiting for a slot of this plan)
     if (plan) scn_plan_destroy(plan);
     while (SampleQueue::MessageType *m = q.GetNextSamples()) q.MessageProcessed(m);
   };
@@ -143,11 +144,13 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
          " (sample kind or count mismatch)");
     return abandon(plan);
   }
-  // One consumer: the queue writes the producer's buffers straight into the plan's pinned slots and a slot is submitted as
-  // it is -- no copy in this thread (the reference's ThreadWorker copies every buffer, process.cpp:293; so did rounds 1-3 here).
-  // Several consumers (or a capturing queue, whose history ring needs storage of its own) keep the copying path.
-  // (What the producer queued while this thread was creating its plan comes first, unstaged, with a slot reserved for it.)
-  const bool staged = m_threadCount == 1 && kPipe >= 2 && q.AttachStaging((void *const *)stage, (uint32_t)kPipe, d.max_batch);
+  // The queue writes the producer's buffers straight into the plan's pinned slots and a slot is submitted as it is -- no copy in
+  // this thread (the reference's ThreadWorker copies every buffer, process.cpp:293; so did rounds 1-3 here).  Every consumer thread
+  // lends the queue a ring of its own (scan.cpp:217 runs two: the producer deals its batches to them in turn); only a capturing
+  // queue, whose history ring needs storage of its own, keeps the copying path.
+  // (What the producer queued while the threads were creating their plans comes first, unstaged, with a slot reserved for it.)
+  if (kPipe >= 2) ring = q.AttachStaging((void *const *)stage, (uint32_t)kPipe, d.max_batch);
+  const bool staged = ring >= 0;
   if (staged) m_stagedWorkers++;
 
   std::vector<double> fc(d.max_batch);
@@ -224,7 +227,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
     m_bufferCount += inflight[s].size();
     inflight[s].clear();
     pending[s] = false;
-    if (staged) q.ReleaseStaging(s);  // the slot goes back to the producer
+    if (staged) q.ReleaseStaging(ring, s);  // the slot goes back to the producer
     m_tReport += nowNs() - tDrain1;
   };
 
@@ -244,7 +247,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
       // every queued message of the queue's oldest slot -- which is `head`: the queue fills its slots in ring order and a
       // slot is sealed by being taken.  Block only while nothing is in flight.
       int slot = -1;
-      n = q.TakeStagedBatch(inflight[head], &slot, inFlight == 0, 40);
+      n = q.TakeStagedBatch(ring, inflight[head], &slot, inFlight == 0, 40);
       if (!n && !inFlight) more = false;
       // (The queue fills -- and, for messages queued before the attach, reserves -- its slots in ring order, the order this
       //  thread submits them in; anything else means the slot about to be submitted is not the memory the samples are in.)
@@ -304,7 +307,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   // Shutdown writing gracefully (process.cpp:311-313).
   UpdateEndSequenceId(lastSequenceId);
   ProcessWrite(false, lastFrequency, lastSequenceId);
-  q.DetachStaging();
+  q.DetachStaging(ring);
   scn_plan_destroy(plan);
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-to-end rate of the kept class surface: SyntheticSource (replaying 64 generated buffers) -> SampleQueue (writing into the
-# consumer's pinned slots when there is one consumer) -> batched ProcessSamples worker(s) -> scn_submit -> scn_collect +
+# consumers' pinned slots: a ring per consumer thread) -> batched ProcessSamples worker(s) -> scn_submit -> scn_collect +
 # scn_hits_view -> stdout (/dev/null).  Each configuration runs twice, N and 3N sweeps: the difference is the steady-state
 # rate (plan creation, pinning the slots and the discarded warm-up sweep are in both runs).
 cd "$GRAFT_REPO_ROOT/scanner_amd/host"
@@ -19,6 +19,8 @@ st = [l for l in b.splitlines() if l.startswith("staging")][0]
 print("   " + st)   # WHICH path ran: a silent fall-back to the copying worker is a different measurement
 if "--threads 1" in what:
     assert st.startswith("staging: 1 of 1"), "one consumer must run the zero-copy path"
+if "--threads 2" in what:
+    assert st.startswith("staging: 2 of 2"), "both consumers must run the zero-copy path (a ring each, round 6)"
 PY
 }
 pair 8192 150 --kind short_complex --enob 12 --stop 24576e6 --batch 2048 --depth 8192 --threads 1
@@ -26,3 +28,4 @@ pair 8192 150 --kind short_complex --enob 12 --stop 24576e6 --batch 2048 --depth
 pair 4096 75 --kind float --stop 49152e6 --batch 4096 --depth 16384 --threads 1
 pair 4096 75 --kind float --stop 49152e6 --batch 4096 --depth 16384 --threads 2
 pair 8192 150 --kind byte --enob 8 --stop 24576e6 --batch 2048 --depth 8192 --threads 1
+pair 8192 150 --kind byte --enob 8 --stop 24576e6 --batch 2048 --depth 8192 --threads 2

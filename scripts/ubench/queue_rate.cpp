@@ -10,7 +10,7 @@ int main(int argc, char **argv) {
   SampleQueue q(SampleQueue::ShortComplex, 12, n, depth, false, false);
   std::vector<std::vector<unsigned char>> slots(nslots, std::vector<unsigned char>((size_t)batch * n * 4));
   void *bases[nslots]; for (uint32_t i = 0; i < nslots; i++) bases[i] = slots[i].data();
-  if (staged) q.AttachStaging(bases, nslots, batch);
+  const int ring = staged ? q.AttachStaging(bases, nslots, batch) : -1;
   std::vector<int16_t> src(64 * n * 2, 3);
   auto t0 = std::chrono::steady_clock::now();
   std::thread prod([&] {
@@ -20,11 +20,11 @@ int main(int argc, char **argv) {
   size_t got = 0; std::vector<SampleQueue::MessageType *> out; std::vector<unsigned char> stage((size_t)batch * n * 4);
   while (true) {
     out.clear(); int slot = -1; uint32_t c = 0;
-    if (staged) c = q.TakeStagedBatch(out, &slot, true);
+    if (staged) c = q.TakeStagedBatch(ring, out, &slot, true);
     else { SampleQueue::MessageType *m = q.GetNextSamples(); while (m) { memcpy(stage.data() + (size_t)c * n * 4, m->GetRawData(), n * 4); out.push_back(m); c++; if (c >= batch) break; m = q.TryGetNextSamples(); } }
     if (!c) break;
     for (auto *m : out) q.MessageProcessed(m);
-    if (staged) q.ReleaseStaging(slot);
+    if (staged) q.ReleaseStaging(ring, slot);
     got += c;
   }
   prod.join();

@@ -5,6 +5,7 @@
 // them to the order the batches were submitted in (what a single reference thread prints, process.cpp:46-61).
 // The definitions here take precedence over libscanner_hip's (executable before shared libraries); what is not faked
 // (scn_frequency_table, ...) still comes from the library.  Built with -fsanitize=thread / address by tests/test_host_cpp.py.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -31,13 +32,17 @@ struct FakeSlot {
 struct FakePlan {
   scn_plan_desc d;
   size_t bufBytes = 0;
+  uint64_t tickets = 0, collected = 0;  // per plan: a consumer collects ITS submits oldest first
+  uint64_t lastSeq = 0;
+  bool anySeq = false;
   FakeSlot slot[SCN_NUM_SLOTS];
 };
 
-std::mutex g_m;                        // one consumer thread per test run; the lock is for the sanitizers' peace
+std::mutex g_m;                        // (the consumer threads of a run share the counters below)
 std::vector<std::string> g_violations;
 std::vector<uint64_t> g_expected;      // freq_hz of every record, in the order the reference would print them
-uint64_t g_tickets = 0, g_collected = 0;
+std::vector<uint64_t> g_seenSeq;       // every sequence id submitted, any plan
+int g_plans = 0;
 uint32_t g_hitsPerBuffer = 2;
 int g_failSubmitAt = -1;               // fail the k-th submit (1-based); -1: never
 int g_collectSleepUs = 0;              // "GPU time" a collect waits for
@@ -66,6 +71,10 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   if (g_planCreateSleepUs) std::this_thread::sleep_for(std::chrono::microseconds(g_planCreateSleepUs));
   FakePlan *p = new FakePlan;
   p->d = *desc;
+  {
+    std::lock_guard<std::mutex> g(g_m);
+    g_plans++;
+  }
   const size_t per = desc->sample_kind == SCN_KIND_FLOAT_COMPLEX ? 8 : desc->sample_kind == SCN_KIND_BYTE_COMPLEX ? 2 : 4;
   p->bufBytes = per * desc->n;
   *out = reinterpret_cast<scn_plan *>(p);
@@ -103,9 +112,18 @@ int scn_submit(scn_plan *plan, int slot, uint32_t n, const double *fc, const uin
   if (s.pending) g_violations.push_back("submit on slot " + std::to_string(slot) + " which is still pending");
   if (n == 0 || n > p->d.max_batch) g_violations.push_back("submit of " + std::to_string(n) + " buffers");
   s.pending = true;
-  s.ticket = ++g_tickets;
+  s.ticket = ++p->tickets;
   s.fc.assign(fc, fc + n);
   s.seq.assign(seq, seq + n);
+  for (uint32_t b = 0; b < n; b++) {  // a consumer sees the queue's sequence ids in increasing order
+    if (p->anySeq && seq[b] <= p->lastSeq) g_violations.push_back("sequence id " + std::to_string(seq[b]) + " submitted after " + std::to_string(p->lastSeq));
+    p->lastSeq = seq[b];
+    p->anySeq = true;
+    g_seenSeq.push_back(seq[b]);
+  }
+  {  // a staged slot is submitted as it is: the samples must BE in this plan's slot (SyntheticSource stamps nothing, so check the address
+    // range only through what the worker passes: nothing to do here) -- the protocol checks are the point
+  }
   g_inFlight++;
   if (g_inFlight > g_maxInFlight) g_maxInFlight = g_inFlight;
   for (uint32_t b = 0; b < n; b++)
@@ -121,9 +139,9 @@ int scn_collect(scn_plan *plan, int slot, float *, scn_hit *hits, uint32_t cap, 
     g_violations.push_back("collect on slot " + std::to_string(slot) + " which is not pending");
     return SCN_E_STATE;
   }
-  if (s.ticket != g_collected + 1)
-    g_violations.push_back("collect out of order: ticket " + std::to_string(s.ticket) + " after " + std::to_string(g_collected));
-  g_collected = s.ticket;
+  if (s.ticket != p->collected + 1)
+    g_violations.push_back("collect out of order: ticket " + std::to_string(s.ticket) + " after " + std::to_string(p->collected));
+  p->collected = s.ticket;
   s.pending = false;
   g_inFlight--;
   s.list.clear();
@@ -176,10 +194,11 @@ int g_failures = 0;
   } while (0)
 
 // one run: a synthetic producer, one consumer thread on the fake plan; returns the freq values ProcessSamples printed
-std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t sweeps, bool &ok) {
+std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t sweeps, bool &ok, uint32_t threads = 1) {
   g_violations.clear();
   g_expected.clear();
-  g_tickets = g_collected = 0;
+  g_seenSeq.clear();
+  g_plans = 0;
   g_submits = g_maxInFlight = g_inFlight = 0;
   char path[] = "/tmp/scn_ring_XXXXXX";
   const int fd = mkstemp(path);
@@ -188,7 +207,7 @@ std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t s
   stdout = fdopen(fd, "w");
   {
     SyntheticSource source(8000000, n, 88e6, 130e6, SampleQueue::ShortComplex, 5, 0.02);
-    ProcessSamples process(n, 8000000, 12, 10.0f, gr::fft::window::WIN_BLACKMAN_HARRIS, ProcessSamples::FrequencyDomain, 1);
+    ProcessSamples process(n, 8000000, 12, 10.0f, gr::fft::window::WIN_BLACKMAN_HARRIS, ProcessSamples::FrequencyDomain, threads);
     process.SetMaxBatch(batch);
     SampleQueue q(SampleQueue::ShortComplex, 12, n, depth, false, false);
     ok = source.Start() && source.StartStreaming(sweeps + 1, q);
@@ -275,6 +294,52 @@ int main() {
   for (const std::string &v : g_violations) fprintf(stderr, "violation: %s\n", v.c_str());
   CHECK(g_violations.empty());
   CHECK(!got.empty() && got.size() == g_expected.size() && got == g_expected);  // what was submitted was reported, in order
+
+  // 5. TWO consumer threads (the reference's shipped setting, scan.cpp:217), each with a ring of its own in the queue: both run the
+  //    zero-copy path, the producer deals its batches to them in turn, every buffer is submitted exactly once, each consumer sees
+  //    increasing sequence ids and collects its own submits oldest first; the printed lines are the single-thread lines as a multiset
+  //    (their order across threads is free, as in the reference).  Fast producer / slow GPU, then with plans that take their time
+  //    (a full queue at the attach: both consumers take the queued messages first), then a slow producer.
+  g_failSubmitAt = -1;
+  g_hitsPerBuffer = 2;
+  for (int variant = 0; variant < 3; variant++) {
+    g_collectSleepUs = variant == 2 ? 0 : 1500;
+    g_planCreateSleepUs = variant == 1 ? 50000 : 0;
+    got = variant == 2 ? run(16384, 4, 16, 3, ok, 2) : run(256, 4, 64, 40, ok, 2);
+    g_planCreateSleepUs = 0;
+    CHECK(ok);
+    for (const std::string &v : g_violations) fprintf(stderr, "violation (two consumers, variant %d): %s\n", variant, v.c_str());
+    CHECK(g_violations.empty());
+    std::vector<uint64_t> a = got, b = g_expected;
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    CHECK(a.size() > 20 && a == b);
+    std::vector<uint64_t> ids = g_seenSeq;
+    std::sort(ids.begin(), ids.end());
+    bool once = ids.size() == g_buffers;
+    for (size_t k = 0; k < ids.size(); k++) once = once && ids[k] == k;  // every buffer exactly once: ids 0 .. buffers-1
+    CHECK(once);
+    fprintf(stderr, "5.%d: plans %d, staged workers %u, queued at attach %lu, copied %lu, staged %lu, buffers %lu, submits %d\n", variant, g_plans, g_stagedWorkers,
+            (unsigned long)g_queuedAtAttach, (unsigned long)g_copiedAppends, (unsigned long)g_stagedAppends, (unsigned long)g_buffers, g_submits);
+    CHECK(g_plans == 2 && g_stagedWorkers == 2);
+    CHECK(g_stagedAppends + g_copiedAppends == g_buffers && g_stagedAppends > 0);
+    if (variant == 1) CHECK(g_queuedAtAttach == 64 && g_copiedAppends == 64);
+  }
+  // 5b. one of the two consumers loses its GPU path half way: it reports what it had in flight, detaches its ring and leaves; the
+  //     other goes on alone and the producer is never left waiting for the dead ring's slots
+  g_collectSleepUs = 1500;
+  g_failSubmitAt = 20;
+  got = run(256, 4, 64, 40, ok, 2);
+  g_failSubmitAt = -1;
+  CHECK(!ok);
+  for (const std::string &v : g_violations) fprintf(stderr, "violation (5b): %s\n", v.c_str());
+  CHECK(g_violations.empty());
+  {
+    std::vector<uint64_t> a = got, b = g_expected;
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    CHECK(!a.empty() && a == b);  // what was submitted was reported
+  }
 
   if (g_failures) return 1;
   printf("worker ring tests ok\n");

@@ -275,6 +275,8 @@ def test_scan_synth_two_consumer_threads_and_time_domain(host_build, tmp_path):
     f2 = sorted(l for l in two.stdout.splitlines() if l.startswith("freq "))
     assert len(f1) > 10 and f1 == f2
     assert "Starting process thread 1" in two.stdout and "Stopped process thread 1" in two.stdout
+    # both consumers run the zero-copy path: a staging ring each in the queue (the reference's shipped setting, scan.cpp:217)
+    assert "staging: 2 of 2 consumer thread(s) zero-copy" in two.stderr and "staging: 1 of 1 consumer thread(s) zero-copy" in one.stderr
     # time-domain mode, the reference CLI's default (scan.cpp:87): one line per buffer whose peak is above threshold
     td = subprocess.run([demo, "--kind", "float", "--n", "8192", "--start", "400e6", "--stop", "460e6",
                          "--niterations", "2", "--mode", "time", "--threshold", "-7", "--sigma", "0.02",

@@ -310,6 +310,19 @@ def set_direct_dft(direct):
     lib().scn_oracle_set_direct_dft(1 if direct else 0)
 
 
+class direct_dft:
+    """`with oracle.direct_dft():` -- plans created inside evaluate the DFT sum as written, O(n^2); the process-wide switch is back
+    at the factored form on the way out, also when the body raises (a test that failed half way used to leave it on)."""
+
+    def __enter__(self):
+        set_direct_dft(True)
+        return self
+
+    def __exit__(self, *exc):
+        set_direct_dft(False)
+        return False
+
+
 def set_fft_mode(accurate):
     """True (default): double-internal FFT rounded to float (FFTW's accuracy class, the parity reference);
     False: textbook float radix-2 (the timed cpu_baseline, a second opinion)."""

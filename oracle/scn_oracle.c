@@ -162,7 +162,7 @@ void scn_oracle_set_fft_mode(int accurate) { g_fft_accurate = accurate ? 1 : 0; 
 int scn_oracle_get_fft_mode(void) { return g_fft_accurate; }
 /* Lengths that are not powers of two: by default the DFT sum factored over the prime factors of n (O(n * sum of the factors):
  * a 12000-point buffer costs what 25 radix passes cost, not 1.4e8 multiply-adds); with direct = 1 plans created from then on
- * evaluate the sum as written, O(n^2) -- the two are held against each other in tests/test_oracle.py. */
+ * evaluate the sum as written, O(n^2) -- the two are held against each other in tests/test_mixed_cpu.py (through oracle.direct_dft(), which resets the switch whatever happens). */
 static int g_direct_dft = 0;
 void scn_oracle_set_direct_dft(int direct) { g_direct_dft = direct ? 1 : 0; }
 

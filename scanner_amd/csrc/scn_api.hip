@@ -78,7 +78,9 @@ struct Slot {
   uint32_t *h_buf_hits = nullptr;
   unsigned long long *h_total = nullptr;  // pinned (the tail of h_buf_hits): the batch's total, stored by scn_hit_total_kernel
   unsigned long long *d_total_acc = nullptr;  // its two device words
-  bool total_ready = false;         // the pending / last submit's total is (going to be) in *h_total: scn_collect need not walk the counts
+  bool total_ready = false;         // the pending / last submit's total is (going to be) in *h_total and its trigger flags, one bit per buffer, in the
+                                    // front of h_buf_hits: the counts themselves stayed on the GPU and scn_collect walks nothing
+  uint32_t *d_trig_bits = nullptr;  // [(max_batch + 31) / 32] the trigger bitmap on its way to the host
   hipEvent_t kernel_done = nullptr, staged = nullptr;
   hipStream_t stream = nullptr;     // where this slot's kernels run: the plan's compute stream, or its own (SCN_PLAN_OVERLAP_SLOTS)
   // buffer-queue heads of the persistent workgroups (ScnFftArgs::work_counter; 8 heads, never reset) and their values
@@ -152,7 +154,7 @@ struct scn_plan {
   uint32_t fft_m = 0, log2m = 0;     // ... and its transform length: n for a power of two, >= 2n - 1 for Bluestein
   double *d_twiddle64 = nullptr;     // [fft_m][2]: W_m^k in double (the staged path applies its tables in double)
   double *d_table = nullptr;         // [table_count] the plan's frequency table (scn_plan_set_table), read by the compaction kernel
-  uint32_t table_count = 0;
+  uint32_t table_count = 0, table_cap = 0;  // entries in use / allocated
   double *d_chirp = nullptr;         // Bluestein: [n][2], w[i] = exp(-i pi i^2 / n)
   double *d_bfilter = nullptr;       // Bluestein: [fft_m][2], FFT_m of the chirp filter / m
   hipStream_t stream = nullptr;      // compute
@@ -277,6 +279,7 @@ int ensure_slot_outputs(scn_plan *p, Slot &s, uint32_t gen) {
       SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * ((size_t)mb + 4u), hipHostMallocDefault));
       s.h_total = reinterpret_cast<unsigned long long *>(s.h_buf_hits + (((size_t)mb + 1u) & ~(size_t)1u));
     }
+    if (!s.d_trig_bits && mb >= kTotalKernelFrom) SCN_HIP(hipMalloc(&s.d_trig_bits, sizeof(uint32_t) * (((size_t)mb + 31u) / 32u)));
     if (!s.d_total_acc) {
       SCN_HIP(hipMalloc(&s.d_total_acc, 2u * sizeof(unsigned long long)));
       SCN_HIP(hipMemset(s.d_total_acc, 0, 2u * sizeof(unsigned long long)));
@@ -534,12 +537,15 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     if (after && !in_packet) SCN_HIP(hipEventRecord(after, s.stream));
     if (cnt != s.stream) SCN_HIP(hipStreamWaitEvent(cnt, after, 0));
     if (fork_list) SCN_HIP(hipStreamWaitEvent(lst, after, 0));
-    // launches of very many small buffers: the total by itself, so that a collect without trigger flags reads one word instead
-    // of walking nb counts; in front of the counts' DMA, behind the kernel
-    s.total_ready = !direct && nb >= kTotalKernelFrom;
-    if (s.total_ready) SCN_HIP(scn_launch_hit_total(s.d_buf_hits[s.gen], nb, s.d_total_acc, s.h_total, cnt));
-    if (!direct)
+    // launches of very many small buffers: the total and the trigger flags (a bit per buffer) by themselves -- the counts stay on
+    // the GPU, where the list kernels read them: nb / 8 bytes cross PCIe instead of 4 nb, and a collect walks nothing
+    s.total_ready = !direct && nb >= kTotalKernelFrom && s.d_trig_bits;
+    if (s.total_ready) {
+      SCN_HIP(scn_launch_hit_total(s.d_buf_hits[s.gen], nb, p->d.trigger_count, s.d_total_acc, s.h_total, s.d_trig_bits, cnt));
+      SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_trig_bits, sizeof(uint32_t) * (((size_t)nb + 31u) / 32u), hipMemcpyDeviceToHost, cnt));
+    } else if (!direct) {
       SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits[s.gen], sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, cnt));
+    }
     if (!(after_is_done && after)) SCN_HIP(hipEventRecord(s.done, cnt));
     if (eager) {
       int st2 = build_list(p, s, true);
@@ -560,6 +566,7 @@ void free_slot(Slot &s) {
   if (s.d_power) (void)hipFree(s.d_power);
   if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
   if (s.d_total_acc) (void)hipFree(s.d_total_acc);
+  if (s.d_trig_bits) (void)hipFree(s.d_trig_bits);
   for (int g = 0; g < 2; g++) {
     if (s.d_buf_hits[g]) (void)hipFree(s.d_buf_hits[g]);
     if (s.d_hits[g]) (void)hipFree(s.d_hits[g]);
@@ -901,16 +908,26 @@ int scn_plan_set_table(scn_plan *p, const double *fc, uint32_t count) {
   for (int i = 0; i < SCN_NUM_SLOTS; i++)
     if (p->slot[i].pending) return fail(SCN_E_STATE, "slot %d has an uncollected submit: its records still read the table", i);
   SCN_HIP(hipSetDevice(p->d.device_id));
-  // (a list of an already collected submit may still be completed on demand -- scn_collect_more -- from the OLD table: wait for
-  // whatever is queued, then forget those lists)
-  SCN_HIP(hipDeviceSynchronize());
+  // (a list of an already collected submit may still be being completed -- the prefetch of scn_collect, scn_collect_more --
+  // from the OLD table: wait for what THIS plan has queued on the streams that read the table, then forget those lists.  Not a
+  // device-wide synchronisation: other plans' pipelines and the caller's own streams on this GPU go on undisturbed.)
+  SCN_HIP(hipStreamSynchronize(p->list_stream));
+  SCN_HIP(hipStreamSynchronize(p->d2h_stream));
+  SCN_HIP(hipStreamSynchronize(p->h2d_stream));
+  for (int i = 0; i < SCN_NUM_SLOTS; i++)  // (a slot with a stream of its own builds its list there)
+    if (p->slot[i].own_stream && p->slot[i].stream) SCN_HIP(hipStreamSynchronize(p->slot[i].stream));
   for (int i = 0; i < SCN_NUM_SLOTS; i++) p->slot[i].list_valid = false;
-  if (p->d_table) SCN_HIP(hipFree(p->d_table));
-  p->d_table = nullptr;
   p->table_count = 0;
   if (!count) return SCN_OK;
-  SCN_HIP(hipMalloc(&p->d_table, sizeof(double) * (size_t)count));
-  SCN_HIP(hipMemcpy(p->d_table, fc, sizeof(double) * (size_t)count, hipMemcpyHostToDevice));
+  if (count > p->table_cap) {  // (a caller that re-tables between sweeps keeps its allocation)
+    if (p->d_table) SCN_HIP(hipFree(p->d_table));
+    p->d_table = nullptr;
+    p->table_cap = 0;
+    SCN_HIP(hipMalloc(&p->d_table, sizeof(double) * (size_t)count));
+    p->table_cap = count;
+  }
+  SCN_HIP(hipMemcpyAsync(p->d_table, fc, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, p->list_stream));
+  SCN_HIP(hipStreamSynchronize(p->list_stream));  // (fc is the caller's: done with it before returning; the list kernels run on this stream, after the copy)
   p->table_count = count;
   return SCN_OK;
 }
@@ -1009,8 +1026,10 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   if (power_db && !s.cur_power) return fail(SCN_E_INVALID, "plan was created without SCN_OUT_SPECTRUM");
 
   uint64_t total = 0;
-  if (have_hits && nb && !trigger && s.total_ready) {
+  if (have_hits && nb && s.total_ready) {
     total = *s.h_total;
+    if (trigger)  // process.cpp:62, one bit per buffer from the GPU
+      for (uint32_t b = 0; b < nb; b++) trigger[b] = (uint8_t)((s.h_buf_hits[b >> 5] >> (b & 31u)) & 1u);
   } else if (have_hits && nb) {
     for (uint32_t b = 0; b < nb; b++) {
       const uint32_t c = s.h_buf_hits[b];

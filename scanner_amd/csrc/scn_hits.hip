@@ -165,22 +165,42 @@ __global__ __launch_bounds__(256) void scn_hit_compact_kernel(ScnCompactArgs a) 
   }
 }
 
-// The batch's total alone, for a collect that asks for nothing per buffer: the host's walk over the counts (2 MB read per
-// launch of 524288 16-point buffers: three times the kernel) becomes one 8-byte word in pinned memory.  Partial sums meet in a
-// device word; the last workgroup to arrive stores the total for the host and leaves both words zero for the next launch.
+// The batch's total and its trigger flags, for launches of very many small buffers: what the host needs of the per-buffer counts
+// is their sum (n_hits) and one bit each (process_fft's return value, hits > trigger_count, process.cpp:62) -- the records are
+// ranked on the GPU from the counts where they lie.  So instead of 4 bytes per buffer crossing PCIe after every launch (2 MB per
+// launch of 524288 16-point buffers, 40 us of the bus for a 27 us kernel) and the host walking them, one 8-byte word and a bitmap
+// of nb / 8 bytes (64 KB) do.  Partial sums meet in a device word; the last workgroup to arrive stores the total for the host and
+// leaves both words zero for the next launch.  A lane handles four counts (one 16-byte load); the eight lanes of a bitmap word
+// meet in three cross-lane steps.
 // (scn_api.hip launches it from 2^19 buffers per launch: below, its place on the chip costs the next launch more than the walk.)
 constexpr uint32_t kTotalThreads = 256, kTotalBlocks = 128;
 
-__global__ __launch_bounds__(kTotalThreads) void scn_hit_total_kernel(const uint32_t *counts, uint32_t nb, unsigned long long *acc,
-                                                                        unsigned long long *host_total) {
+__global__ __launch_bounds__(kTotalThreads) void scn_hit_total_kernel(const uint32_t *counts, uint32_t nb, uint32_t trigger_count, unsigned long long *acc,
+                                                                        unsigned long long *host_total, uint32_t *bits) {
   unsigned long long sum = 0;
-  const uint32_t quads = nb / 4u;  // (hipMalloc'd: 16-byte loads are aligned)
+  const uint32_t quads = nb / 4u, rest = nb - quads * 4u;  // (hipMalloc'd: 16-byte loads are aligned)
+  const uint32_t quads_all = quads + (rest ? 1u : 0u), words = (nb + 31u) / 32u;
   const uint4 *const c4 = reinterpret_cast<const uint4 *>(counts);
-  for (uint32_t i = blockIdx.x * kTotalThreads + threadIdx.x; i < quads; i += kTotalBlocks * kTotalThreads) {
-    const uint4 v = c4[i];
+  const uint32_t lane8 = threadIdx.x & 7u;
+  // (the loop's bound is the same for the eight lanes of a word -- for a whole wave, in fact: they all take part in the shuffles)
+  for (uint32_t base = blockIdx.x * kTotalThreads + (threadIdx.x & ~63u); base < quads_all; base += kTotalBlocks * kTotalThreads) {
+    const uint32_t i = base + (threadIdx.x & 63u);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (i < quads) {
+      v = c4[i];
+    } else if (i == quads && rest) {  // the last, partial quad
+      v.x = counts[4u * i];
+      if (rest > 1u) v.y = counts[4u * i + 1u];
+      if (rest > 2u) v.z = counts[4u * i + 2u];
+    }
     sum += (unsigned long long)v.x + v.y + v.z + v.w;
+    uint32_t b = (v.x > trigger_count ? 1u : 0u) | (v.y > trigger_count ? 2u : 0u) | (v.z > trigger_count ? 4u : 0u) | (v.w > trigger_count ? 8u : 0u);
+    b <<= 4u * lane8;
+    b |= (uint32_t)__shfl_xor((int)b, 1, 64);
+    b |= (uint32_t)__shfl_xor((int)b, 2, 64);
+    b |= (uint32_t)__shfl_xor((int)b, 4, 64);
+    if (lane8 == 0u && i / 8u < words) bits[i / 8u] = b;
   }
-  if (blockIdx.x == 0 && threadIdx.x < nb - quads * 4u) sum += counts[quads * 4u + threadIdx.x];
 #pragma unroll
   for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off, 64);
   __shared__ unsigned long long part[kTotalThreads / 64u];
@@ -202,9 +222,9 @@ __global__ __launch_bounds__(kTotalThreads) void scn_hit_total_kernel(const uint
 
 }  // namespace
 
-hipError_t scn_launch_hit_total(const uint32_t *counts, uint32_t n_buffers, unsigned long long *acc, unsigned long long *host_total,
-                                hipStream_t stream) {
-  hipLaunchKernelGGL(scn_hit_total_kernel, dim3(kTotalBlocks), dim3(kTotalThreads), 0, stream, counts, n_buffers, acc, host_total);
+hipError_t scn_launch_hit_total(const uint32_t *counts, uint32_t n_buffers, uint32_t trigger_count, unsigned long long *acc, unsigned long long *host_total,
+                                uint32_t *trigger_bits, hipStream_t stream) {
+  hipLaunchKernelGGL(scn_hit_total_kernel, dim3(kTotalBlocks), dim3(kTotalThreads), 0, stream, counts, n_buffers, trigger_count, acc, host_total, trigger_bits);
   return hipGetLastError();
 }
 

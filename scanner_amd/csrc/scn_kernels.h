@@ -110,8 +110,8 @@ struct ScnCompactArgs {
 hipError_t scn_launch_hit_scan(const ScnCompactArgs &args, hipStream_t stream);
 hipError_t scn_launch_hit_compact(const ScnCompactArgs &args, hipStream_t stream);
 // sum of counts[0, n_buffers) -> *host_total (pinned host memory); acc: two zeroed device words the kernel leaves zeroed
-hipError_t scn_launch_hit_total(const uint32_t *counts, uint32_t n_buffers, unsigned long long *acc, unsigned long long *host_total,
-                                hipStream_t stream);
+hipError_t scn_launch_hit_total(const uint32_t *counts, uint32_t n_buffers, uint32_t trigger_count, unsigned long long *acc, unsigned long long *host_total,
+                                uint32_t *trigger_bits, hipStream_t stream);
 
 // The same path for the power-of-two sizes without a fused kernel (scn_generic.hip): through HBM, stage by stage
 struct ScnGenericArgs {

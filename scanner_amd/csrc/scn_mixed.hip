@@ -22,6 +22,8 @@
 // Output modes as everywhere (HITS, SPEC template parameters); integer-mean DC removal (utility.cpp:70-79) is a runtime flag
 // here (one uniform branch per buffer): 12 kernels per size instead of 21.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
@@ -486,14 +488,18 @@ hipError_t launch_mixed_kind(const ScnFftArgs &a, bool dc, bool hits, bool spec,
   }
   // one resident wave of persistent workgroups: what fits a CU by registers, LDS and waves (asked of the runtime: the register
   // count of these kernels is the compiler's choice)
-  // (asked once per kernel: one static per instantiation and output mode; the GPUs of a node are alike)
-  static int per_cu_of_mode[3] = {0, 0, 0};
-  int &per_cu = per_cu_of_mode[!hits ? 0 : spec ? 1 : 2];
+  // (asked once per kernel: one static per instantiation and output mode, atomic because several host threads -- one plan each --
+  // may come through here at once; whoever asks first stores the answer, a second asker stores the same one: the figure is a property
+  // of the kernel's code object and the GPU model, and the GPUs of a node are alike)
+  static std::atomic<int> per_cu_of_mode[3];
+  std::atomic<int> &cached = per_cu_of_mode[!hits ? 0 : spec ? 1 : 2];
+  int per_cu = cached.load(std::memory_order_relaxed);
   if (per_cu < 1) {
     int q = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k, (int)G::W, G::LDS_BYTES);
     if (e != hipSuccess) return e;
     per_cu = q < 1 ? 1 : q;
+    cached.store(per_cu, std::memory_order_relaxed);
   }
   int grid = num_cus * per_cu;
   if ((uint32_t)grid > a.n_buffers) grid = (int)a.n_buffers;

@@ -43,13 +43,9 @@ def test_oracle_factored_dft_is_the_dft_sum(oracle_mod):
     from scanner_amd import synth
 
     O = oracle_mod
-    try:
-        for n in (17, 30, 1000, 1023, 3000, 4097, 6000):
-            x = synth.cfloat_batch(n, 3, seed=n, sigma=0.1)
-            O.set_direct_dft(True)
+    for n in (17, 30, 1000, 1023, 3000, 4097, 6000):
+        x = synth.cfloat_batch(n, 3, seed=n, sigma=0.1)
+        with O.direct_dft():
             a = O.Oracle(n, 8000000, 1e9).run(x)[0]
-            O.set_direct_dft(False)
-            b = O.Oracle(n, 8000000, 1e9).run(x)[0]
-            assert np.array_equal(a, b), n
-    finally:
-        O.set_direct_dft(False)
+        b = O.Oracle(n, 8000000, 1e9).run(x)[0]
+        assert np.array_equal(a, b), n

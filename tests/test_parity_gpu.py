@@ -959,6 +959,38 @@ def test_counts_by_kernel_stores_and_by_dma_agree(torch_cuda, oracle_mod):
             assert np.array_equal(np.bincount(h["seq_id"].astype(np.int64), minlength=count), c_ref[:count])
 
 
+def test_total_and_trigger_bitmap_from_the_gpu(torch_cuda, oracle_mod):
+    """Launches of 2^19 buffers and more (16-point plans at the bench's batch): the host gets the batch's total and ONE BIT per
+    buffer (process_fft's return value, hits > trigger_count, process.cpp:62) from a reduction on the GPU instead of 4 bytes per
+    buffer over PCIe; the counts stay on the device, where the list kernels rank the records from them.  Both sides of that line
+    on one plan, a count that is not a multiple of 32 or of 4, trigger flags against the oracle's, records intact."""
+    n, nb = 16, (1 << 19) + 37
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((nb, n, 2), dtype=np.float32) * np.float32(0.3)).view(np.complex64).reshape(nb, n)
+    fc = 1e9 + 6e6 * (np.arange(nb) % 1000)
+    thr = -3.0
+    o = oracle_mod.Oracle(n, FS, thr)
+    o.params.trigger_count = 2
+    p_ref, h_ref, t_ref = o.run(x, fc, threads=8)
+    ok = ~(tol.flip_unsafe(p_ref, thr) & tol.evaluated_mask(n)[None, :]).any(axis=1)      # buffers whose every bin is clear of the threshold
+    assert t_ref.any() and not t_ref.all() and ok.mean() > 0.9
+    d = _to_dev(torch_cuda, x)
+    with Plan(n, FS, thr, max_batch=nb, max_hits=len(h_ref) + 1024, flags=capi.OUT_HITS, trigger_count=2) as plan:
+        for count in (nb, (1 << 19) - 1, 1 << 19, nb - 2):        # bitmap, counts by DMA, bitmap, bitmap (a partial quad, a partial word)
+            plan.submit_device(0, d, count, fc[:count])
+            total = plan.collect_counts(0)
+            plan.submit_device(0, d, count, fc[:count])
+            _, h, t = plan.collect(0, want_hits=False)
+            assert np.array_equal(t[ok[:count]], t_ref[:count][ok[:count]]), count
+            assert total == plan.last_n_hits
+            assert abs(total - int((h_ref["seq_id"] < count).sum())) <= int((~ok[:count]).sum()) * n
+        plan.submit_device(1, d, nb, fc)                           # ... and the records behind a bitmap collect are the oracle's
+        _, h, t = plan.collect(1, hit_cap=len(h_ref) + 1024)
+        keep_ref, keep = ok[h_ref["seq_id"].astype(np.int64)], ok[h["seq_id"].astype(np.int64)]
+        _assert_hits_equal(h[keep], h_ref[keep_ref])
+        assert np.array_equal(t[ok], t_ref[ok])
+
+
 def test_special_inputs(torch_cuda, oracle_mod):
     """all-zero buffer (-inf everywhere, no hits), a unit impulse (flat spectrum), full-scale DC."""
     n = 4096

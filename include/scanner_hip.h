@@ -63,8 +63,19 @@ enum {
 /* process.h:27-31 ProcessSamples::Mode */
 enum { SCN_MODE_TIME_DOMAIN = 1, SCN_MODE_FREQUENCY_DOMAIN = 2 };
 
-/* gr::fft::window::win_type subset; scan.cpp:215 only ever passes this one. */
-enum { SCN_WIN_BLACKMAN_HARRIS = 5, SCN_WIN_RECTANGULAR = 3 };
+/* gr::fft::window::win_type (GNU Radio 3.7 / 3.8 numbering), what process.cpp:18 hands to window::build(type, N, 0.0): every
+ * type is built ([3P] published definitions; scan.cpp:215 only ever passes Blackman-Harris).  One exception to the numbering:
+ * 0 is WIN_HAMMING there and "the default" in the zero-initialised descriptors here, so Hamming travels as 8. */
+enum {
+  SCN_WIN_HANN = 1,
+  SCN_WIN_BLACKMAN = 2,
+  SCN_WIN_RECTANGULAR = 3,
+  SCN_WIN_KAISER = 4, /* with the beta the reference passes, 0.0: all ones */
+  SCN_WIN_BLACKMAN_HARRIS = 5,
+  SCN_WIN_BARTLETT = 6,
+  SCN_WIN_FLATTOP = 7,
+  SCN_WIN_HAMMING = 8
+};
 
 /* output selection (flags) */
 enum {

@@ -171,6 +171,10 @@ def lib():
         L.scn_oracle_byte_complex_to_float_complex.argtypes = [vp, vp, u32, u32, C.c_int]
         L.scn_oracle_window_blackman_harris.argtypes = [vp, u32]
         L.scn_oracle_window_apply.argtypes = [vp, vp, u32]
+        L.scn_oracle_window.restype = C.c_int
+        L.scn_oracle_window.argtypes = [u32, vp, u32]
+        L.scn_oracle_set_window_type.restype = C.c_int
+        L.scn_oracle_set_window_type.argtypes = [u32]
         L.scn_oracle_fft_create.restype = vp
         L.scn_oracle_fft_create.argtypes = [u32]
         L.scn_oracle_fft_destroy.argtypes = [vp]
@@ -308,6 +312,45 @@ def set_direct_dft(direct):
     """Lengths that are not powers of two: False (default) = the DFT sum factored over the prime factors of n, in double;
     True = the sum as written, O(n^2), in double.  Applies to Oracle objects created afterwards."""
     lib().scn_oracle_set_direct_dft(1 if direct else 0)
+
+
+WIN_HAMMING, WIN_HANN, WIN_BLACKMAN, WIN_RECTANGULAR, WIN_KAISER, WIN_BLACKMAN_HARRIS, WIN_BARTLETT, WIN_FLATTOP = range(8)
+
+
+def window(win_type, n):
+    """gr::fft::window::build(win_type, n, 0.0) as process.cpp:18 calls it ([3P], published definitions), float32 [n]."""
+    w = np.empty(n, np.float32)
+    assert lib().scn_oracle_window(int(win_type), _p(w), n) == 0, win_type
+    return w
+
+
+def ref64_window_of(win_type, n):
+    """float64 evaluation of the same published definitions (independent of the C code: numpy)."""
+    x = np.arange(n, dtype=np.float64) / (n - 1)
+    cs = {WIN_HAMMING: (0.54, 0.46), WIN_HANN: (0.5, 0.5), WIN_BLACKMAN: (0.42, 0.5, 0.08),
+          WIN_BLACKMAN_HARRIS: (0.35875, 0.48829, 0.14128, 0.01168),
+          WIN_FLATTOP: tuple(c / 4.63867 for c in (1.0, 1.93, 1.29, 0.388, 0.028))}
+    if win_type in (WIN_RECTANGULAR, WIN_KAISER):   # Kaiser with beta = 0.0: I0(0) / I0(0)
+        return np.ones(n)
+    if win_type == WIN_BARTLETT:
+        i = np.arange(n, dtype=np.float64)
+        return np.where(i < n // 2, 2 * i / (n - 1), 2 - 2 * i / (n - 1))
+    return sum(((-1) ** k) * c * np.cos(2 * np.pi * k * x) for k, c in enumerate(cs[win_type]))
+
+
+class window_type:
+    """`with oracle.window_type(t):` -- run_batch / welch build window t inside (process-wide switch, reset on the way out)."""
+
+    def __init__(self, t):
+        self.t = int(t)
+
+    def __enter__(self):
+        assert lib().scn_oracle_set_window_type(self.t) == 0, self.t
+        return self
+
+    def __exit__(self, *exc):
+        lib().scn_oracle_set_window_type(WIN_BLACKMAN_HARRIS)
+        return False
 
 
 class direct_dft:

@@ -124,6 +124,60 @@ void scn_oracle_window_blackman_harris(float *w, uint32_t n) {
   }
 }
 
+/* The other types of gr::fft::window::win_type (GNU Radio 3.7 / 3.8 numbering), which process.cpp:18 would hand to
+ * window::build just the same (with beta = 0.0): [3P] restated from the published definitions -- cosine-sum windows with the
+ * symmetric denominator n - 1, the triangular Bartlett window, Kaiser through the series of I0 (beta = 0: all ones).  Parity
+ * unpinned like the Blackman-Harris one: no source of GNU Radio is at hand; held to float64 evaluations of the same formulas
+ * (and to scipy.signal.windows where scipy uses the same coefficients) in tests/test_oracle.py. */
+static double izero(double x) { /* modified Bessel function of the first kind, order 0: the series GNU Radio's Izero sums */
+  double sum = 1.0, u = 1.0, halfx = x / 2.0;
+  for (int n = 1; n < 500; n++) {
+    double t = halfx / (double)n;
+    u *= t * t;
+    sum += u;
+    if (u < 1e-21 * sum) break;
+  }
+  return sum;
+}
+static int g_window_type = 5; /* WIN_BLACKMAN_HARRIS */
+int scn_oracle_set_window_type(uint32_t type) {
+  if (type > 7u) return -1;
+  g_window_type = (int)type;
+  return 0;
+}
+int scn_oracle_window(uint32_t type, float *w, uint32_t n) {
+  const double pi = 3.14159265358979323846, m = (double)n - 1.0;
+  const double flat = 4.63867; /* GNU Radio's flat-top scale */
+  double c[5] = {0, 0, 0, 0, 0};
+  switch (type) {
+    case 0: c[0] = 0.54; c[1] = 0.46; break;                  /* WIN_HAMMING */
+    case 1: c[0] = 0.5; c[1] = 0.5; break;                    /* WIN_HANN */
+    case 2: c[0] = 0.42; c[1] = 0.5; c[2] = 0.08; break;      /* WIN_BLACKMAN */
+    case 3:                                                   /* WIN_RECTANGULAR */
+      for (uint32_t i = 0; i < n; i++) w[i] = 1.0f;
+      return 0;
+    case 4: {                                                 /* WIN_KAISER with the beta process.cpp:18 passes: 0.0 */
+      const double beta = 0.0, ib = 1.0 / izero(beta);
+      for (uint32_t i = 0; i < n; i++) {
+        double t = n > 1 ? 2.0 * (double)i / m - 1.0 : 0.0;
+        w[i] = (float)(izero(beta * sqrt(1.0 - t * t)) * ib);
+      }
+      return 0;
+    }
+    case 5: scn_oracle_window_blackman_harris(w, n); return 0; /* WIN_BLACKMAN_HARRIS */
+    case 6:                                                   /* WIN_BARTLETT */
+      for (uint32_t i = 0; i < n; i++) w[i] = (float)(i < n / 2 ? 2.0 * (double)i / m : 2.0 - 2.0 * (double)i / m);
+      return 0;
+    case 7: c[0] = 1.0 / flat; c[1] = 1.93 / flat; c[2] = 1.29 / flat; c[3] = 0.388 / flat; c[4] = 0.028 / flat; break; /* WIN_FLATTOP */
+    default: return -1;
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    double x = (double)i / m;
+    w[i] = (float)(c[0] - c[1] * cos(2.0 * pi * x) + c[2] * cos(4.0 * pi * x) - c[3] * cos(6.0 * pi * x) + c[4] * cos(8.0 * pi * x));
+  }
+  return 0;
+}
+
 /* process.cpp:28-34: in-place complex * real multiply. */
 void scn_oracle_window_apply(float *s, const float *w, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) {
@@ -510,7 +564,7 @@ static void *worker_main(void *arg) {
   float *out = (float *)aligned_alloc(64, sizeof(float) * 2 * n);   /* m_fftOutputBuffer[tid] */
   float *mag = (float *)aligned_alloc(64, sizeof(float) * n);
   scn_oracle_hit *tmp = (scn_oracle_hit *)malloc(sizeof(scn_oracle_hit) * n);
-  scn_oracle_window_blackman_harris(win, n);
+  scn_oracle_window((uint32_t)g_window_type, win, n);
   for (uint32_t b = w->lo; b < w->hi; b++) {
     const uint8_t *src = w->raw + (size_t)b * w->buf_bytes;
     const float *fsrc = conv;
@@ -622,7 +676,7 @@ void scn_oracle_welch(const float *x, uint32_t n, uint32_t k, uint32_t n_psd, fl
   float *seg = (float *)aligned_alloc(64, sizeof(float) * 2 * n);
   float *out = (float *)aligned_alloc(64, sizeof(float) * 2 * n);
   float *acc = (float *)aligned_alloc(64, sizeof(float) * n);
-  scn_oracle_window_blackman_harris(win, n);
+  scn_oracle_window((uint32_t)g_window_type, win, n);
   const double log10v = log2(10.0);
   for (uint32_t p = 0; p < n_psd; p++) {
     memset(acc, 0, sizeof(float) * n);

@@ -77,6 +77,11 @@ void scn_oracle_byte_complex_to_float_complex(const int8_t *src /*[n][2]*/,
 
 /* process.cpp:14-21 (gr::fft::window::build, [3P]) */
 void scn_oracle_window_blackman_harris(float *w, uint32_t n);
+/* any gr::fft::window::win_type (GNU Radio 3.7 / 3.8 numbering: 0 Hamming, 1 Hann, 2 Blackman, 3 rectangular, 4 Kaiser with
+ * beta = 0.0 as process.cpp:18 passes it, 5 Blackman-Harris, 6 Bartlett, 7 flat-top), [3P] published definitions; -1 = unknown */
+int scn_oracle_window(uint32_t type, float *w, uint32_t n);
+/* the window scn_oracle_run_batch and scn_oracle_welch build from here on (default 5, the only one scan.cpp:215 passes) */
+int scn_oracle_set_window_type(uint32_t type);
 /* process.cpp:28-34 (volk_32fc_32f_multiply_32fc_a, [3P]) */
 void scn_oracle_window_apply(float *samples /*[n][2]*/, const float *w,
                              uint32_t n);

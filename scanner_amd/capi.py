@@ -16,6 +16,7 @@ OK, E_INVALID, E_HIP, E_NOMEM, E_STATE, E_TRUNCATED, E_NO_DEVICE, E_COMM = range
 KIND_BYTE_COMPLEX, KIND_SHORT, KIND_SHORT_COMPLEX, KIND_FLOAT_COMPLEX = 1, 2, 3, 4
 MODE_TIME_DOMAIN, MODE_FREQUENCY_DOMAIN = 1, 2
 WIN_RECTANGULAR, WIN_BLACKMAN_HARRIS = 3, 5
+WIN_HANN, WIN_BLACKMAN, WIN_KAISER, WIN_BARTLETT, WIN_FLATTOP, WIN_HAMMING = 1, 2, 4, 6, 7, 8   # (0, GNU Radio's WIN_HAMMING, is "the default" here)
 OUT_SPECTRUM, OUT_HITS = 1, 2
 PLAN_OVERLAP_SLOTS = 4  # each slot on its own compute stream (scanner_hip.h)
 DC_IGNORE_NONE = 0xFFFFFFFF

@@ -198,21 +198,35 @@ float convert_scale(uint32_t kind, uint32_t enob) {
   return 1.0f;
 }
 
-// gr::fft::window::build(type, N, 0.0) as process.cpp:18 calls it ([3P]); 4-term
-// Blackman-Harris 0.35875/0.48829/0.14128/0.01168, symmetric, double -> float.
-void build_window(uint32_t type, uint32_t n, std::vector<float> &w) {
+// gr::fft::window::build(type, N, 0.0) as process.cpp:18 calls it ([3P], GNU Radio 3.7 / 3.8): the published definitions --
+// cosine sums with the symmetric denominator N - 1 (Hamming 0.54 / 0.46, Hann 0.5 / 0.5, Blackman 0.42 / 0.5 / 0.08, 4-term
+// Blackman-Harris 0.35875 / 0.48829 / 0.14128 / 0.01168, flat-top 1 / 1.93 / 1.29 / 0.388 / 0.028 over 4.63867), the triangular
+// Bartlett window, Kaiser with the beta the call passes (0.0: I0(0) / I0(0) = 1 everywhere) -- evaluated in double, stored float.
+// scan.cpp:215 only ever asks for Blackman-Harris.
+bool build_window(uint32_t type, uint32_t n, std::vector<float> &w) {
   w.resize(n);
-  if (type == SCN_WIN_RECTANGULAR) {
-    std::fill(w.begin(), w.end(), 1.0f);
-    return;
+  const double pi = 3.14159265358979323846, m = (double)n - 1.0, flat = 4.63867;
+  double c[5] = {0, 0, 0, 0, 0};
+  switch (type) {
+    case SCN_WIN_HAMMING: c[0] = 0.54; c[1] = 0.46; break;
+    case SCN_WIN_HANN: c[0] = 0.5; c[1] = 0.5; break;
+    case SCN_WIN_BLACKMAN: c[0] = 0.42; c[1] = 0.5; c[2] = 0.08; break;
+    case SCN_WIN_RECTANGULAR:
+    case SCN_WIN_KAISER:
+      std::fill(w.begin(), w.end(), 1.0f);
+      return true;
+    case SCN_WIN_BLACKMAN_HARRIS: c[0] = 0.35875; c[1] = 0.48829; c[2] = 0.14128; c[3] = 0.01168; break;
+    case SCN_WIN_BARTLETT:
+      for (uint32_t i = 0; i < n; i++) w[i] = (float)(i < n / 2 ? 2.0 * (double)i / m : 2.0 - 2.0 * (double)i / m);
+      return true;
+    case SCN_WIN_FLATTOP: c[0] = 1.0 / flat; c[1] = 1.93 / flat; c[2] = 1.29 / flat; c[3] = 0.388 / flat; c[4] = 0.028 / flat; break;
+    default: return false;
   }
-  const double pi = 3.14159265358979323846;
-  const double m = (double)n - 1.0;
   for (uint32_t i = 0; i < n; i++) {
-    double x = (double)i / m;
-    w[i] = (float)(0.35875 - 0.48829 * std::cos(2.0 * pi * x) + 0.14128 * std::cos(4.0 * pi * x) -
-                   0.01168 * std::cos(6.0 * pi * x));
+    const double x = (double)i / m;
+    w[i] = (float)(c[0] - c[1] * std::cos(2.0 * pi * x) + c[2] * std::cos(4.0 * pi * x) - c[3] * std::cos(6.0 * pi * x) + c[4] * std::cos(8.0 * pi * x));
   }
+  return true;
 }
 
 // In-place forward DFT of a power-of-two length in double (plan creation only: the Bluestein filter's transform).
@@ -651,8 +665,7 @@ int scn_plan_create(const scn_plan_desc *desc, scn_plan **out) {
   if (bytes_per_sample(d.sample_kind) == 0) return fail(SCN_E_INVALID, "unknown sample_kind %u", d.sample_kind);
   if (d.sample_kind != SCN_KIND_FLOAT_COMPLEX && (d.enob < 1 || d.enob > 32))
     return fail(SCN_E_INVALID, "enob %u out of range", d.enob);
-  if (d.window_type != SCN_WIN_BLACKMAN_HARRIS && d.window_type != SCN_WIN_RECTANGULAR)
-    return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
+  if (d.window_type < SCN_WIN_HANN || d.window_type > SCN_WIN_HAMMING) return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
   if (d.mode != SCN_MODE_FREQUENCY_DOMAIN && d.mode != SCN_MODE_TIME_DOMAIN)
     return fail(SCN_E_INVALID, "unsupported mode %u", d.mode);
   if (d.mode == SCN_MODE_FREQUENCY_DOMAIN && !scn_fft_size_supported(d.n) && !scn_mixed_size_supported(d.n) && !scn_generic_size_supported(d.n) &&
@@ -1327,8 +1340,7 @@ int scn_welch_create(const scn_welch_desc *desc, scn_welch **out) {
     return fail(SCN_E_INVALID, "enob %u out of range for sample_kind %u", d.enob, d.sample_kind);
   if (d.n != 65536) return fail(SCN_E_INVALID, "unsupported Welch segment length %u (65536)", d.n);
   if (d.segments_per_psd < 1 || d.max_psd < 1) return fail(SCN_E_INVALID, "segments_per_psd and max_psd must be >= 1");
-  if (d.window_type != SCN_WIN_BLACKMAN_HARRIS && d.window_type != SCN_WIN_RECTANGULAR)
-    return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
+  if (d.window_type < SCN_WIN_HANN || d.window_type > SCN_WIN_HAMMING) return fail(SCN_E_INVALID, "unsupported window_type %u", d.window_type);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SCN_E_NO_DEVICE, "no HIP device visible");
   if (d.device_id < 0 || d.device_id >= ndev) return fail(SCN_E_INVALID, "device_id %d out of range", d.device_id);

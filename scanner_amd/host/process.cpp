@@ -109,7 +109,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   d.sample_kind = planKind(q.m_kind);
   d.enob = m_enob;
   d.correct_dc = q.GetCorrectDCOffset();
-  d.window_type = (uint32_t)m_windowType;
+  d.window_type = m_windowType == gr::fft::window::WIN_HAMMING ? (uint32_t)SCN_WIN_HAMMING : (uint32_t)m_windowType;  // (0 is "the default" in the descriptor)
   d.mode = timeDomain ? SCN_MODE_TIME_DOMAIN : SCN_MODE_FREQUENCY_DOMAIN;
   d.threshold = m_threshold;
   d.use_bandwidth = m_useBandWidth;
@@ -375,7 +375,7 @@ bool ProcessSamples::Run(int16_t sample_buffer[][2], uint32_t centerFrequency) {
   d.sample_kind = SCN_KIND_SHORT_COMPLEX;
   d.enob = m_enob;
   d.correct_dc = 0;  // m_correctDCOffset(false), process.cpp:84
-  d.window_type = (uint32_t)m_windowType;
+  d.window_type = m_windowType == gr::fft::window::WIN_HAMMING ? (uint32_t)SCN_WIN_HAMMING : (uint32_t)m_windowType;  // (0 is "the default" in the descriptor)
   d.threshold = m_threshold;
   d.use_bandwidth = m_useBandWidth;
   d.max_batch = 1;

@@ -10,7 +10,7 @@ namespace gr {
 namespace fft {
 namespace window {
 // gr::fft::window::win_type (GNU Radio 3.7/3.8 numbering).  scan.cpp:215 only ever passes
-// WIN_BLACKMAN_HARRIS; WIN_RECTANGULAR is accepted too, anything else is rejected at plan creation.
+// WIN_BLACKMAN_HARRIS; every type is accepted (process.cpp:18 hands any of them to window::build).
 enum win_type {
   WIN_HAMMING = 0,
   WIN_HANN = 1,

@@ -232,3 +232,33 @@ def test_fft_modes_bracket_the_float64_transform(oracle_mod):
         oracle_mod.set_fft_mode(True)
     assert errs[True] < 1e-6 and errs[False] < tol.REL_POWER, errs
     assert errs[True] < errs[False]
+
+
+def test_every_gnuradio_window_type(oracle_mod):
+    """process.cpp:18 hands ANY gr::fft::window::win_type to window::build(type, N, 0.0) ([3P], GNU Radio 3.7 / 3.8): the oracle
+    builds all eight from the published definitions -- held here to an independent float64 evaluation and, where scipy uses the
+    same coefficients, to scipy.signal.windows (symmetric form)."""
+    import scipy.signal.windows as W
+
+    O = oracle_mod
+    for n in (16, 1000, 4096):
+        for t in range(8):
+            w = O.window(t, n)
+            assert w.dtype == np.float32 and np.abs(w - O.ref64_window_of(t, n)).max() < 6e-8, (t, n)
+        for t, f in ((O.WIN_HAMMING, W.hamming), (O.WIN_HANN, W.hann), (O.WIN_BLACKMAN, W.blackman), (O.WIN_BARTLETT, W.bartlett),
+                     (O.WIN_BLACKMAN_HARRIS, W.blackmanharris)):
+            assert np.abs(O.window(t, n) - f(n, sym=True)).max() < 1.2e-7, (t, n)
+        assert np.all(O.window(O.WIN_RECTANGULAR, n) == 1) and np.all(O.window(O.WIN_KAISER, n) == 1)   # Kaiser with beta = 0.0
+        assert np.array_equal(O.window(O.WIN_BLACKMAN_HARRIS, n), O.Oracle(n).window())
+        ft = O.window(O.WIN_FLATTOP, n).astype(np.float64)
+        assert (n < 1000 or abs(ft.max() - (1 + 1.93 + 1.29 + 0.388 + 0.028) / 4.63867) < 1e-3) and ft.min() < 0   # its peak (between two samples of an even length) and its negative lobes
+    # run_batch follows the switch, and the switch resets
+    x = (np.random.default_rng(3).standard_normal((2, 1024, 2)) * 0.1).astype(np.float32).view(np.complex64).reshape(2, 1024)
+    with O.window_type(O.WIN_HANN):
+        p = O.Oracle(1024, threshold=1e9).run(x)[0]
+    _, _, db64 = O.ref64_spectrum(x, O.window(O.WIN_HANN, 1024))
+    from tests import tolerances as tol
+    tol.compare_spectra(p, db64)
+    assert np.array_equal(O.Oracle(1024, threshold=1e9).run(x)[0], O.Oracle(1024, threshold=1e9).run(x)[0])
+    _, _, db_bh = O.ref64_spectrum(x, O.Oracle(1024).window())
+    tol.compare_spectra(O.Oracle(1024, threshold=1e9).run(x)[0], db_bh)

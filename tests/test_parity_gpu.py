@@ -959,6 +959,29 @@ def test_counts_by_kernel_stores_and_by_dma_agree(torch_cuda, oracle_mod):
             assert np.array_equal(np.bincount(h["seq_id"].astype(np.int64), minlength=count), c_ref[:count])
 
 
+@pytest.mark.parametrize("wt", ["HAMMING", "HANN", "BLACKMAN", "RECTANGULAR", "KAISER", "BLACKMAN_HARRIS", "BARTLETT", "FLATTOP"])
+def test_every_window_type(torch_cuda, oracle_mod, wt):
+    """process.cpp:18 hands any gr::fft::window::win_type to window::build: the plan's table has the oracle's bits for each, and the
+    spectra + hits follow (a 1024-point fused kernel, the 3000-point mixed-radix one and the four-step pair take the table the same way)."""
+    o_t, p_t = getattr(oracle_mod, "WIN_" + wt), getattr(capi, "WIN_" + wt)
+    for n, nb in ((1024, 16), (3000, 6), (32768, 3)):
+        x = synth.cfloat_batch(n, nb, seed=n + o_t)
+        fc = 3e6 + 6e6 * np.arange(nb)
+        with oracle_mod.window_type(o_t):
+            p_ref, _, _ = oracle_mod.Oracle(n, FS, 1e9).run(x, threads=4)
+            thr = tol.pick_threshold(p_ref, n, start=6.0)
+            p_ref, h_ref, t_ref = oracle_mod.Oracle(n, FS, thr).run(x, fc, threads=4)
+        with Plan(n, FS, thr, max_batch=nb, max_hits=nb * n, window_type=p_t) as plan:
+            assert np.array_equal(plan.window(), oracle_mod.window(o_t, n))
+            plan.submit_device(0, _to_dev(torch_cuda, x), nb, fc)
+            p, h, t = plan.collect(0, hit_cap=nb * n)
+        tol.compare_spectra(p, p_ref)
+        _assert_hits_equal(h, h_ref)
+        assert np.array_equal(t, t_ref)
+    with pytest.raises(capi.ScannerError):
+        Plan(1024, FS, 10.0, window_type=9)
+
+
 def test_total_and_trigger_bitmap_from_the_gpu(torch_cuda, oracle_mod):
     """Launches of 2^19 buffers and more (16-point plans at the bench's batch): the host gets the batch's total and ONE BIT per
     buffer (process_fft's return value, hits > trigger_count, process.cpp:62) from a reduction on the GPU instead of 4 bytes per

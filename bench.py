@@ -296,7 +296,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
     lst, tot = C.c_void_p(), C.c_uint64()
     per_rank = np.zeros(world, np.uint32)
     per_rank_p = vp(per_rank)
-    state = {"launch": 0, "base": 0, "records": 0, "lists": 0, "wait_s": 0.0, "last": None, "keep": False}
+    state = {"launch": 0, "base": 0, "records": 0, "lists": 0, "wait_s": 0.0, "post_s": 0.0, "collect_s": 0.0, "last": None, "keep": False}
     tickets = [None] * D
     pending = [False] * D
 
@@ -326,10 +326,14 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
         state["launch"] = j + 1
         if j - LAG >= state["base"]:           # (launches before `base` were drained)
             s2 = (j - LAG) % D
+            tc0 = time.perf_counter()
             plan.collect_counts(s2)
+            tc1 = time.perf_counter()
+            state["collect_s"] += tc1 - tc0
             pending[s2] = False
             if gather:
                 st = post(comm, ph, s2, 0, cap, C.byref(tk))
+                state["post_s"] += time.perf_counter() - tc1
                 if st:
                     capi.check(st, "scn_gather_post")
                 tickets[s2] = tk.value
@@ -367,11 +371,12 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
         if sync:
             sync()
         state["records"] = state["lists"] = 0
-        state["wait_s"] = 0.0
+        state["wait_s"] = state["post_s"] = state["collect_s"] = 0.0
         t0 = time.perf_counter()
         run(steps, gather, keep_last=gather)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        state["host_" + ("gather" if gather else "plain")] = {k: round(state[k] / steps * 1e6, 2) for k in ("wait_s", "post_s", "collect_s")}
         if sync:
             sync()
         if world > 1:
@@ -409,6 +414,8 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
                    "value_without_gather": round(n_centres * n * steps / el_plain / 1e6, 1),
                    "lists_gathered": lists, "records_per_sweep": round(records / max(steps, 1), 1), "cap_per_rank": cap,
                    "root_blocked_in_wait_us_per_sweep": round(wait_s / steps * 1e6, 2),
+                   "host_us_per_sweep": {"without_gather": state.get("host_plain"), "with_gather": state.get("host_gather"),
+                                         "note": "this rank's host time per sweep inside scn_collect (waiting for the launch two behind), scn_gather_post, scn_gather_wait"},
                    "check": {"expected_hits": int(len(want)), "gathered_hits": int(len(last)), "match": bool(ok), "max_power_db_diff": worst,
                              "of": "the LAST timed sweep's gathered list against the planted emitters' closed form"},
                    "transport": ("scn_gather_post / scn_gather_wait: one fixed-size message per rank per launch (header + cap records), ONE group of "

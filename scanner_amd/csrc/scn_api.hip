@@ -139,6 +139,8 @@ struct scn_plan {
   // any batch without a detection the next submit was not eager and the first batch with hits built its list on demand, on
   // the consumer's critical path.)
   uint32_t view_age = 0xffffffffu;  // collects with hits since the last scn_hits_view (saturating; "never" at first)
+  uint32_t device_list_age = 0xffffffffu;  // ... since the last scn_gather_hits_device / scn_gather_post took a slot's list where it lies
+  bool device_list_wanted = false;         // the ordered list is built behind every launch, without the prefetch to pinned memory
   uint32_t predict = 0;         // records the next list is expected to hold (last total + a margin, scn_collect): the prefetch size
   uint32_t last_total = 0;      // the total before that: the margin grows with the change between consecutive batches
   // How the per-buffer counts reach the host.  false: a 4*n_buffers-byte copy on the d2h stream behind the kernel -- on
@@ -469,7 +471,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   // -> 19.3 us per step), and fatal when the ordered list's DMA shares the D2H stream with it (two per submit: 92 us per submit
   // on that stream against 73 us of FFT; records read in place, three in flight: 373 .. 403 -> 429 Gsamples/s).  So the kernel
   // stores the counts itself when the launch has few buffers or the list follows eagerly, and a DMA carries them otherwise.
-  const bool eager = hits && nb && p->records_wanted;
+  const bool eager = hits && nb && (p->records_wanted || p->device_list_wanted);
   const bool direct = !p->generic && !p->big && (p->direct_counts || nb <= 4096u || eager);
   a.host_hits = (hits && direct) ? s.h_buf_hits : nullptr;
   a.work_counter = s.d_work_counter;
@@ -562,7 +564,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     }
     if (!(after_is_done && after)) SCN_HIP(hipEventRecord(s.done, cnt));
     if (eager) {
-      int st2 = build_list(p, s, true);
+      int st2 = build_list(p, s, p->records_wanted);  // (the prefetch to pinned memory only for a caller that reads the records on the host)
       if (st2) return st2;
     }
   } else if (!(after && in_packet)) {  // spectrum-only plans: `done` follows the kernel on its stream
@@ -1058,6 +1060,8 @@ int scn_collect(scn_plan *p, int slot, float *power_db, scn_hit *hits, uint32_t 
   if (have_hits) {  // what the automatic mode goes by at the next submit
     if (total && p->view_age < 0xffffffffu) p->view_age++;
     p->records_wanted = hits != nullptr || p->view_age <= 4u;
+    if (total && p->device_list_age < 0xffffffffu) p->device_list_age++;
+    p->device_list_wanted = p->device_list_age <= 4u;
     // the prefetch covers this total + 1/16 + twice the change since the total before (the DMA's time is the records loop's
     // period on a hits-only plan: a flat 25 % margin cost 46 us per submit instead of 39; a short prediction costs one small
     // top-up copy at collect)
@@ -1145,6 +1149,8 @@ int scn_plan_device_hits(scn_plan *p, int slot, const scn_hit **d_list, uint32_t
     return fail(SCN_E_TRUNCATED, "slot %d holds %u hits, the plan's device list %u (max_hits): gather from a host list read with scn_collect_more",
                 slot, s.total_hits, p->d.max_hits);
   SCN_HIP(hipSetDevice(p->d.device_id));
+  p->device_list_age = 0;  // (a caller that sends the list from the device wants it built eagerly too: behind the launch, on the list
+  p->device_list_wanted = true;  // stream, instead of here with the host waiting for it -- 56 us per scn_gather_post against 3, r06_experiments.md)
   if (s.total_hits) {
     if (!s.list_built)
       if ((st = build_list(p, s, false))) return st;

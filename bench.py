@@ -255,10 +255,11 @@ def welch_leg(torch, dev, local_rank, seed, npsd, steps, warmup, rotate=0, pinne
     return elapsed, new_samples
 
 
-def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60, sync=None, threshold=10.0):
+def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60, sync=None, threshold=10.0, sweeps_per_launch=0):
     """BASELINE config 4 in its steady state, the ONE collective inside the timed region: this rank sweeps its contiguous shard of the
-    n_centres-entry table once per step (one launch per sweep, launches of at most 8192 buffers; four slots in flight, each on its
-    own stream below 8192 buffers), and every launch's ordered hit list goes to rank 0 through scn_gather_post / scn_gather_wait on
+    n_centres-entry table once per step (launches of at most 8192 buffers; a shard smaller than that is launched S sweeps at a time --
+    a launch is a batch of whatever is queued, as in the main C4 loop -- unless sweeps_per_launch says otherwise; four slots in
+    flight, each on its own stream below 8192 buffers), and every launch's ordered hit list goes to rank 0 through scn_gather_post / scn_gather_wait on
     a communicator created ONCE, before the region -- posted two launches behind the newest submit, waited for two launches later,
     so that the exchange runs beside the next sweeps' kernels.  Timed twice over the same launches: without the gather (the
     counts are collected at the same place) and with it.  Returns the figures; raises ParityError when the root's last list
@@ -271,19 +272,26 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
     _, fc_all = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0)
     first, fc = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
     shard = len(fc)
-    nb = min(shard, 8192)
-    chunks = [(lo, min(lo + nb, shard)) for lo in range(0, shard, nb)]
+    S = (max(1, 8192 // shard) if sweeps_per_launch == 0 else sweeps_per_launch) if shard < 8192 else 1
+    nb = min(shard, 8192) * S                # buffers per launch
+    chunks = [(lo, min(lo + 8192, shard)) for lo in range(0, shard, 8192)] if S == 1 else [(0, nb)]
     centres, i0 = synth.c4_emitters(n_centres, n)
     step_bytes = shard * n * 12
     R = max(2, -(-(3 << 29) // step_bytes))
+    R = -(-R // S) * S
     raws = [synth.c4_shard_torch(n, first, shard, centres, i0, seed=4 + 1000 * r, device=dev) for r in range(R)]
-    outs = [torch.empty((shard, n), dtype=torch.float32, device=dev) for _ in range(R)]
-    seq = np.arange(first, first + shard, dtype=np.uint64)
+    if S > 1:   # S consecutive sweeps back to back in memory = one launch; ids run on from sweep to sweep (messageQueue.h:86)
+        raws = [torch.cat(raws[g * S:(g + 1) * S], dim=0).contiguous() for g in range(R // S)]
+        R = R // S
+    outs = [torch.empty((nb if S > 1 else shard, n), dtype=torch.float32, device=dev) for _ in range(R)]
+    seq = np.concatenate([np.arange(first, first + shard, dtype=np.uint64) + np.uint64(j * n_centres) for j in range(S)])
+    steps = -(-steps // S) * S               # whole launches
+    warm = -(-warm // S) * S
     D, LAG = 4, 2
     hit_cap = nb * 64
-    cap = 7 * (-(-nb // 4) + 1) * 2          # per launch: an emitter on every 4th centre, seven bins each, and as much again
+    cap = 7 * (-(-nb // 4) + S) * 2          # per launch: an emitter on every 4th centre, seven bins each, and as much again
     flags = capi.OUT_SPECTRUM | capi.OUT_HITS | (capi.PLAN_OVERLAP_SLOTS if nb < 8192 else 0)
-    plan = Plan(n, FS, threshold, max_batch=nb, max_hits=hit_cap, device_id=local_rank, flags=flags)
+    plan = Plan(n, FS, threshold, max_batch=min(nb, 8192 * S), max_hits=hit_cap, device_id=local_rank, flags=flags)
     plan.set_table(fc)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     prep = [[(C.c_void_p(raws[r][lo:hi].data_ptr()), hi - lo, lo, vp(seq[lo:hi]), C.c_void_p(outs[r][lo:hi].data_ptr())) for lo, hi in chunks]
@@ -356,6 +364,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
         state["base"] = j
 
     def run(k_steps, gather, keep_last=False):
+        k_steps //= S                          # launches of S sweeps
         for k in range(k_steps):
             if keep_last and k == k_steps - 1:
                 drain(gather)                  # everything before the last sweep has arrived; now record the last sweep's lists
@@ -403,16 +412,24 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
         out = None
         if rank == 0:
             want = synth.c4_expected_hits(plan.window(), fc_all, centres, i0, n, FS, threshold)
+            if S > 1:   # the last launch holds S sweeps: the same records, the ids running on
+                parts = []
+                for j in range(S):
+                    w = want.copy()
+                    w["seq_id"] += np.uint64(j * n_centres)
+                    parts.append(w)
+                want = np.concatenate(parts)
             ok, worst = compare_hit_lists(last, want)
             sweep_us = el_plain / steps * 1e6
             gsweep_us = el_gather / steps * 1e6
             out = {"value": round(n_centres * n * steps / el_gather / 1e6, 1), "unit": "Msamples/s", "steps": steps, "scaling": "strong",
-                   "centres": n_centres, "centres_per_gpu": shard, "launches_per_sweep": len(chunks), "n_gpus": world,
+                   "centres": n_centres, "centres_per_gpu": shard, "launches_per_sweep": len(chunks) if S == 1 else round(1.0 / S, 4), "sweeps_per_launch": S,
+                   "buffers_per_launch": chunks[0][1] - chunks[0][0], "n_gpus": world,
                    "sweep_us": round(sweep_us, 2), "sweep_with_gather_us": round(gsweep_us, 2),
                    "exposed_gather_us": round(gsweep_us - sweep_us, 2), "exposed_frac": round((gsweep_us - sweep_us) / sweep_us, 4),
                    "gather_us": round(float(np.median(lat)), 1), "gather_us_min": round(float(min(lat)), 1),
                    "value_without_gather": round(n_centres * n * steps / el_plain / 1e6, 1),
-                   "lists_gathered": lists, "records_per_sweep": round(records / max(steps, 1), 1), "cap_per_rank": cap,
+                   "lists_gathered": lists, "records_per_sweep": round(records / max(steps, 1), 1), "cap_per_rank": cap, "lists_per_sweep": round(lists / max(steps, 1), 4),
                    "root_blocked_in_wait_us_per_sweep": round(wait_s / steps * 1e6, 2),
                    "host_us_per_sweep": {"without_gather": state.get("host_plain"), "with_gather": state.get("host_gather"),
                                          "note": "this rank's host time per sweep inside scn_collect (waiting for the launch two behind), scn_gather_post, scn_gather_wait"},
@@ -423,7 +440,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
                                  "behind the newest submit, waited for two launches later; communicator created once before the region"
                                  + ("; one rank: no peers, the root's own part only" if world == 1 else "")),
                    "workload": f"C4: {n_centres} centres x 4096-pt cfloat, {shard} per GPU per sweep over {world} GPU(s), a launch per "
-                               f"{'sweep' if len(chunks) == 1 else 'half sweep'}, four slots in flight"
+                               f"{('sweep' if S == 1 else str(S) + ' sweeps') if len(chunks) == 1 else 'half sweep'}, four slots in flight"
                                + (", each on its own stream (SCN_PLAN_OVERLAP_SLOTS)" if nb < 8192 else "") + ", the hit list of every launch gathered to rank 0"}
             if not ok:
                 raise ParityError(f"C4 gathered list differs from the closed form: {out['check']}")
@@ -1345,7 +1362,7 @@ def main():
     if not stuck and ((args.gather_every_sweep and c4) or (world > 1 and default_shape and not args.no_configs_leg)):
         try:
             c4_steady = c4_gather_leg(torch, dev, local_rank, rank, world, args.centres, max(200, min(args.steps, 2000)),
-                                      sync=dist.barrier if world > 1 else None, threshold=args.threshold)
+                                      sync=dist.barrier if world > 1 else None, threshold=args.threshold, sweeps_per_launch=args.sweeps_per_launch)
         except ParityError as e:
             print(f"bench.py: {e}", file=sys.stderr)
             sys.stdout.flush()

@@ -1138,11 +1138,15 @@ int scn_hits_view(scn_plan *p, int slot, const scn_hit **hits, uint32_t *n) {
 
 }  // extern "C"
 
-// internal (scn_gather.hip): the collected slot's ordered list where the compaction kernel left it, in device memory
-int scn_plan_device_hits(scn_plan *p, int slot, const scn_hit **d_list, uint32_t *n, int *device_id) {
+// internal (scn_gather.hip): the collected slot's ordered list where the compaction kernel left it, in device memory.
+// list_ready == nullptr: the call returns when the list is complete (the host waits for the list kernels).  Otherwise *list_ready
+// receives the event that marks its completion (nullptr when there is nothing to wait for) and the caller orders its own stream
+// behind it (hipStreamWaitEvent): nothing waits on the host -- what scn_gather_post needs to stay out of the sweep loop's way.
+int scn_plan_device_hits(scn_plan *p, int slot, const scn_hit **d_list, uint32_t *n, int *device_id, void **list_ready) {
   int st = check_slot(p, slot);
   if (st) return st;
   if (!d_list || !n) return fail(SCN_E_INVALID, "null argument");
+  if (list_ready) *list_ready = nullptr;
   Slot &s = p->slot[slot];
   if (s.pending || !s.list_valid) return fail(SCN_E_STATE, "slot %d: no collected submit whose hit list is still on the device", slot);
   if (s.total_hits > p->d.max_hits)
@@ -1154,7 +1158,8 @@ int scn_plan_device_hits(scn_plan *p, int slot, const scn_hit **d_list, uint32_t
   if (s.total_hits) {
     if (!s.list_built)
       if ((st = build_list(p, s, false))) return st;
-    SCN_HIP(hipEventSynchronize(s.list_done[s.gen]));
+    if (list_ready) *list_ready = (void *)s.list_done[s.gen];
+    else SCN_HIP(hipEventSynchronize(s.list_done[s.gen]));
   }
   *d_list = s.d_list;
   *n = s.total_hits;

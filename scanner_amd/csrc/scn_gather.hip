@@ -27,7 +27,7 @@
 
 int scn_set_last_error(int status, const char *fmt, ...);  // scn_api.hip
 // scn_api.hip: the collected slot's ordered list in device memory (built if it was not yet), without a host copy
-int scn_plan_device_hits(scn_plan *p, int slot, const scn_hit **d_list, uint32_t *n, int *device_id);
+int scn_plan_device_hits(scn_plan *p, int slot, const scn_hit **d_list, uint32_t *n, int *device_id, void **list_ready = nullptr);
 
 namespace {
 
@@ -457,8 +457,11 @@ int scn_gather_post(scn_comm *c, scn_plan *plan, int slot, uint32_t root, uint32
   const scn_hit *d_list = nullptr;
   uint32_t n_local = 0;
   int dev = c->device;
-  int status = plan ? scn_plan_device_hits(plan, slot, &d_list, &n_local, &dev) : scn_set_last_error(SCN_E_INVALID, "null plan");
+  void *list_ready = nullptr;  // the list kernels' event: the communicator's stream waits for it, the host does not
+  int status = plan ? scn_plan_device_hits(plan, slot, &d_list, &n_local, &dev, &list_ready) : scn_set_last_error(SCN_E_INVALID, "null plan");
   if (status == SCN_OK && dev != c->device) status = scn_set_last_error(SCN_E_INVALID, "the plan lives on device %d, the communicator on device %d", dev, c->device);
+  if (status == SCN_OK && list_ready && hipStreamWaitEvent(c->stream, (hipEvent_t)list_ready, 0) != hipSuccess)
+    status = scn_set_last_error(SCN_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
   if (status != SCN_OK) n_local = 0;
   ScnStreamHeader h;
   h.count = n_local;

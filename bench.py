@@ -285,7 +285,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
         R = R // S
     outs = [torch.empty((nb if S > 1 else shard, n), dtype=torch.float32, device=dev) for _ in range(R)]
     seq = np.concatenate([np.arange(first, first + shard, dtype=np.uint64) + np.uint64(j * n_centres) for j in range(S)])
-    steps = -(-steps // S) * S               # whole launches
+    steps = -(-steps // S) * S * (2 if S > 1 else 1)   # whole launches, and no fewer than a hundred of them
     warm = -(-warm // S) * S
     D, LAG = 4, 2
     hit_cap = nb * 64

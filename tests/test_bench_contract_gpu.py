@@ -113,8 +113,10 @@ def check_gather_leg(g, centres, per_gpu):
         assert k in g and isinstance(g[k], (int, float)), k
     assert g["scaling"] == "strong" and g["centres"] == centres and g["centres_per_gpu"] == per_gpu and g["n_gpus"] == 1
     assert g["sweep_us"] > 0 and g["gather_us"] > 0 and abs(g["exposed_gather_us"] - (g["sweep_with_gather_us"] - g["sweep_us"])) < 0.02
-    assert g["check"]["match"] is True and g["check"]["gathered_hits"] == g["check"]["expected_hits"] == 7 * (centres // 4)
-    assert g["records_per_sweep"] == 7 * (centres // 4) and g["lists_gathered"] == g["steps"] * g["launches_per_sweep"]
+    S = g["sweeps_per_launch"]                       # a shard below 8192 buffers is launched S sweeps at a time: the last LAUNCH's list is checked
+    assert S == max(1, 8192 // per_gpu) and g["buffers_per_launch"] == min(per_gpu, 8192) * S
+    assert g["check"]["match"] is True and g["check"]["gathered_hits"] == g["check"]["expected_hits"] == 7 * (centres // 4) * S
+    assert g["records_per_sweep"] == 7 * (centres // 4) and g["lists_gathered"] == round(g["steps"] * g["launches_per_sweep"])
     assert "scn_gather_post" in g["transport"]
 
 

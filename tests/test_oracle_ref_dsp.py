@@ -91,3 +91,33 @@ def test_product_k1_matches_reference_fixture(built_lib):
         with Plan(n, kind=kind, enob=enob, correct_dc=bool(dc), max_batch=1, mode=capi.MODE_TIME_DOMAIN) as plan:
             got = plan.convert_raw(GOLD[name + "_in"])[0]
         assert got.tobytes() == GOLD[name + "_out"].tobytes(), name
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_product_k1_matches_the_live_reference_object(built_lib):
+    """oracle/_ref travels to the GPU box (git-ignored, not gpurun-ignored): the HIP path's own K1 -- scn_convert_raw, the load
+    phase of the fused kernels -- against the REFERENCE's compiled utility.cpp on random buffers there, bit for bit: every wire
+    format, ENOB 2 .. 16, with and without DC removal, negative means (the int32 /= uint32 quirk) included."""
+    import torch
+
+    from scanner_amd import Plan, capi
+
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(20261004)
+    for case in range(60):
+        kind = int(rng.choice([O.KIND_SHORT_COMPLEX, O.KIND_SHORT, O.KIND_BYTE_COMPLEX]))
+        n = int(rng.choice([16, 64, 700, 1024, 4096, 8192]))
+        enob = int(rng.integers(2, 9 if kind == O.KIND_BYTE_COMPLEX else 17))
+        dc = bool(rng.integers(0, 2))
+        offset = int(rng.integers(-3000, 3000))
+        if kind == O.KIND_BYTE_COMPLEX:
+            raw = np.clip(rng.integers(-128, 128, size=(n, 2)) + offset // 32, -128, 127).astype(np.int8)
+        else:
+            raw = np.clip(rng.integers(-2048, 2048, size=(n, 2)) + offset, -32768, 32767).astype(np.int16)
+            if kind == O.KIND_SHORT:
+                raw = np.ascontiguousarray(raw.T)
+        want = O.ref_convert(kind, raw, n, enob, dc)
+        with Plan(n, kind=kind, enob=enob, correct_dc=dc, max_batch=1, mode=capi.MODE_TIME_DOMAIN) as plan:
+            got = plan.convert_raw(raw)[0]
+        assert got.tobytes() == want.tobytes(), (case, kind, n, enob, dc, offset)

@@ -80,7 +80,6 @@ struct Slot {
   unsigned long long *d_total_acc = nullptr;  // its two device words
   bool total_ready = false;         // the pending / last submit's total is (going to be) in *h_total and its trigger flags, one bit per buffer, in the
                                     // front of h_buf_hits: the counts themselves stayed on the GPU and scn_collect walks nothing
-  uint32_t *d_trig_bits = nullptr;  // [(max_batch + 31) / 32] the trigger bitmap on its way to the host
   hipEvent_t kernel_done = nullptr, staged = nullptr;
   hipStream_t stream = nullptr;     // where this slot's kernels run: the plan's compute stream, or its own (SCN_PLAN_OVERLAP_SLOTS)
   // buffer-queue heads of the persistent workgroups (ScnFftArgs::work_counter; 8 heads, never reset) and their values
@@ -295,7 +294,6 @@ int ensure_slot_outputs(scn_plan *p, Slot &s, uint32_t gen) {
       SCN_HIP(hipHostMalloc(&s.h_buf_hits, sizeof(uint32_t) * ((size_t)mb + 4u), hipHostMallocDefault));
       s.h_total = reinterpret_cast<unsigned long long *>(s.h_buf_hits + (((size_t)mb + 1u) & ~(size_t)1u));
     }
-    if (!s.d_trig_bits && mb >= kTotalKernelFrom) SCN_HIP(hipMalloc(&s.d_trig_bits, sizeof(uint32_t) * (((size_t)mb + 31u) / 32u)));
     if (!s.d_total_acc) {
       SCN_HIP(hipMalloc(&s.d_total_acc, 2u * sizeof(unsigned long long)));
       SCN_HIP(hipMemset(s.d_total_acc, 0, 2u * sizeof(unsigned long long)));
@@ -481,7 +479,10 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   // the list stream, beside the next launch).  With overlapped slots both follow the kernel on the slot's own stream --
   // its next kernel is two submits away, and fewer streams keep both compute streams on hardware queues of their own
   // (HIP maps streams onto 4 queues by default; with a fifth active stream the two compute streams ended up sharing one).
-  hipStream_t cnt = (s.own_stream || direct) ? s.stream : p->d2h_stream;
+  // launches of very many small buffers (total_path): the counts stay on the GPU -- a reduction behind the kernel, ON ITS STREAM, leaves the
+  // batch's total and one trigger bit per buffer in pinned memory (below)
+  const bool total_path = hits && !direct && nb >= kTotalKernelFrom;
+  hipStream_t cnt = (s.own_stream || direct || total_path) ? s.stream : p->d2h_stream;
   hipStream_t lst = list_stream_of(p, s);
   const bool fork_list = eager && lst != s.stream;
   // ONE event marks the kernel's end for whoever waits for it: the host (`done`, when nothing else follows on the compute
@@ -491,7 +492,7 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
   // launches 75.6 -> 73.1 (4096-pt cfloat), 77 -> 74.5 (2048-pt), 60.2 -> 59.3 (int16); 67 M samples 144.5 -> 140.8; but
   // 16.8 M samples 44 -> 46..58 and 8.4 M 31 -> 29..56 (erratic: short kernels that carry an event get serialised).
   const bool after_is_done = cnt == s.stream && !s.own_stream;  // direct counts on the plan's stream
-  hipEvent_t after = (!nb || s.own_stream) ? nullptr : !hits ? s.done : after_is_done ? s.done : s.kernel_done;
+  hipEvent_t after = (!nb || s.own_stream || total_path) ? nullptr : !hits ? s.done : after_is_done ? s.done : s.kernel_done;
   const bool in_packet = after && !p->generic && !p->big && (uint64_t)nb * n >= (1u << 25);
   if (p->big) {
     if (nb && !s.d_gen_work[0]) SCN_HIP(hipMalloc(&s.d_gen_work[0], sizeof(float) * 2 * (size_t)n * p->d.max_batch));
@@ -554,11 +555,14 @@ int submit_common(scn_plan *p, Slot &s, const void *d_raw, uint32_t nb, const do
     if (cnt != s.stream) SCN_HIP(hipStreamWaitEvent(cnt, after, 0));
     if (fork_list) SCN_HIP(hipStreamWaitEvent(lst, after, 0));
     // launches of very many small buffers: the total and the trigger flags (a bit per buffer) by themselves -- the counts stay on
-    // the GPU, where the list kernels read them: nb / 8 bytes cross PCIe instead of 4 nb, and a collect walks nothing
-    s.total_ready = !direct && nb >= kTotalKernelFrom && s.d_trig_bits;
-    if (s.total_ready) {
-      SCN_HIP(scn_launch_hit_total(s.d_buf_hits[s.gen], nb, p->d.trigger_count, s.d_total_acc, s.h_total, s.d_trig_bits, cnt));
-      SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_trig_bits, sizeof(uint32_t) * (((size_t)nb + 31u) / 32u), hipMemcpyDeviceToHost, cnt));
+    // the GPU, where the list kernels read them: nb / 8 bytes cross PCIe instead of 4 nb, and a collect walks nothing.  The
+    // reduction runs on the launch's own stream and stores into pinned memory itself: such a step is bound by the HOST's calls
+    // (a 16-point launch of 524288 buffers takes 27 us on the GPU, every HIP call 4 .. 5 us in a torch process), and this way a
+    // submit is three of them -- kernel, reduction, event -- where the route over the side stream took six (event, wait, reduction,
+    // DMA, event: 72 -> 56 us per step, profiles/r06_experiments.md section 5)
+    s.total_ready = total_path;
+    if (total_path) {
+      SCN_HIP(scn_launch_hit_total(s.d_buf_hits[s.gen], nb, p->d.trigger_count, s.d_total_acc, s.h_total, s.h_buf_hits, cnt));
     } else if (!direct) {
       SCN_HIP(hipMemcpyAsync(s.h_buf_hits, s.d_buf_hits[s.gen], sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, cnt));
     }
@@ -582,7 +586,6 @@ void free_slot(Slot &s) {
   if (s.d_power) (void)hipFree(s.d_power);
   if (s.h_buf_hits) (void)hipHostFree(s.h_buf_hits);
   if (s.d_total_acc) (void)hipFree(s.d_total_acc);
-  if (s.d_trig_bits) (void)hipFree(s.d_trig_bits);
   for (int g = 0; g < 2; g++) {
     if (s.d_buf_hits[g]) (void)hipFree(s.d_buf_hits[g]);
     if (s.d_hits[g]) (void)hipFree(s.d_hits[g]);

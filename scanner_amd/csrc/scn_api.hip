@@ -111,13 +111,15 @@ struct Slot {
   uint32_t n_buffers = 0;
 };
 
-// Buffers per launch from which the batch's total is summed on the GPU (scn_hit_total_kernel) instead of by the host's walk over
-// the counts.  The kernel needs CUs the next launch is using: measured on one box (profiles/r05_table_ab.txt, us per step, host
-// walk -> GPU total) 524288 16-point buffers 80.7 -> 72.3 (hits-only plan: 89 -> 73), but 262144 x 128 points 86.2 -> 99.8,
-// 131072 x 256: 75.0 -> 84.6, 32768 x 1024: 75.3 -> 82.9 -- a walk over 2 MB of counts costs more than the kernel's place on the
-// chip, a walk over 1 MB or less does not.
+// Buffers per launch from which the batch's total and its trigger flags come from a reduction on the GPU (scn_hit_total_kernel, on the
+// launch's own stream, storing into pinned memory) instead of the counts crossing PCIe and the host walking them.  The reduction takes
+// ~6 us of the compute stream per launch; the counts' DMA it replaces runs beside the next launch but costs three more host calls and
+// 4 bytes per buffer of PCIe.  Measured on one box (profiles/r06_total_ab.txt, us per step of the spectrum + hits leg, counts by DMA ->
+// reduction): 524288 x 16 points 56.5 -> 37.1, 262144 x 64: 74.0 -> 51.5, 262144 x 128: 88.1 -> 82.6, but 131072 x 256: 75.0 -> 81.8,
+// 65536 x 512: 75.0 -> 80.9, 32768 x 1024: 74.8 -> 81.9 -- it pays from 2^18 buffers per launch.  (Round 5's form -- the reduction on
+// a side stream behind an event, the flags still by DMA -- paid only from 2^19: profiles/r05_table_ab.txt.)
 #ifndef SCN_TOTAL_KERNEL_FROM
-#define SCN_TOTAL_KERNEL_FROM (1u << 19)
+#define SCN_TOTAL_KERNEL_FROM (1u << 18)
 #endif
 constexpr uint32_t kTotalKernelFrom = SCN_TOTAL_KERNEL_FROM;
 

@@ -983,11 +983,11 @@ def test_every_window_type(torch_cuda, oracle_mod, wt):
 
 
 def test_total_and_trigger_bitmap_from_the_gpu(torch_cuda, oracle_mod):
-    """Launches of 2^19 buffers and more (16-point plans at the bench's batch): the host gets the batch's total and ONE BIT per
+    """Launches of 2^18 buffers and more (16 ... 128-point plans at the bench's batch): the host gets the batch's total and ONE BIT per
     buffer (process_fft's return value, hits > trigger_count, process.cpp:62) from a reduction on the GPU instead of 4 bytes per
     buffer over PCIe; the counts stay on the device, where the list kernels rank the records from them.  Both sides of that line
     on one plan, a count that is not a multiple of 32 or of 4, trigger flags against the oracle's, records intact."""
-    n, nb = 16, (1 << 19) + 37
+    n, nb = 16, (1 << 18) + 37
     rng = np.random.default_rng(5)
     x = (rng.standard_normal((nb, n, 2), dtype=np.float32) * np.float32(0.3)).view(np.complex64).reshape(nb, n)
     fc = 1e9 + 6e6 * (np.arange(nb) % 1000)
@@ -999,7 +999,7 @@ def test_total_and_trigger_bitmap_from_the_gpu(torch_cuda, oracle_mod):
     assert t_ref.any() and not t_ref.all() and ok.mean() > 0.9
     d = _to_dev(torch_cuda, x)
     with Plan(n, FS, thr, max_batch=nb, max_hits=len(h_ref) + 1024, flags=capi.OUT_HITS, trigger_count=2) as plan:
-        for count in (nb, (1 << 19) - 1, 1 << 19, nb - 2):        # bitmap, counts by DMA, bitmap, bitmap (a partial quad, a partial word)
+        for count in (nb, (1 << 18) - 1, 1 << 18, nb - 2):        # bitmap, counts by DMA, bitmap, bitmap (a partial quad, a partial word)
             plan.submit_device(0, d, count, fc[:count])
             total = plan.collect_counts(0)
             plan.submit_device(0, d, count, fc[:count])

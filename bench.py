@@ -450,12 +450,12 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
         plan.close()
 
 
-def welch_roofline(elapsed, steps, new_samples, npsd, kind="cfloat"):
+def welch_roofline(elapsed, steps, new_samples, npsd, kind="cfloat", dc=False):
     N, K = 65536, 16
     algo = new_samples * WELCH_KINDS[kind][1] + npsd * N * 4  # 8 (4, 2) B per NEW sample + 4N/K per segment
     ms = elapsed / steps * 1e3
     achieved = algo / (ms * 1e-3) / 1e9
-    prof = _tracked(f"welch/{N}/{K}/{npsd}" + ("" if kind == "cfloat" else f"/{kind}"))
+    prof = _tracked(f"welch/{N}/{K}/{npsd}" + ("" if kind == "cfloat" else f"/{kind}") + ("/dc" if dc and kind != "cfloat" else ""))
     r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_is": "frac_wall (host wall time per step: the Welch plan exposes no stream to put events on)",
          "kernel": "scn_welch_cols_kernel + scn_welch_rows_kernel (two-pass four-step FFT: the work "
@@ -492,7 +492,7 @@ def welch_main(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     if rank == 0:
-        roof, ms = welch_roofline(elapsed, args.steps, new_samples, npsd, args.kind)
+        roof, ms = welch_roofline(elapsed, args.steps, new_samples, npsd, args.kind, args.dc)
         emit({
             "metric": "Msamples/s (new complex samples through 65536-pt 50%-overlap Welch PSD)",
             "value": round(world * new_samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
@@ -502,7 +502,8 @@ def welch_main(args):
                                    f"{' with DC removal per delivery block' if args.dc and args.kind != 'cfloat' else ''}, "
                                    f"{'pinned host staging + hipGraph replay' if args.welch_pinned else 'stream resident in HBM'}; "
                                    f"independent stream per GPU (replicas)",
-                       "n": 65536, "segments_per_psd": 16, "psd_per_submit": npsd, "pinned": bool(args.welch_pinned), "kind": args.kind},
+                       "n": 65536, "segments_per_psd": 16, "psd_per_submit": npsd, "pinned": bool(args.welch_pinned), "kind": args.kind,
+                       "sample_kind": args.kind, "correct_dc": bool(args.dc and args.kind != "cfloat")},
             "roofline": roof,
             "c5_check": check,
         })

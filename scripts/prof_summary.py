@@ -119,7 +119,11 @@ if "FETCH_SIZE" in summary or "WRITE_SIZE" in summary:
                     "build": _source_hash()},
                    **shape),
               open(os.path.join(out, "pmc_traffic.json"), "w"))
-try:
-    print("bench line under trace:", open(os.path.join(out, "bench_trace.json")).read().strip()[-1400:])
+try:  # (the figures of the traced run itself -- not the roofline object's tracked-profile fields, which at trace time still describe the build BEFORE this one)
+    line = json.loads(open(os.path.join(out, "bench_trace.json")).read().strip().splitlines()[-1])
+    r = line.get("roofline") or {}
+    print("bench line under trace:", json.dumps({"value": line.get("value"), "unit": line.get("unit"), "steps": line.get("steps"), "ms_per_step": line.get("ms_per_step"),
+                                                  "kernel_avg_ms_hip_events": r.get("kernel_avg_ms"), "frac_event": r.get("frac"),
+                                                  "workload": (line.get("config") or {}).get("workload", "")[:160]}))
 except Exception:
     pass

@@ -27,7 +27,8 @@ for shape in found:  # every launch shape scripts/prof_all.sh profiled under thi
     t = json.load(open(os.path.join(d, "pmc_traffic.json")))
     welch = t.get("segments_per_psd") is not None
     mode = t.get("plan_mode") or "both"
-    key = (f"welch/{t['n']}/{t['segments_per_psd']}/{t['psd_per_submit']}" if welch
+    key = (f"welch/{t['n']}/{t['segments_per_psd']}/{t['psd_per_submit']}" + ("" if (t.get("sample_kind") or "cfloat") == "cfloat" else f"/{t['sample_kind']}") +
+           ("/dc" if t.get("correct_dc") else "") if welch
            else f"{t['n']}/{t['sample_kind']}/{t['buffers_per_launch']}" +  # = bench.py's shape_key
                 ("/td" if t.get("time_domain") else "" if mode == "both" else "/" + mode) + ("/dc" if t.get("correct_dc") else ""))
     entry = {("hbm_bytes_per_step" if welch else "hbm_bytes_per_launch"): int(round(t["hbm_bytes_per_launch"])),

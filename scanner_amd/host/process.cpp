@@ -131,7 +131,7 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
 
   // Batches in flight.  This consumer prints every record of every batch (process.cpp:57), so a submit's chain is kernel ->
   // list kernels -> DMA, longer than one kernel: three in flight keep the GPU fed where two left it idle between launches
-  // (the records pipeline); a batch's lines still appear as soon as the queue runs empty, and always in
+  // (HISTORY.md section 8, the records pipeline); a batch's lines still appear as soon as the queue runs empty, and always in
   // submit order.
   const int kPipe = (int)std::min<uint32_t>(std::max<uint32_t>(m_pipeDepth, 1u), (uint32_t)SCN_NUM_SLOTS);
   unsigned char *stage[SCN_NUM_SLOTS];

@@ -158,3 +158,22 @@ def test_bench_with_the_centres_per_buffer_and_from_the_table():
     assert t["final_sweep_hits"] == b["final_sweep_hits"] > 0
     # (the records legs driven from the bench's own process go through the same two forms)
     assert t["with_hit_records"]["python_torch_runtime"]["hits_per_step"] == b["with_hit_records"]["python_torch_runtime"]["hits_per_step"] > 0
+
+
+@pytest.mark.parametrize("extra,kind", [([], "cfloat"), (["--kind", "int16", "--dc"], "int16"), (["--kind", "int8", "--welch-pinned"], "int8")])
+def test_welch_line_checks_its_own_output(extra, kind):
+    """`bench.py --welch` (BASELINE C5): the first and last PSD of the last TIMED step are held to the oracle outside the timed
+    region (a mismatch exits non-zero and prints no line), for float samples and for the integer wire formats, device-resident and
+    through pinned memory + the captured hipGraph."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--welch", "--welch-psd", "8", "--steps", "4", "--warmup", "1"] + extra,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip())
+    for k, t in CONTRACT.items():
+        assert k in d and isinstance(d[k], t), k
+    assert d["config"]["kind"] == kind and d["config"]["psd_per_submit"] == 8 and d["config"]["workload"].startswith("C5:")
+    c = d["c5_check"]
+    assert c["match"] is True and c["psds_checked"] == [0, 7] and c["max_rel_power_vs_max_bin_mean"] <= c["bar"] == 1e-5
+    r = d["roofline"]
+    want = 8 * 16 * 32768 * {"cfloat": 8, "int16": 4, "int8": 2}[kind] + 8 * 65536 * 4     # bytes of NEW samples + the PSDs
+    assert r["bound"] == "hbm" and r["algorithmic_bytes_per_launch"] == want and 0 < r["frac"] < 1

@@ -3,7 +3,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "scripts/README.md", "profiles/r04_experiments.md"]
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "scripts/README.md", "profiles/r04_experiments.md", "profiles/r06_experiments.md"]
 
 
 def test_every_cited_path_exists():
@@ -22,3 +22,12 @@ def test_every_cited_path_exists():
             if not os.path.exists(os.path.join(ROOT, q)):
                 missing.append((d, q))
     assert not missing, missing
+
+
+def test_design_document_stays_reviewable():
+    """DESIGN.md is the current design and the current numbers only -- at most 40 KB, lines of at most 120
+    characters; the rounds before live in HISTORY.md."""
+    txt = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert len(txt.encode()) <= 40 * 1024
+    assert max(len(l) for l in txt.split("\n")) <= 120
+    assert os.path.exists(os.path.join(ROOT, "HISTORY.md"))

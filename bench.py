@@ -1360,10 +1360,10 @@ def main():
     # --gather-every-sweep at any N
     default_shape = not c4 and (n, args.kind, nb) == (4096, "cfloat", 8192) and args.plan_mode == "both" and not td
     c4_steady = None
-    if not stuck and ((args.gather_every_sweep and c4) or (world > 1 and default_shape and not args.no_configs_leg)):
+    if not stuck and ((args.gather_every_sweep and c4) or ((world > 1 or force_dist) and default_shape and not args.no_configs_leg)):
         try:
             c4_steady = c4_gather_leg(torch, dev, local_rank, rank, world, args.centres, max(200, min(args.steps, 2000)),
-                                      sync=dist.barrier if world > 1 else None, threshold=args.threshold, sweeps_per_launch=args.sweeps_per_launch)
+                                      sync=dist.barrier if use_dist else None, threshold=args.threshold, sweeps_per_launch=args.sweeps_per_launch)
         except ParityError as e:
             print(f"bench.py: {e}", file=sys.stderr)
             sys.stdout.flush()

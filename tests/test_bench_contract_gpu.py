@@ -87,6 +87,20 @@ def test_bench_line_through_torch_distributed_one_rank():
     assert g["per_rank"] == [d["final_sweep_hits"]]
 
 
+def test_default_multi_rank_line_carries_the_strong_scaling_sweep():
+    """`bench.py --gpus N` (N > 1) prints the weak-scaling value AND configs.c4: BASELINE config 4 sharded over the ranks (strong
+    scaling) with every launch's hit list gathered inside the timed region.  Here through torch.distributed with ONE rank (the
+    N > 1 code path: process group, barriers, RCCL communicator)."""
+    d = run_bench(["--no-cpu-baseline", "--no-overlap-leg", "--no-records-leg", "--no-hits-only-leg", "--no-copy-ref"], batch=(),
+                  env={"SCN_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29519",
+                       "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    check_common(d)
+    assert d["scaling"] == "weak" and d["config"]["buffers_per_launch"] == 8192
+    g = d["configs"]["c4"]
+    check_gather_leg(g, centres=16384, per_gpu=16384)
+    assert g["launches_per_sweep"] == 2 and "16384 centres" in g["workload"]
+
+
 def test_default_line_carries_a_leg_per_baseline_config():
     """`python bench.py` (C2) also times C3, the C4 per-GPU share and C5 on the same box in the same run"""
     d = run_bench(["--no-records-leg", "--no-overlap-leg", "--no-copy-ref"], batch=())

@@ -45,7 +45,7 @@ ProcessSamples::ProcessSamples(uint32_t numSamples, uint32_t sampleRate, uint32_
       m_preTrigger(preTrigger), m_postTrigger(postTrigger), m_endSequenceId(0), m_writing(false), m_mode(mode),
       m_fileNameBase(fileNameBase), m_threshold(threshold), m_useBandWidth(useBandWidth), m_windowType(windowType),
       m_sampleQueue(nullptr), m_threadCount(threadCount), m_maxBatch(1024), m_pipeDepth(4), m_firstDevice(0), m_hitCount(0),
-      m_bufferCount(0), m_stagedWorkers(0), m_tWait(0), m_tSubmit(0), m_tCollect(0), m_tReport(0), m_failed(false) {
+      m_bufferCount(0), m_stagedWorkers(0), m_indexedSubmits(0), m_tWait(0), m_tSubmit(0), m_tCollect(0), m_tReport(0), m_failed(false) {
   (void)dcIgnoreWidth;  // the reference ignores it too and hard-codes 4 bins (process.cpp:86-88)
   assert(mode > Illegal && mode <= FrequencyDomain);  // process.cpp:99
   assert(threadCount <= MAX_THREADS);                 // process.cpp:100
@@ -152,6 +152,29 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
   if (kPipe >= 2) ring = q.AttachStaging((void *const *)stage, (uint32_t)kPipe, d.max_batch);
   const bool staged = ring >= 0;
   if (staged) m_stagedWorkers++;
+
+  // the sweep's frequency table on the GPU (SetFrequencyTable): a batch that is a consecutive, wrapping run of it names its first entry
+  const std::vector<double> &table = m_tableCentres;
+  const bool useTable = !table.empty() && !timeDomain && Ok(scn_plan_set_table(plan, table.data(), (uint32_t)table.size()), "scn_plan_set_table");
+  uint32_t tableNext = 0;  // where the run is expected to go on
+  auto tableRun = [&](const std::vector<double> &f, uint32_t n, uint32_t *first) -> bool {
+    const uint32_t count = (uint32_t)table.size();
+    uint32_t at = tableNext;
+    if (table[at] != f[0]) {  // (another consumer took the batches in between, or the stream started mid-table: look it up)
+      at = count;
+      for (uint32_t i = 0; i < count; i++)
+        if (table[i] == f[0]) {
+          at = i;
+          break;
+        }
+      if (at == count) return false;
+    }
+    for (uint32_t b = 0; b < n; b++)
+      if (table[(at + b) % count] != f[b]) return false;
+    *first = at;
+    tableNext = (at + n) % count;
+    return true;
+  };
 
   std::vector<double> fc(d.max_batch);
   std::vector<uint64_t> seq(d.max_batch);
@@ -284,7 +307,10 @@ void ProcessSamples::ThreadWorker(uint32_t threadId) {
     const uint64_t tTake1 = nowNs();
     m_tWait += tTake1 - tTake0;
     if (n) {
-      const int stSubmit = scn_submit(plan, head, n, fc.data(), seq.data());
+      uint32_t first = 0;
+      const bool indexed = useTable && tableRun(fc, n, &first);
+      const int stSubmit = indexed ? scn_submit_indexed(plan, head, n, first, seq.data()) : scn_submit(plan, head, n, fc.data(), seq.data());
+      if (indexed) m_indexedSubmits++;
       m_tSubmit += nowNs() - tTake1;
       if (Ok(stSubmit, "scn_submit")) {
         pending[head] = true;

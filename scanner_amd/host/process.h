@@ -2,8 +2,8 @@
 // as the reference (process.h:24-93); the per-buffer CPU work of ThreadWorker
 // (process.cpp:293-299: memcpy, FFTWindow::apply, FFT::process, process_fft) is replaced by
 // one scn_plan per consumer thread: each thread submits up to a batch of queued messages at a time from a
-// pinned staging slot and, while that runs on the GPU, the next slots fill.  With ONE consumer thread the queue
-// writes the producer's buffers straight into those slots (SampleQueue::AttachStaging: no copy in the worker).
+// pinned staging slot and, while that runs on the GPU, the next slots fill.  The queue writes the producer's buffers
+// straight into those slots -- a staging ring per consumer thread (SampleQueue::AttachStaging: no copy in the worker).
 // The stdout protocol ("Start scan at", "freq %lu power_db %f", thread start/stop lines) and
 // the ack / trigger bookkeeping per message follow the reference.
 #pragma once
@@ -49,6 +49,13 @@ class ProcessSamples {
   // (max_batch buffers), two generations of hit regions (8 B x evaluated bins x max_batch each: 2 x 201 MB for a 8192 x
   // 4096-point batch) and its record lists: a host short of GPU memory trades depth for footprint here.
   void SetPipelineDepth(uint32_t depth) { m_pipeDepth = depth; }
+  // The sweep's centre frequencies, in table order (what FrequencyTable(sampleRate, start, stop, useBandWidth, dcIgnoreWidth) holds,
+  // frequencyTable.cpp:9-37): every consumer thread then uploads them to its plan ONCE (scn_plan_set_table), and a batch whose
+  // buffers carry a consecutive, wrapping run of the table -- what a source that retunes through it delivers, frequencyTable.cpp:38-46 --
+  // is submitted by naming its first entry (scn_submit_indexed): no centre frequency per buffer crosses the boundary.  Any other
+  // batch (HackRF sweep headers, a source with a table of its own) goes out with its centres as before; the records are the same.
+  void SetFrequencyTable(const std::vector<double> &centres) { m_tableCentres = centres; }
+  uint64_t GetIndexedSubmitCount() const { return m_indexedSubmits; }  // batches that went out as a run of the table
   uint64_t GetHitCount() const { return m_hitCount; }
   uint64_t GetBufferCount() const { return m_bufferCount; }
   // consumer threads that run the zero-copy path (the queue writes into their plan's pinned slots, SampleQueue::AttachStaging);
@@ -91,6 +98,8 @@ class ProcessSamples {
   int m_firstDevice;
   std::atomic<uint64_t> m_hitCount, m_bufferCount;
   std::atomic<uint32_t> m_stagedWorkers;
+  std::vector<double> m_tableCentres;
+  std::atomic<uint64_t> m_indexedSubmits;
   std::atomic<uint64_t> m_tWait, m_tSubmit, m_tCollect, m_tReport;  // nanoseconds, see GetWorkerTimes
   std::atomic<bool> m_failed;
   std::mutex m_errorMutex;

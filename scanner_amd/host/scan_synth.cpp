@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 
+#include "frequencyTable.h"
 #include "process.h"
 #include "syntheticSource.h"
 
@@ -18,7 +19,7 @@ int main(int argc, char **argv) {
   double start = 88e6, stop = 108e6, sigma = 0.01;
   float threshold = 10.0f;
   uint64_t seed = 1;
-  bool correctDC = false, timeDomain = false;
+  bool correctDC = false, timeDomain = false, useTable = false;
   std::string kindName = "short_complex", dump, outFile;
   uint32_t pre = 0, post = 0;
   unsigned long burstFirst = 1, burstLast = 0;
@@ -48,6 +49,7 @@ int main(int argc, char **argv) {
     else if (a == "--seed") seed = (uint64_t)atoll(val());
     else if (a == "--kind") kindName = val();
     else if (a == "--correct-dc") correctDC = true;
+    else if (a == "--table") useTable = true;  // hand the worker the sweep's frequency table (scn_plan_set_table / scn_submit_indexed)
     else if (a == "--mode") timeDomain = std::string(val()) == "time";
     else if (a == "--dump") dump = val();
     else if (a == "--outfile") outFile = val();
@@ -87,6 +89,12 @@ int main(int argc, char **argv) {
   ProcessSamples process(n, fs, enob, threshold, gr::fft::window::WIN_BLACKMAN_HARRIS, timeDomain ? ProcessSamples::TimeDomain : ProcessSamples::FrequencyDomain,
                          threads, outFile, 0.75, 0.0, pre, post);
   process.SetMaxBatch(batch);
+  if (useTable) {  // the table the source retunes through, built the way the reference builds it (frequencyTable.cpp:9-37)
+    FrequencyTable table(fs, start, stop, 0.75, 0.0, true);
+    std::vector<double> centres;
+    for (uint32_t i = 0; i < table.GetFrequencyCount(); i++) centres.push_back(table.GetFrequencyFromIndex(i));
+    process.SetFrequencyTable(centres);
+  }
   SampleQueue sampleQueue(kind, enob, n, depth, correctDC, outFile != "");  // scan.cpp:223
 
   // scan.cpp:234-238 (the source delivers numIterations+1 sweeps: the first one is the queue's warm-up discard)
@@ -100,6 +108,7 @@ int main(int argc, char **argv) {
   if (!ok) fprintf(stderr, "scan_synth: %s\n", process.GetLastError().c_str());
   const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   fprintf(stderr, "buffers %lu hits %lu\n", (unsigned long)process.GetBufferCount(), (unsigned long)process.GetHitCount());
+  if (useTable) fprintf(stderr, "table: %lu batch(es) submitted as a run of the GPU-resident frequency table\n", (unsigned long)process.GetIndexedSubmitCount());
   // (the clock starts before the discarded warm-up sweep and includes plan creation: a lower bound on the pipeline's rate)
   fprintf(stderr, "seconds %.3f Msamples/s %.1f\n", seconds, (double)process.GetBufferCount() * n / seconds / 1e6);
   const ProcessSamples::WorkerTimes wt = process.GetWorkerTimes();

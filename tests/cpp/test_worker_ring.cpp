@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/scanner_hip.h"
+#include "frequencyTable.h"
 #include "process.h"
 #include "syntheticSource.h"
 
@@ -30,6 +31,7 @@ struct FakeSlot {
   std::vector<scn_hit> list;  // the collected submit's records (scn_collect_more reads it)
 };
 struct FakePlan {
+  std::vector<double> table;  // scn_plan_set_table
   scn_plan_desc d;
   size_t bufBytes = 0;
   uint64_t tickets = 0, collected = 0;  // per plan: a consumer collects ITS submits oldest first
@@ -130,6 +132,28 @@ int scn_submit(scn_plan *plan, int slot, uint32_t n, const double *fc, const uin
     for (uint32_t h = 0; h < g_hitsPerBuffer; h++) g_expected.push_back((uint64_t)fc[b] + h);
   return SCN_OK;
 }
+int g_indexedSubmits = 0;
+int scn_plan_set_table(scn_plan *plan, const double *fc, uint32_t count) {
+  FakePlan *p = P(plan);
+  for (int s = 0; s < SCN_NUM_SLOTS; s++)
+    if (p->slot[s].pending) violation("scn_plan_set_table with slot " + std::to_string(s) + " pending");
+  p->table.assign(fc, fc + count);
+  return SCN_OK;
+}
+int scn_submit_indexed(scn_plan *plan, int slot, uint32_t n, uint32_t first, const uint64_t *seq) {
+  FakePlan *p = P(plan);
+  if (p->table.empty() || first >= p->table.size()) {
+    violation("scn_submit_indexed without a table / outside it");
+    return SCN_E_STATE;
+  }
+  std::vector<double> fc(n);
+  for (uint32_t b = 0; b < n; b++) fc[b] = p->table[(first + b) % p->table.size()];  // what the real plan's compaction kernel reads
+  {
+    std::lock_guard<std::mutex> g(g_m);
+    g_indexedSubmits++;
+  }
+  return scn_submit(plan, slot, n, fc.data(), seq);
+}
 int scn_collect(scn_plan *plan, int slot, float *, scn_hit *hits, uint32_t cap, uint32_t *n_hits, uint8_t *trig) {
   FakePlan *p = P(plan);
   FakeSlot &s = p->slot[slot];
@@ -194,7 +218,8 @@ int g_failures = 0;
   } while (0)
 
 // one run: a synthetic producer, one consumer thread on the fake plan; returns the freq values ProcessSamples printed
-std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t sweeps, bool &ok, uint32_t threads = 1) {
+std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t sweeps, bool &ok, uint32_t threads = 1, bool withTable = false) {
+  g_indexedSubmits = 0;
   g_violations.clear();
   g_expected.clear();
   g_seenSeq.clear();
@@ -209,6 +234,12 @@ std::vector<uint64_t> run(uint32_t n, uint32_t batch, uint32_t depth, uint32_t s
     SyntheticSource source(8000000, n, 88e6, 130e6, SampleQueue::ShortComplex, 5, 0.02);
     ProcessSamples process(n, 8000000, 12, 10.0f, gr::fft::window::WIN_BLACKMAN_HARRIS, ProcessSamples::FrequencyDomain, threads);
     process.SetMaxBatch(batch);
+    if (withTable) {
+      FrequencyTable table(8000000, 88e6, 130e6, 0.75, 0.0, true);
+      std::vector<double> centres;
+      for (uint32_t i = 0; i < table.GetFrequencyCount(); i++) centres.push_back(table.GetFrequencyFromIndex(i));
+      process.SetFrequencyTable(centres);
+    }
     SampleQueue q(SampleQueue::ShortComplex, 12, n, depth, false, false);
     ok = source.Start() && source.StartStreaming(sweeps + 1, q);
     if (ok) ok = process.StartProcessing(q);
@@ -324,6 +355,22 @@ int main() {
     CHECK(g_plans == 2 && g_stagedWorkers == 2);
     CHECK(g_stagedAppends + g_copiedAppends == g_buffers && g_stagedAppends > 0);
     if (variant == 1) CHECK(g_queuedAtAttach == 64 && g_copiedAppends == 64);
+  }
+  // 5a. the sweep's frequency table on the "GPU" (ProcessSamples::SetFrequencyTable): every batch is a consecutive, wrapping run of the
+  //     7-entry table (batches of 4: the runs wrap in most of them), so every submit names its first entry -- and the lines are the same
+  g_collectSleepUs = 300;
+  for (uint32_t threads = 1; threads <= 2; threads++) {
+    got = run(256, 4, 64, 30, ok, threads, true);
+    CHECK(ok);
+    for (const std::string &v : g_violations) fprintf(stderr, "violation (table, %u consumers): %s\n", threads, v.c_str());
+    CHECK(g_violations.empty());
+    std::vector<uint64_t> a = got, b = g_expected;
+    if (threads > 1) {
+      std::sort(a.begin(), a.end());
+      std::sort(b.begin(), b.end());
+    }
+    CHECK(a.size() > 50 && a == b);
+    CHECK(g_indexedSubmits == g_submits && g_submits > 10);
   }
   // 5b. one of the two consumers loses its GPU path half way: it reports what it had in flight, detaches its ring and leaves; the
   //     other goes on alone and the producer is never left waiting for the dead ring's slots

@@ -145,20 +145,26 @@ KINDS = {"float": 4, "short_complex": 3, "short": 2, "byte": 1}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,enob,dc,fs", [("short_complex", 12, False, 8000000), ("float", 12, False, 8000000), ("byte", 8, False, 8000000),
-                                             ("short", 12, True, 8000000),
-                                             # the HackRF's other rates (hackRFSource.cpp:156-161): fs / N does not divide, bin_step truncates
-                                             ("short_complex", 12, False, 20000000), ("byte", 8, False, 12500000)])
-def test_scan_synth_transcript_matches_oracle(host_build, oracle_mod, tmp_path, kind, enob, dc, fs):
+@pytest.mark.parametrize("kind,enob,dc,fs,table", [("short_complex", 12, False, 8000000, False), ("float", 12, False, 8000000, False), ("byte", 8, False, 8000000, False),
+                                                   ("short", 12, True, 8000000, False),
+                                                   # the HackRF's other rates (hackRFSource.cpp:156-161): fs / N does not divide, bin_step truncates
+                                                   ("short_complex", 12, False, 20000000, False), ("byte", 8, False, 12500000, False),
+                                                   # the worker with the sweep's frequency table on the GPU (ProcessSamples::SetFrequencyTable):
+                                                   # batches of 5 over 7 / 4 centres, so the runs wrap; the same transcript
+                                                   ("short_complex", 12, False, 8000000, True), ("float", 12, False, 12500000, True)])
+def test_scan_synth_transcript_matches_oracle(host_build, oracle_mod, tmp_path, kind, enob, dc, fs, table):
     _, demo = host_build
     n, iters = 4096, 2
     dump = tmp_path / "raw.bin"
     cmd = [demo, "--kind", kind, "--n", str(n), "--fs", str(fs), "--start", "88e6", "--stop", "130e6",
            "--niterations", str(iters), "--threshold", "10", "--enob", str(enob), "--sigma", "0.02", "--batch", "5",
            "--depth", "16", "--dump", str(dump), "--emitter", "98.5e6:0.2", "--emitter", "101.1e6:0.05",
-           "--emitter", "119.3e6:0.4", "--emitter", "127.0e6:0.1"] + (["--correct-dc"] if dc else [])
+           "--emitter", "119.3e6:0.4", "--emitter", "127.0e6:0.1"] + (["--correct-dc"] if dc else []) + (["--table"] if table else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
+    if table:   # every batch went out as a run of the GPU-resident table (scn_submit_indexed)
+        m = re.search(r"table: (\d+) batch", out.stderr)
+        assert m and int(m.group(1)) >= 2
     got = [l for l in out.stdout.splitlines() if l.startswith("freq ")]
     starts = [l for l in out.stdout.splitlines() if l.startswith("Start scan at ")]
 

@@ -10,7 +10,10 @@
 // (process.cpp:272-314); bench.py runs this program as a child and reports both.
 //
 //   abi_bench [--n 4096] [--batch 8192] [--kind cfloat|int16|int8] [--threshold 10] [--steps 300] [--warmup 50]
-//             [--depth 3] [--mode counts|copy|view|landed] [--rotate 4] [--flags extra plan flags] [--lib libscanner_hip.so]
+//             [--depth 3] [--mode counts|copy|view|landed|gather] [--rotate 4] [--flags extra plan flags] [--lib libscanner_hip.so]
+// --mode gather (round 6): the steady state of a sharded sweep -- counts collected two launches behind the newest submit, that launch's
+// ordered list posted to rank 0 (scn_gather_post on a ONE-rank communicator created before the loop: no peers, what a rank adds to
+// its own sweep) and waited for two launches later; `--mode counts --lag 2` is the same loop without the gather.
 // prints one JSON line.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
@@ -45,6 +48,11 @@ struct Api {
   decltype(&scn_hits_view) hits_view;
   decltype(&scn_last_error) last_error;
   decltype(&scn_abi_version) abi_version;
+  decltype(&scn_comm_unique_id) comm_unique_id;
+  decltype(&scn_comm_create) comm_create;
+  decltype(&scn_comm_destroy) comm_destroy;
+  decltype(&scn_gather_post) gather_post;
+  decltype(&scn_gather_wait) gather_wait;
 };
 
 // xoshiro128+ and Box-Muller: 67 M Gaussian values per C2 batch in well under a second
@@ -76,7 +84,7 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 }  // namespace
 
 int main(int argc, char **argv) {
-  uint32_t n = 4096, batch = 8192, steps = 300, warmup = 50, depth = 3, rotate = 4, extra_flags = 0;
+  uint32_t n = 4096, batch = 8192, steps = 300, warmup = 50, depth = 3, rotate = 4, extra_flags = 0, lag = 0;
   float threshold = 10.0f;
   bool hits_only = false;
   std::string kind = "cfloat", mode = "copy", lib = "", host_log = "";
@@ -89,6 +97,7 @@ int main(int argc, char **argv) {
     else if (a == "--depth") depth = (uint32_t)atoi(v.c_str());
     else if (a == "--rotate") rotate = (uint32_t)atoi(v.c_str());
     else if (a == "--flags") extra_flags = (uint32_t)atoi(v.c_str());
+    else if (a == "--lag") lag = (uint32_t)atoi(v.c_str());  // counts mode: collect the launch `lag` behind the newest right after each submit (the gather loop's shape)
     else if (a == "--hits-only") hits_only = atoi(v.c_str()) != 0;  // 1: a plan without SCN_OUT_SPECTRUM, what ProcessSamples::ThreadWorker creates
     else if (a == "--threshold") threshold = (float)atof(v.c_str());
     else if (a == "--kind") kind = v;
@@ -100,7 +109,7 @@ int main(int argc, char **argv) {
       return 2;
     }
   }
-  if (depth < 1 || depth > SCN_NUM_SLOTS || rotate < 1 || (mode != "counts" && mode != "copy" && mode != "view" && mode != "landed")) {
+  if (depth < 1 || depth > SCN_NUM_SLOTS || rotate < 1 || (mode != "counts" && mode != "copy" && mode != "view" && mode != "landed" && mode != "gather") || lag >= depth) {
     fprintf(stderr, "abi_bench: bad --depth / --rotate / --mode\n");
     return 2;
   }
@@ -129,6 +138,11 @@ int main(int argc, char **argv) {
   SYM(hits_view, "scn_hits_view");
   SYM(last_error, "scn_last_error");
   SYM(abi_version, "scn_abi_version");
+  SYM(comm_unique_id, "scn_comm_unique_id");
+  SYM(comm_create, "scn_comm_create");
+  SYM(comm_destroy, "scn_comm_destroy");
+  SYM(gather_post, "scn_gather_post");
+  SYM(gather_wait, "scn_gather_wait");
 #undef SYM
   if (api.abi_version() != SCN_ABI_VERSION) {
     fprintf(stderr, "abi_bench: library ABI %u, header %u\n", api.abi_version(), (unsigned)SCN_ABI_VERSION);
@@ -264,6 +278,100 @@ int main(int argc, char **argv) {
     collects++;
     pending[s] = false;
   };
+  // ---- the gather loop (--mode gather) and its plain twin (--mode counts --lag L)
+  if (mode == "gather" || lag) {
+    if (mode == "gather") lag = lag ? lag : 2;
+    scn_comm *comm = nullptr;
+    if (mode == "gather") {
+      unsigned char id[SCN_COMM_ID_BYTES];
+      if (api.comm_unique_id(id) != SCN_OK || api.comm_create(id, 0, 1, 0, &comm) != SCN_OK) {
+        fprintf(stderr, "abi_bench: communicator: %s\n", api.last_error());
+        return 2;
+      }
+    }
+    const uint32_t cap = d.max_hits;
+    std::vector<int> ticket(depth, -1);
+    std::vector<bool> pend(depth, false);
+    uint64_t j = 0, base_j = 0, records = 0, lists = 0;
+    double post_s = 0, wait_s = 0, coll_s = 0;
+    auto finish = [&](uint32_t s) {
+      const double t0 = now();
+      const scn_hit *list = nullptr;
+      uint64_t total = 0;
+      uint32_t per_rank = 0;
+      if (api.gather_wait(comm, (uint32_t)ticket[s], &list, &total, &per_rank) != SCN_OK && !rc) {
+        fprintf(stderr, "abi_bench: gather_wait: %s\n", api.last_error());
+        rc = 3;
+      }
+      if (total) checksum += list[0].freq_hz + list[total - 1].freq_hz;
+      wait_s += now() - t0;
+      ticket[s] = -1;
+      records += total;
+      lists++;
+    };
+    auto behind = [&](uint64_t jj) {  // launch jj: its counts, then (gather mode) its list on the way to the root
+      const uint32_t s2 = (uint32_t)(jj % depth);
+      double t0 = now();
+      uint32_t nh = 0;
+      if (api.collect(plan, (int)s2, nullptr, nullptr, 0, &nh, nullptr) != SCN_OK && !rc) {
+        fprintf(stderr, "abi_bench: collect: %s\n", api.last_error());
+        rc = 3;
+      }
+      coll_s += now() - t0;
+      pend[s2] = false;
+      if (comm) {
+        t0 = now();
+        uint32_t tk = 0;
+        if (api.gather_post(comm, plan, (int)s2, 0, cap, &tk) != SCN_OK && !rc) {
+          fprintf(stderr, "abi_bench: gather_post: %s\n", api.last_error());
+          rc = 3;
+        }
+        post_s += now() - t0;
+        ticket[s2] = (int)tk;
+      }
+    };
+    auto gstep = [&]() {
+      const uint32_t s = (uint32_t)(j % depth), r = (uint32_t)(j % rotate);
+      if (ticket[s] >= 0) finish(s);
+      else if (pend[s]) behind(j - depth);
+      if (api.submit_device(plan, (int)s, d_in[r], batch, fc.data(), seq.data(), hits_only ? nullptr : static_cast<float *>(d_out[r])) != SCN_OK && !rc) {
+        fprintf(stderr, "abi_bench: submit: %s\n", api.last_error());
+        rc = 3;
+      }
+      pend[s] = true;
+      j++;
+      if (j - 1 >= base_j + lag) behind(j - 1 - lag);
+    };
+    auto gdrain = [&]() {
+      for (uint64_t jj = (j > lag && j - lag > base_j) ? j - lag : base_j; jj < j; jj++)
+        if (pend[jj % depth]) behind(jj);
+      for (uint32_t s = 0; s < depth; s++)
+        if (ticket[s] >= 0) finish(s);
+      base_j = j;
+    };
+    for (double t0 = now(); now() - t0 < 0.5 && !rc;)
+      for (int k = 0; k < 100; k++) gstep();
+    for (uint32_t k = 0; k < warmup; k++) gstep();
+    gdrain();
+    HIPCK(hipDeviceSynchronize());
+    records = lists = 0;
+    post_s = wait_s = coll_s = 0;
+    const double t0 = now();
+    for (uint32_t k = 0; k < steps; k++) gstep();
+    gdrain();
+    HIPCK(hipDeviceSynchronize());
+    const double el = now() - t0;
+    if (comm) api.comm_destroy(comm);
+    api.plan_destroy(plan);
+    int hip_version = 0;
+    (void)hipRuntimeGetVersion(&hip_version);
+    printf("{\"value\": %.1f, \"unit\": \"Msamples/s\", \"ms_per_step\": %.5f, \"steps\": %u, \"n\": %u, \"batch\": %u, \"kind\": \"%s\", \"mode\": \"%s\", "
+           "\"submits_in_flight\": %u, \"lag\": %u, \"lists_gathered\": %llu, \"records_per_step\": %.1f, \"host_us_per_step\": {\"collect\": %.2f, \"gather_post\": %.2f, "
+           "\"gather_wait\": %.2f}, \"hip_runtime_version\": %d, \"checksum\": %llu}\n",
+           (double)batch * n * steps / el / 1e6, el / steps * 1e3, steps, n, batch, kind.c_str(), mode.c_str(), depth, lag, (unsigned long long)lists,
+           (double)records / steps, coll_s / steps * 1e6, post_s / steps * 1e6, wait_s / steps * 1e6, hip_version, (unsigned long long)checksum);
+    return rc;
+  }
   uint64_t launch = 0;
   auto step = [&]() {
     const uint32_t s = (uint32_t)(launch % depth), r = (uint32_t)(launch % rotate);

@@ -15,3 +15,4 @@ for b in 2048 8192; do
   done
 done
 } | tee $O/abi_gather.jsonl | cut -c1-330
+timeout 900 python3 scripts/r06_welch_acc.py 2>&1 | grep -v amdgpu.ids | tee $O/welch_acc.txt

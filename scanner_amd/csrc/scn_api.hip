@@ -1304,6 +1304,7 @@ struct scn_welch {
   float scale = 1.0f;      // K1's 1/max
   bool dc = false;         // correct_dc on an integer wire format
   int *d_dc = nullptr;     // [max_psd*K + 1][2] block sums (device path; the pinned path's slots own theirs)
+  double *d_tw256 = nullptr;  // W_256^m in double (the row transform)
   WelchSlot slot[SCN_NUM_SLOTS];
 };
 
@@ -1317,6 +1318,7 @@ int welch_enqueue(scn_welch *w, const void *d_in, uint32_t n_psd, float *d_psd, 
   ScnWelchArgs a;
   a.scale = w->scale;
   a.dc_sums = d_dc;
+  a.tw256 = reinterpret_cast<const double2_scn *>(w->d_tw256);
   a.partial = d_partial;
   a.parts = w->parts;
   a.in = d_in;
@@ -1385,6 +1387,16 @@ int scn_welch_create(const scn_welch_desc *desc, scn_welch **out) {
     if ((e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)) != hipSuccess) break;
     if ((e = hipMalloc(&w->d_window, sizeof(float) * d.n)) != hipSuccess) break;
     if ((e = hipMalloc(&w->d_twiddle, sizeof(float) * 2 * d.n)) != hipSuccess) break;
+    {
+      std::vector<double> tw256(2 * 256);
+      for (uint32_t m = 0; m < 256; m++) {
+        const double a = -2.0 * pi * (double)m / 256.0;
+        tw256[2 * m] = std::cos(a);
+        tw256[2 * m + 1] = std::sin(a);
+      }
+      if ((e = hipMalloc(&w->d_tw256, sizeof(double) * tw256.size())) != hipSuccess) break;
+      if ((e = hipMemcpy(w->d_tw256, tw256.data(), sizeof(double) * tw256.size(), hipMemcpyHostToDevice)) != hipSuccess) break;
+    }
     if ((e = hipMalloc(&w->d_work, sizeof(float) * 2 * (size_t)d.n * d.max_psd * d.segments_per_psd)) != hipSuccess) break;
     // enough row workgroups for one per CU: 16 tiles x max_psd x parts >= CUs, parts <= 4 and <= K (measured, 8 PSDs per
     // submit: 68.5 / 75.9 / 73.7 Gsamples/s with 1 / 2 / 4 parts; from 16 PSDs per submit up the split only costs)
@@ -1427,6 +1439,7 @@ int scn_welch_destroy(scn_welch *w) {
   if (w->d_work) (void)hipFree(w->d_work);
   if (w->d_partial) (void)hipFree(w->d_partial);
   if (w->d_dc) (void)hipFree(w->d_dc);
+  if (w->d_tw256) (void)hipFree(w->d_tw256);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
   return SCN_OK;

@@ -86,6 +86,7 @@ struct ScnWelchArgs {
   float inv_k;
   float scale;             // K1's 1/max (utility.cpp:16-17,40-41,64-65); 1 for float samples
   int *dc_sums;            // [n_segments + 1][2] integer sums per delivery block (correctDC on integer samples), or nullptr
+  const double2_scn *tw256;  // W_256^m, m in [0, 256), in double: the row transform's twiddles
 };
 hipError_t scn_launch_welch(int kind, bool correct_dc, const ScnWelchArgs &args, int num_cus, hipStream_t stream);
 // the column kernel's split of a submit: `groups` workgroups per column tile, `per` consecutive segments each (the last ragged)

@@ -270,6 +270,12 @@ __global__ __launch_bounds__(256, SCN_WELCH_ROWS_WPS) void scn_welch_rows_kernel
   const uint32_t k1 = 16u * i + hi;
   const uint32_t s_lo = (args.k * part) / args.parts, s_hi = (args.k * (part + 1u)) / args.parts;  // this part's segments
 
+  // The LAST pass of the row transform runs in DOUBLE, as pass 3 of the 16384-point kernel and the rows of the plain 65536-point plan do
+  // (scn_big.hip, where the all-float form read 1.0e-5 .. 1.9e-5 on strong-tone buffers): a strong tone's partial sums in the last
+  // levels are 256x the input and their float rounding lands on the other 255 bins of the tone's row.  The all-float form of THIS
+  // kernel stayed inside the bar in every test, but only just (round 6: 9.97e-6 in a 30-minute fuzz, 9.27e-6 on 192 strong-tone
+  // PSDs with K = 2) -- Welch averages the power, not the error of a bin that sits beside the same tone in every segment.
+  // (profiles/r06_experiments.md section 8: all float / last pass double / both passes double.)
   cf twa[16];
 #pragma unroll
   for (int p = 1; p < 16; p++) twa[p] = from_v2f(args.twiddle[(256u * lo * p) & (WN - 1)]);  // W_256^{b p}
@@ -294,30 +300,31 @@ __global__ __launch_bounds__(256, SCN_WELCH_ROWS_WPS) void scn_welch_rows_kernel
     for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r0, ld_voff, a * 2048u, SCN_WELCH_AUX_WK_LD));
   }
   for (uint32_t s = s_lo; s < s_hi; s++) {
-    cf v[16];
+    cf u[16];
 #pragma unroll
-    for (int a = 0; a < 16; a++) v[a] = from_v2f(raw[a]);
+    for (int a = 0; a < 16; a++) u[a] = from_v2f(raw[a]);
     {
       const __amdgpu_buffer_rsrc_t rn = wk_rsrc(s + 1u);
 #pragma unroll
       for (int a = 0; a < 16; a++) raw[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rn, ld_voff, a * 2048u, SCN_WELCH_AUX_WK_LD));
     }
-    fft16(v);
+    fft16(u);
 #pragma unroll
     for (int p = 0; p < 16; p++) {
-      cf y = v[OUT16(p)];
+      cf y = u[OUT16(p)];
       if (p) y = cmul(y, twa[p]);
       w1[p] = to_v2f(y);
     }
     __syncthreads();
+    cd v[16];
 #pragma unroll
-    for (int b = 0; b < 16; b++) v[b] = from_v2f(r1[b * 17]);
-    fft16(v);
+    for (int b = 0; b < 16; b++) v[b] = to_cd(r1[b * 17]);
+    fft16_d(v);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-      const cf x = v[OUT16(q)];
-      // |X|^2 exactly as the single-FFT path forms it, summed over this part's segments in order
-      acc[q] += __builtin_fmaf(x.y, x.y, x.x * x.x);
+      const cd x = v[OUT16(q)];
+      // |X|^2 as the plain 65536-point plan forms it (one rounding), summed over this part's segments in order, in float like the oracle
+      acc[q] += (float)__builtin_fma(x.y, x.y, x.x * x.x);
     }
     __syncthreads();
   }

@@ -114,6 +114,23 @@ def test_abi_bench_refuses_what_it_does_not_understand(host_build):
         assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+@pytest.mark.gpu
+def test_abi_bench_gather_loop(host_build):
+    """abi_bench --mode gather: the steady-state gather loop from a C++ process on the system HIP runtime (a one-rank communicator:
+    RCCL loaded with dlopen outside a torch process too) -- every launch's list is posted and waited for, none is lost."""
+    import json
+
+    exe = os.path.join(HOST, "abi_bench")
+    r = subprocess.run([exe, "--batch", "512", "--steps", "40", "--warmup", "5", "--depth", "4", "--mode", "gather", "--flags", "4"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["mode"] == "gather" and d["lists_gathered"] == 40 and d["records_per_step"] > 100 and d["lag"] == 2
+    plain = subprocess.run([exe, "--batch", "512", "--steps", "40", "--warmup", "5", "--depth", "4", "--mode", "counts", "--lag", "2", "--flags", "4"],
+                           capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0 and json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])["lists_gathered"] == 0
+
+
 def test_reference_call_sites_compile(host_build, tmp_path):
     """The wiring of scan.cpp:211-239 written against the reference's names compiles unchanged."""
     src = tmp_path / "wiring.cpp"

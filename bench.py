@@ -655,6 +655,7 @@ def claim_stdout():
 
 
 GATHER_DEADLINE_S = 120
+C4_LEG_DEADLINE_S = 180  # the steady-state leg of configs.c4 at N > 1 (a few seconds of work: generous)
 
 
 def emit(obj):
@@ -1360,16 +1361,42 @@ def main():
     # --gather-every-sweep at any N
     default_shape = not c4 and (n, args.kind, nb) == (4096, "cfloat", 8192) and args.plan_mode == "both" and not td
     c4_steady = None
+    leg_stuck = False
     if not stuck and ((args.gather_every_sweep and c4) or ((world > 1 or force_dist) and default_shape and not args.no_configs_leg)):
-        try:
-            c4_steady = c4_gather_leg(torch, dev, local_rank, rank, world, args.centres, max(200, min(args.steps, 2000)),
-                                      sync=dist.barrier if use_dist else None, threshold=args.threshold, sweeps_per_launch=args.sweeps_per_launch)
-        except ParityError as e:
-            print(f"bench.py: {e}", file=sys.stderr)
+        # On a helper thread with a deadline when there are peers: the leg's exchange (scn_gather_post: grouped ncclSend / ncclRecv of fixed
+        # size) has only ever run with ONE rank on hardware -- no multi-GPU node was available to the builder --, and a rank that never
+        # arrives there must cost the line one field, not the run its line.
+        import threading
+
+        leg = {}
+
+        def leg_job():
+            try:
+                torch.cuda.set_device(dev)  # (the current device is per thread)
+                leg["out"] = c4_gather_leg(torch, dev, local_rank, rank, world, args.centres, max(200, min(args.steps, 2000)),
+                                           sync=dist.barrier if use_dist else None, threshold=args.threshold, sweeps_per_launch=args.sweeps_per_launch)
+            except ParityError as e:
+                leg["parity"] = str(e)
+            except Exception as e:  # a side leg must not cost the run its line
+                leg["error"] = f"{type(e).__name__}: {e}"[:300]
+
+        if world > 1:
+            th = threading.Thread(target=leg_job, daemon=True)
+            th.start()
+            th.join(C4_LEG_DEADLINE_S)
+            leg_stuck = th.is_alive()
+        else:
+            leg_job()
+        if "parity" in leg:
+            print(f"bench.py: {leg['parity']}", file=sys.stderr)
             sys.stdout.flush()
             os._exit(3)
-        except Exception as e:  # a side leg must not cost the run its line (a rank that fails here fails on every rank: the calls are collective)
-            c4_steady = {"error": f"{type(e).__name__}: {e}"[:300]} if rank == 0 else None
+        if leg_stuck:
+            c4_steady = {"error": f"the C4 steady-state leg did not return within {C4_LEG_DEADLINE_S} s on rank {rank}: a rank is waiting in the exchange"} if rank == 0 else None
+        elif "error" in leg:
+            c4_steady = {"error": leg["error"]} if rank == 0 else None
+        else:
+            c4_steady = leg.get("out")
     if rank == 0:
         sid = all_hits["seq_id"].astype(np.int64)
         order_ok = bool(np.all((np.diff(sid) > 0) | ((np.diff(sid) == 0) & (np.diff(all_hits["i"].astype(np.int64)) > 0)))) if len(all_hits) > 1 else True
@@ -1526,10 +1553,22 @@ def main():
     if stuck:  # a thread is still inside the collective: the line is out, leave without the teardown that would wait for it
         sys.stdout.flush()
         os._exit(rc or 4)
+    if leg_stuck:  # the same for the side leg -- whose failure is in the line (configs.c4.error) and does not void `value`
+        sys.stdout.flush()
+        os._exit(rc)
     plan.close()
     if use_dist:
+        watchdog = None
+        if world > 1:  # (a peer whose side leg hung has left without the teardown: do not wait for it for ever -- the line is out)
+            import threading
+
+            watchdog = threading.Timer(60.0, lambda: (sys.stdout.flush(), os._exit(rc)))
+            watchdog.daemon = True
+            watchdog.start()
         dist.barrier()
         dist.destroy_process_group()
+        if watchdog:
+            watchdog.cancel()
     if rc:
         sys.exit(rc)
 

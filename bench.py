@@ -272,9 +272,14 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
     _, fc_all = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0)
     first, fc = capi.frequency_table(FS, 0.0, n_centres * USE_BW * FS, USE_BW, 0.0, shard=rank, n_shards=world)
     shard = len(fc)
-    S = (max(1, 8192 // shard) if sweeps_per_launch == 0 else sweeps_per_launch) if shard < 8192 else 1
+    # what every rank must agree on -- the number of posts per sweep and the size of a message -- comes from the LARGEST shard (ranks of
+    # a ragged split differ by one centre; N = 1, 2, 4, 8 split 16384 evenly)
+    max_shard = -(-n_centres // world)
+    S = (max(1, 8192 // max_shard) if sweeps_per_launch == 0 else sweeps_per_launch) if max_shard < 8192 else 1
     nb = min(shard, 8192) * S                # buffers per launch
     chunks = [(lo, min(lo + 8192, shard)) for lo in range(0, shard, 8192)] if S == 1 else [(0, nb)]
+    n_chunks_all = -(-max_shard // 8192) if S == 1 else 1
+    assert len(chunks) == n_chunks_all, "ranks would post different numbers of lists per sweep"
     centres, i0 = synth.c4_emitters(n_centres, n)
     step_bytes = shard * n * 12
     R = max(2, -(-(3 << 29) // step_bytes))
@@ -289,7 +294,7 @@ def c4_gather_leg(torch, dev, local_rank, rank, world, n_centres, steps, warm=60
     warm = -(-warm // S) * S
     D, LAG = 4, 2
     hit_cap = nb * 64
-    cap = 7 * (-(-nb // 4) + S) * 2          # per launch: an emitter on every 4th centre, seven bins each, and as much again
+    cap = 7 * (-(-(min(max_shard, 8192) * S) // 4) + S) * 2   # per launch: an emitter on every 4th centre, seven bins each, and as much again (the same on every rank)
     flags = capi.OUT_SPECTRUM | capi.OUT_HITS | (capi.PLAN_OVERLAP_SLOTS if nb < 8192 else 0)
     plan = Plan(n, FS, threshold, max_batch=min(nb, 8192 * S), max_hits=hit_cap, device_id=local_rank, flags=flags)
     plan.set_table(fc)

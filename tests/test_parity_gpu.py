@@ -959,6 +959,31 @@ def test_counts_by_kernel_stores_and_by_dma_agree(torch_cuda, oracle_mod):
             assert np.array_equal(np.bincount(h["seq_id"].astype(np.int64), minlength=count), c_ref[:count])
 
 
+@pytest.mark.parametrize("n", [1024, 3000, 4096, 8192, 16384, 65536])
+def test_hip_against_rocfft_through_torch(torch_cuda, n):
+    """A third opinion on the transform, on the same GPU: torch.fft.fft on complex64 runs the vendor's FFT library (rocFFT / hipFFT) --
+    another independent production float32 FFT, never on the product path.  Both it and the HIP kernels sit a few 1e-6 from the
+    float64 spectrum and within the 1e-5 bar of each other (the plan's own window table multiplies both)."""
+    torch = torch_cuda
+    nb = 12 if n < 65536 else 4
+    x = synth.cfloat_batch(n, nb, seed=77 + n)
+    with Plan(n, FS, 1e9, max_batch=nb) as plan:
+        w = plan.window()
+        plan.submit_device(0, _to_dev(torch, x), nb)
+        p, _, _ = plan.collect(0)
+    xw = torch.from_numpy(x).cuda() * torch.from_numpy(w).cuda()                 # float32 multiply, as VOLK's kernel does
+    X = torch.fft.fft(xw, dim=-1)                                                # complex64: the vendor library's float32 transform
+    P = (X.real.double() ** 2 + X.imag.double() ** 2).cpu().numpy()
+    with np.errstate(divide="ignore"):
+        db_vendor = 5.0 * np.log10(P)
+    X64 = np.fft.fft(x.astype(np.complex128) * w.astype(np.float64), axis=-1)
+    with np.errstate(divide="ignore"):
+        db64 = 5.0 * np.log10(X64.real ** 2 + X64.imag ** 2)
+    print(n, "HIP vs rocFFT float32:", tol.compare_spectra(p, db_vendor)["max_rel_power_vs_max_bin_mean"],
+          "| rocFFT vs float64:", tol.compare_spectra(db_vendor, db64)["max_rel_power_vs_max_bin_mean"],
+          "| HIP vs float64:", tol.compare_spectra(p, db64)["max_rel_power_vs_max_bin_mean"])
+
+
 @pytest.mark.parametrize("wt", ["HAMMING", "HANN", "BLACKMAN", "RECTANGULAR", "KAISER", "BLACKMAN_HARRIS", "BARTLETT", "FLATTOP"])
 def test_every_window_type(torch_cuda, oracle_mod, wt):
     """process.cpp:18 hands any gr::fft::window::win_type to window::build: the plan's table has the oracle's bits for each, and the

@@ -274,7 +274,82 @@ static void test_failures_are_reported() {
   q.SetIsDone();
 }
 
+// The staging rings of SampleQueue::AttachStaging, single-threaded and deterministic: what is queued before the first attach is handed
+// out first (unstaged, with a slot reserved), then every append lands IN PLACE in a consumer's slot, the batches dealt to the rings in
+// turn, each ring seeing increasing sequence ids; a sealed slot makes the producer move on; a detached ring takes its queued messages
+// with it and the other ring goes on; with the last ring gone appends are pooled messages again.
+static void test_staging_rings() {
+  const uint32_t n = 8, cap = 3, slots = 2;
+  const size_t bytes = n * 4;
+  SampleQueue q(SampleQueue::ShortComplex, 12, n, 64, false, false);
+  int16_t buf[n][2];
+  uint32_t tag = 0;
+  auto append = [&](time_t t = 0) {
+    for (uint32_t i = 0; i < n; i++) buf[i][0] = buf[i][1] = (int16_t)tag;
+    q.AppendSamples(buf, 1e6 * tag, t);
+    tag++;
+  };
+  append(1);      // the discarded warm-up sweep
+  append(2);      // seq 0: from here on messages flow
+  append();       // seq 1 -- both queued BEFORE any consumer attaches
+  std::vector<unsigned char> mem[2][slots];
+  void *bases[2][slots];
+  for (int r = 0; r < 2; r++)
+    for (uint32_t k = 0; k < slots; k++) {
+      mem[r][k].assign(bytes * cap, 0xee);
+      bases[r][k] = mem[r][k].data();
+    }
+  const int r0 = q.AttachStaging(bases[0], slots, cap), r1 = q.AttachStaging(bases[1], slots, cap);
+  CHECK(r0 == 0 && r1 == 1 && q.GetQueuedAtAttachCount() == 2);
+  CHECK(q.AttachStaging(bases[0], slots, cap + 1) == -1);  // one batch size for all the consumers of a queue
+  std::vector<SampleQueue::MessageType *> out;
+  int slot = -1;
+  // the unstaged ones first: whoever asks gets them with its next slot reserved, and copies them itself
+  CHECK(q.TakeStagedBatch(r1, out, &slot, false) == 2 && slot == 0 && out[0]->GetStagingSlot() < 0 && out[0]->GetHeader().m_sequenceId == 0 &&
+        out[1]->GetHeader().m_sequenceId == 1);
+  for (auto *m : out) q.MessageProcessed(m);
+  out.clear();
+  CHECK(q.TakeStagedBatch(r0, out, &slot, false) == 0);
+  // now every append lands in place; batches of `cap` go to the rings in turn -- a new batch starts in the ring AFTER the one filled
+  // last: ring 1 first (its slot 0 is reserved: slot 1), then ring 0, then -- ring 1 having no usable slot -- ring 0 again
+  for (int k = 0; k < 7; k++) append();  // seq 2 .. 8
+  CHECK(q.GetStagedAppendCount() == 7 && q.GetCopiedAppendCount() == 2);
+  CHECK(q.TakeStagedBatch(r1, out, &slot, false) == 3 && slot == 1);
+  CHECK(out[0]->GetHeader().m_sequenceId == 2 && out[2]->GetHeader().m_sequenceId == 4 && out[1]->GetRawData() == mem[1][1].data() + bytes);
+  CHECK(((int16_t *)mem[1][1].data())[0] == 3 && ((int16_t *)(mem[1][1].data() + 2 * bytes))[0] == 5);  // tags 3, 4, 5 = seq 2, 3, 4: IN the slot
+  out.clear();
+  CHECK(q.TakeStagedBatch(r0, out, &slot, false) == 3 && slot == 0 && out[0]->GetHeader().m_sequenceId == 5 && out[0]->GetRawData() == mem[0][0].data());
+  out.clear();
+  CHECK(q.TakeStagedBatch(r0, out, &slot, false) == 1 && slot == 1 && out[0]->GetHeader().m_sequenceId == 8);  // a partial batch, sealed by being taken
+  out.clear();
+  // ring 0: slot 0 in flight (never released), slot 1 just sealed; ring 1: slot 0 reserved, slot 1 in flight -> nothing usable: release one
+  q.ReleaseStaging(r1, 0);
+  append();  // seq 9 -> ring 1, slot 0
+  append();  // seq 10: the batch in progress goes on in the same slot
+  CHECK(q.TakeStagedBatch(r0, out, &slot, false) == 0);
+  CHECK(q.TakeStagedBatch(r1, out, &slot, false) == 2 && slot == 0 && out[0]->GetHeader().m_sequenceId == 9 && out[1]->GetRawData() == mem[1][0].data() + bytes);
+  out.clear();
+  // a consumer that leaves takes its queued messages with it; the other ring goes on
+  q.ReleaseStaging(r0, 0);
+  append();  // seq 11 -> ring 0, slot 0
+  q.DetachStaging(r0);
+  CHECK(q.TakeStagedBatch(r0, out, &slot, false) == 0);
+  q.ReleaseStaging(r1, 1);
+  append();  // seq 12 -> ring 1 (the only one left), slot 1
+  CHECK(q.TakeStagedBatch(r1, out, &slot, false) == 1 && slot == 1 && out[0]->GetHeader().m_sequenceId == 12);
+  out.clear();
+  // the last ring gone: appends are pooled messages again, taken the reference's way
+  q.DetachStaging(r1);
+  append();  // seq 13
+  SampleQueue::MessageType *m = q.TryGetNextSamples();
+  CHECK(m && m->GetStagingSlot() < 0 && m->GetHeader().m_sequenceId == 13 && ((int16_t *)m->GetRawData())[0] == (int16_t)(tag - 1));
+  q.MessageProcessed(m);
+  q.SetIsDone();
+  CHECK(q.GetNextSamples() == nullptr);
+}
+
 int main() {
+  test_staging_rings();
   test_capture_retrigger_while_draining();
   test_failures_are_reported();
   test_queue_basic();

@@ -3,7 +3,8 @@
 Every case draws a size, wire format, ENOB, DC flag, sample rate, threshold, output flags, overlapped-slots flag and a short
 sequence of launches with random batch sizes over both slots; spectra are held to tests/tolerances.py, hit lists
 and trigger flags must be identical wherever no evaluated bin sits within the guard band of the threshold.  One case in
-sixteen is a Welch plan (BASELINE C5): K, PSDs per submit, wire format and DC drawn, device and pinned/hipGraph submits."""
+sixteen is a Welch plan (BASELINE C5): K, PSDs per submit, wire format and DC drawn, device and pinned/hipGraph submits.
+FUZZ_SIZES=8192,... restricts the sizes drawn; FUZZ_WELCH_ONLY=1 makes every case a Welch plan."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -118,7 +119,7 @@ def run(budget, seed, plans=None):
         # 16 ... 512: several buffers per workgroup; 65536, 32768: the four-step pairs; 1000, 6000: the mixed-radix fused kernels; 1023: the staged path (Bluestein)
         sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else \
             [1024, 2048, 4096, 8192, 16384, 16384, 256, 512, 65536, 32768, 1000, 6000, 12000, 1023, 16, 32, 64, 128]
-        if not os.environ.get("FUZZ_SIZES") and rng_f.random() < 1.0 / 16.0:
+        if os.environ.get("FUZZ_WELCH_ONLY") or (not os.environ.get("FUZZ_SIZES") and rng_f.random() < 1.0 / 16.0):
             launches += welch_case(rng_f)
             cases += 1
             continue
